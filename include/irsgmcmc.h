@@ -1,0 +1,218 @@
+/*
+ * irsgmcmc.h -- C ABI of the MI355X-native SG-MCMC registration inner loop.
+ *
+ * Drop-in boundary for ONE path of dgrzech/ir-sgmcmc: `Trainer._SGLD_transition`
+ * (reference trainer/trainer.py:291-356) and the operators it is built from.  The reference has no
+ * FFI of its own -- its extension point is name-based construction of Python classes from JSON
+ * (parse_config.py:251-266) -- so every entry point below cites the reference call site it replaces.
+ * Python binds this header with ctypes (ir_sgmcmc_amd/_lib.py); see INTEGRATION.md.
+ *
+ * Conventions
+ *  - every `float*` / `uint8_t*` argument is a CALLER-OWNED DEVICE pointer (e.g. torch allocation);
+ *    fields are planar fp32 (C, 3, D, H, W), images (C, 1, D, H, W), channel 0 = x = last axis
+ *    (utils/util.py:263-278); masks are 1 byte per voxel (torch.bool).
+ *  - `stream` is a hipStream_t passed as void*; all work is asynchronous on it, nothing synchronises
+ *    except the functions documented as "blocking".
+ *  - every function returns 0 on success, non-zero on error (irs_last_error() gives the message);
+ *    nothing aborts or throws across the boundary; no internal threads.
+ *  - a context is not thread-safe; distinct contexts / streams are independent.
+ */
+#ifndef IRSGMCMC_H
+#define IRSGMCMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRS_MAX_COMPONENTS 8
+#define IRS_MAX_CHAINS 8
+#define IRS_MAX_HALF_WIDTH 4 /* Sobolev / LCC half widths up to 4 */
+
+enum { IRS_DATA_GMM_LCC = 0, IRS_DATA_SSD = 1 };
+enum { IRS_REG_L2 = 0, IRS_REG_LOGNORMAL = 1 };
+
+/* ------------------------------------------------------------------------------------------------
+ * stateless operators (unit-parity surface; the Python modules SVF_3D, RegistrationModule, GMM.map,
+ * GradientOperator ... call these)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* SGLD.forward + SobolevGrad.forward: out = S * (v + sqrt(2 tau) sigma eps)
+ * (utils/functions.py:76-84,98-109; utils/util.py:48-58,394-404).
+ * v, out, tmp: (C,3,D,H,W).  sigma: NULL (=1) or (C,3,D,H,W).  eps: standard-normal tensor, or NULL ->
+ * in-kernel Philox4x32-10 keyed by (seed, iteration).  kernel: 2s+1 host floats; s == 0 -> no smoothing.
+ * tau < 0 -> no noise.  `tmp` may not alias v or out; out may not alias v. */
+int irs_perturb_smooth(const float* v, const float* sigma, const float* eps, float tau, const float* kernel, int s,
+                       int C, int D, int H, int W, float* tmp, float* out, uint64_t seed, uint64_t iteration,
+                       void* stream);
+
+/* SVF_3D.forward (utils/transformation.py:63-76): scaling and squaring.
+ * v: (C,3,D,H,W) voxel units.  steps: (no_steps, C,3,D,H,W) workspace receiving d_1..d_no_steps in
+ * normalised units (kept for the backward).  transformation / displacement: outputs, either may be NULL. */
+int irs_svf_exp_fwd(const float* v, float* steps, float* transformation, float* displacement, int no_steps, int C,
+                    int D, int H, int W, void* stream);
+
+/* adjoint of the above w.r.t. v (what autograd does through the 12 grid_sample calls).
+ * g_last: gradient w.r.t. d_no_steps (normalised units), (C,3,D,H,W).  g_v: output, gradient w.r.t. v.
+ * scratch: 2 x (C,3,D,H,W).  Accumulates with float atomics (order-dependent in the last bits). */
+int irs_svf_exp_bwd(const float* v, const float* steps, const float* g_last, float* scratch, float* g_v, int no_steps,
+                    int C, int D, int H, int W, void* stream);
+
+/* Cubic_B_spline_FFD_3D.forward (utils/transformation.py:126-153) and its adjoint.
+ * v_cp: (C,3,G0,G1,G2), G = ceil((N-1)/cps)+3; dense: (C,3,D,H,W); tmp: 2 x (C,3,D,H,W) scratch. */
+int irs_ffd_up(const float* v_cp, float* dense, float* tmp, int C, int D, int H, int W, int c0, int c1, int c2,
+               void* stream);
+int irs_ffd_adjoint(const float* g_dense, float* g_cp, float* tmp, int C, int D, int H, int W, int c0, int c1, int c2,
+                    void* stream);
+
+/* RegistrationModule.forward, float path (utils/registration.py:29-30) with the optional uniform grid
+ * jitter of utils/util.py:44-53 folded in.  im: (Cim,1,D,H,W) with Cim in {1, C} (1 = shared by all chains).
+ * d_last: d_no_steps in normalised units (C,3,D,H,W).  unif: U[0,1) tensor (C,3,D,H,W), or NULL -> Philox when
+ * alpha > 0.  alpha <= 0 -> no jitter. */
+int irs_warp_fwd(const float* im, int Cim, const float* d_last, const float* unif, float alpha, float* warped, int C,
+                 int D, int H, int W, uint64_t seed, uint64_t iteration, void* stream);
+/* grid-gradient of the warp: g_d = dL/d(d_last) given g_warped (C,1,D,H,W). */
+int irs_warp_bwd(const float* im, int Cim, const float* d_last, const float* unif, float alpha, const float* g_warped,
+                 float* g_d, int C, int D, int H, int W, uint64_t seed, uint64_t iteration, void* stream);
+/* same warp applied to an arbitrary transformation tensor in [-1,1] (the public RegistrationModule call) */
+int irs_warp_transformation(const float* im, int Cim, const float* transformation, float* warped, int C, int D, int H,
+                            int W, void* stream);
+/* nearest-neighbour path for masks (uint8) and label maps (int16) (utils/registration.py:20-27) */
+int irs_warp_nearest_u8(const uint8_t* seg, int Cim, const float* transformation, uint8_t* out, int C, int D, int H,
+                        int W, void* stream);
+int irs_warp_nearest_i16(const int16_t* seg, int Cim, const float* transformation, int16_t* out, int C, int D, int H,
+                         int W, void* stream);
+
+/* LCC normalisation (I - u) / sqrt(var + 1e-10) of model/loss.py:103-109; sigma_out may be NULL. */
+int irs_lcc_normalise(const float* im, float* out, float* sigma_out, int s, int C, int D, int H, int W, void* stream);
+/* GMM.map (model/loss.py:102-111) with the fixed side pre-normalised: z = fhat - LCC(warped).
+ * fhat: (Cf,1,D,H,W), Cf in {1,C}.  sigma_m: output, local std of the warped image (kept for the adjoint). */
+int irs_lcc_map_fwd(const float* fhat, int Cf, const float* warped, float* z, float* sigma_m, int s, int C, int D,
+                    int H, int W, void* stream);
+/* adjoint of GMM.map w.r.t. the warped image given g_z. */
+int irs_lcc_map_bwd(const float* fhat, int Cf, const float* z, const float* sigma_m, const float* g_z, float* g_warped,
+                    int s, int C, int D, int H, int W, void* stream);
+
+/* GradientOperator + energy (utils/diff_op.py:78-96, model/loss.py:158-159): y[c] = sum (fwd diff)^2.
+ * y_out: C doubles on the device.  partials: scratch of irs_reduce_scratch_doubles() doubles. */
+int irs_reg_energy(const float* v, double* y_out, double* partials, int C, int D, int H, int W, void* stream);
+size_t irs_reduce_scratch_doubles(void);
+/* GradientOperator.forward: nabla (C,3,D,H,W,3) as in utils/diff_op.py:92-96; transformation != 0 divides by the
+ * pixel spacing 2/(N-1). */
+int irs_gradient_operator(const float* v, float* nabla, int transformation, int C, int D, int H, int W, void* stream);
+/* calc_det_J of GradientOperator(transformation=True) + NaN count of its log (utils/util.py:72-91,209-212).
+ * log_det: (C,1,D,H,W) or NULL; nan_count: C int64 on the device (zeroed by the call). */
+int irs_log_det_jacobian(const float* transformation, float* log_det, long long* nan_count, int C, int D, int H, int W,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fused transition (Trainer._SGLD_transition, trainer/trainer.py:291-356)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct irs_config {
+    int32_t dims[3];        /* D, H, W of the images */
+    int32_t cps[3];         /* control point spacing; all 0 -> SVF_3D, else SVFFD_3D */
+    int32_t no_chains;      /* C */
+    int32_t no_steps;       /* 12 */
+    int32_t sobolev_s;      /* 0 -> disabled */
+    float sobolev_kernel[2 * IRS_MAX_HALF_WIDTH + 1];
+    float lr;               /* optimizer_SG_MCMC lr == tau (trainer.py:607) */
+    float uniform_alpha;    /* <= 0 -> disabled */
+    int32_t virtual_decimation;
+    int32_t data_loss;      /* IRS_DATA_* */
+    int32_t lcc_s;
+    int32_t gmm_components;
+    float ssd_sigma;
+    /* optimizer_GMM (optimizers/adam_rate_decay.py) + hyper-priors (trainer.py:68-77) */
+    float gmm_lr_log_std, gmm_lr_logits, gmm_lr_decay;
+    float adam_beta1, adam_beta2, adam_eps;
+    float scale_prior_loc, scale_prior_scale;             /* LogScaleNormalPrior */
+    float dirichlet_concentration[IRS_MAX_COMPONENTS];    /* DirichletPrior */
+    /* regulariser (model/loss.py:172-312) */
+    int32_t reg_loss;       /* IRS_REG_* */
+    int32_t reg_learnable;
+    float w_reg;
+    double dof;             /* 3 * prod(image dims), parse_config.py:120,128 */
+    float reg_lr0, reg_lr1, reg_lr_decay; /* (lr_loc, lr_log_scale) or (lr_log_w_reg, -) */
+    float loc_prior_nu, loc_prior_w_reg;  /* LogEnergyExpGammaPrior */
+    float reg_scale_prior_loc, reg_scale_prior_scale; /* LogScaleNormalPrior on log_scale */
+    double w_reg_prior_shape, w_reg_prior_rate;       /* LogPrecisionExpGammaPrior */
+    uint64_t seed;          /* Philox key for in-kernel noise */
+} irs_config;
+
+/* hyper-parameter + optimiser state that lives on the device between transitions */
+typedef struct irs_state {
+    float gmm_log_std[IRS_MAX_COMPONENTS];
+    float gmm_logits[IRS_MAX_COMPONENTS];
+    double gmm_adam_m[2][IRS_MAX_COMPONENTS];
+    double gmm_adam_v[2][IRS_MAX_COMPONENTS];
+    int64_t gmm_adam_step[2];
+    double reg_param[2];     /* L2: {log_w_reg, -}; LogNormal: {loc, log_scale} */
+    double reg_adam_m[2], reg_adam_v[2];
+    int64_t reg_adam_step[2];
+    uint64_t iteration;      /* Philox counter, incremented by every transition */
+} irs_state;
+
+/* per-transition scalars (loss_terms / aux of the reference's return triple) */
+typedef struct irs_scalars {
+    double alpha[IRS_MAX_CHAINS];       /* VD factor */
+    double data_term[IRS_MAX_CHAINS];   /* alpha * sum(-log p(z)) */
+    double reg_term[IRS_MAX_CHAINS];
+    double reg_energy[IRS_MAX_CHAINS];  /* y */
+    double n_mask[IRS_MAX_CHAINS];
+} irs_scalars;
+
+typedef struct irs_io {
+    const float* fixed_im;   /* (Cf,1,D,H,W) */
+    const float* moving_im;  /* (Cm,1,D,H,W) */
+    const uint8_t* mask;     /* (Cmask,1,D,H,W) */
+    int32_t fixed_chains, moving_chains, mask_chains; /* 1 (shared) or C */
+    float* v;                /* (C,3,Dv,Hv,Wv) in/out: v_curr_state */
+    const float* sigma;      /* (C,3,Dv,Hv,Wv) or NULL (= 1) */
+    const float* eps;        /* injected N(0,1) noise or NULL (Philox) */
+    const float* unif;       /* injected U[0,1) noise (C,3,D,H,W) or NULL (Philox) */
+    /* outputs (caller-owned; any may be NULL to skip) */
+    float* curr_state;       /* (C,3,Dv,Hv,Wv) smoothed velocity = the recorded sample */
+    float* im_moving_warped; /* (C,1,D,H,W) */
+    float* residuals;        /* (C,1,D,H,W) dense z */
+    float* displacement;     /* (C,3,D,H,W) voxels */
+    float* transformation;   /* (C,3,D,H,W) [-1,1] */
+    float* grad_v;           /* (C,3,Dv,Hv,Wv) dL/dv before the sigma^2 / lr scaling (debug / parity) */
+} irs_io;
+
+typedef struct irs_ctx irs_ctx;
+
+/* allocates the workspace (saved scaling-and-squaring steps, gradients, tile scratch) with hipMalloc. blocking. */
+int irs_create(const irs_config* cfg, irs_ctx** out);
+void irs_destroy(irs_ctx* ctx);
+size_t irs_workspace_bytes(const irs_ctx* ctx);
+/* control-grid size for the configured transformation model (utils/util.py:61-69) */
+int irs_velocity_dims(const irs_ctx* ctx, int32_t out[3]);
+
+/* pre-normalise the fixed image for the LCC map (iteration-invariant half of model/loss.py:103-105). */
+int irs_set_fixed(irs_ctx* ctx, const float* fixed_im, int fixed_chains, void* stream);
+/* blocking copies of the small state / scalars */
+int irs_get_state(irs_ctx* ctx, irs_state* out, void* stream);
+int irs_set_state(irs_ctx* ctx, const irs_state* in, void* stream);
+int irs_get_scalars(irs_ctx* ctx, irs_scalars* out, void* stream);
+
+/* Trainer.__GMM_init (trainer/trainer.py:529-547): init log_std from std(z[mask]) at the given velocity sample
+ * (NULL = zero field), then `warm_up` _step_GMM iterations.  blocking (reads one scalar back). */
+int irs_gmm_init(irs_ctx* ctx, const irs_io* io, const float* v_sample, int warm_up, void* stream);
+
+/* one SG-MCMC transition; asynchronous, graph-capturable (no allocation, no host sync) */
+int irs_transition(irs_ctx* ctx, const irs_io* io, void* stream);
+
+/* timing hook for bench.py: average duration in ms of the dominant kernel family (scaling-and-squaring
+ * forward+backward) measured with hipEvents on `stream` over the LAST call of irs_transition_timed. blocking. */
+int irs_transition_timed(irs_ctx* ctx, const irs_io* io, void* stream, float* ms_total, float* ms_exp);
+
+const char* irs_last_error(void);
+const char* irs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRSGMCMC_H */

@@ -1,0 +1,702 @@
+// C ABI (include/irsgmcmc.h): argument validation, workspace ownership and the launch sequence of one
+// SG-MCMC transition.  No exceptions / aborts cross this boundary; errors come back as codes + irs_last_error().
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "kernels.h"
+#include "scalar_kernels.h"
+
+using namespace irs;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+#define LAUNCH_CHECK()                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+bool dims_ok(int C, int D, int H, int W) {
+    return C >= 1 && D >= 2 && H >= 2 && W >= 2 && (int64_t)D * H * W < ((int64_t)1 << 40);
+}
+
+SplineTaps make_spline(int cps) {
+    // sampled cubic B-spline (utils/transformation.py:79-102); evaluated in double, stored as float like the reference
+    SplineTaps t;
+    memset(&t, 0, sizeof(t));
+    t.cps = cps;
+    const int n = 4 * cps - 1, r = n / 2;
+    for (int i = 0; i < n; ++i) {
+        const double x = fabs((double)(i - r) / (double)cps);
+        double v = 0.0;
+        if (x < 1.0) v = 2.0 / 3.0 + (0.5 * x - 1.0) * x * x;
+        else if (x < 2.0) v = -1.0 * ((x - 2.0) * (x - 2.0) * (x - 2.0)) / 6.0;
+        t.k[i] = (float)v;
+    }
+    return t;
+}
+
+int control_points(int n, int cps) { return (int)ceil((double)(n - 1) / (double)cps) + 1 + 2; }  // utils/util.py:61-69
+
+}  // namespace
+
+struct irs_ctx {
+    irs_config cfg;
+    DevCfg dcfg;
+    Vol vol, volv;
+    bool ffd;
+    int C;
+    LinTables lin;
+    Taps sob;
+    SplineTaps spl[3];
+    char* slab;
+    size_t slab_bytes;
+    // workspace views
+    float *steps, *tmpA, *tmpB, *vs, *gA, *gB, *warped, *z, *sigM, *fhat, *gM, *dense;
+    double *stat_partials, *energy_partials, *nll_partials;
+    DevState* state;
+    int fhat_chains;
+    bool fixed_set;
+    int nll_blocks;
+    hipEvent_t ev[6];
+};
+
+extern "C" {
+
+const char* irs_last_error(void) { return g_err; }
+const char* irs_version(void) { return "ir-sgmcmc-amd 0.1 (gfx950)"; }
+size_t irs_reduce_scratch_doubles(void) { return (size_t)kMaxPartialBlocks * IRS_MAX_CHAINS; }
+
+// ================================================================================================
+// stateless operators
+// ================================================================================================
+
+int irs_perturb_smooth(const float* v, const float* sigma, const float* eps, float tau, const float* kernel, int s,
+                       int C, int D, int H, int W, float* tmp, float* out, uint64_t seed, uint64_t iteration,
+                       void* stream) {
+    if (!v || !out || !dims_ok(C, D, H, W)) return fail("irs_perturb_smooth: bad arguments");
+    if (s < 0 || s > IRS_MAX_HALF_WIDTH || (s > 0 && (!kernel || !tmp))) return fail("irs_perturb_smooth: bad kernel/s");
+    if (s > 0 && (2 * s >= D || 2 * s >= H || 2 * s >= W)) return fail("irs_perturb_smooth: volume smaller than the kernel");
+    hipStream_t st = (hipStream_t)stream;
+    const Vol vol = make_vol(D, H, W);
+    const size_t bytes = (size_t)C * 3 * vol.V * sizeof(float);
+    if (s == 0) {
+        if (tau >= 0.0f) launch_perturb(v, sigma, eps, sqrtf(2.0f * tau), out, C, vol, seed, iteration, nullptr, st);
+        else HIP_TRY(hipMemcpyAsync(out, v, bytes, hipMemcpyDeviceToDevice, st));
+        LAUNCH_CHECK();
+        return 0;
+    }
+    Taps taps;
+    taps.s = s;
+    for (int i = 0; i <= 2 * s; ++i) taps.k[i] = kernel[i];
+    const float* src = v;
+    if (tau >= 0.0f) {
+        launch_perturb(v, sigma, eps, (float)sqrt(2.0 * (double)tau), out, C, vol, seed, iteration, nullptr, st);
+        src = out;
+    }
+    launch_conv_axis(src, tmp, taps, 2, C * 3, vol, st);   // z
+    launch_conv_axis(tmp, out, taps, 1, C * 3, vol, st);   // y
+    // x pass needs a third buffer: out -> tmp would leave the result in tmp; run x into tmp then copy back
+    launch_conv_axis(out, tmp, taps, 0, C * 3, vol, st);   // x
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int irs_svf_exp_fwd(const float* v, float* steps, float* transformation, float* displacement, int no_steps, int C,
+                    int D, int H, int W, void* stream) {
+    if (!v || !steps || !dims_ok(C, D, H, W) || no_steps < 1 || no_steps > 30) return fail("irs_svf_exp_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const Vol vol = make_vol(D, H, W);
+    Lin lin;
+    if (cached_lin(D, H, W, st, &lin)) return fail("irs_svf_exp_fwd: identity grid allocation failed");
+    const int64_t field = (int64_t)C * 3 * vol.V;
+    for (int k = 0; k < no_steps; ++k)
+        launch_exp_step_fwd(k == 0 ? v : steps + (int64_t)(k - 1) * field, steps + (int64_t)k * field, k == 0, no_steps, C,
+                            vol, lin, st);
+    if (transformation || displacement)
+        launch_svf_outputs(steps + (int64_t)(no_steps - 1) * field, transformation, displacement, C, vol, lin, st);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+static int exp_backward(const float* v, const float* steps, const float* g_last, float* gA, float* gB, int no_steps, int C,
+                        Vol vol, Lin lin, hipStream_t st, float** result) {
+    const int64_t field = (int64_t)C * 3 * vol.V;
+    const float* G = g_last;
+    float* bufs[2] = {gA, gB};
+    int cur = 0;
+    for (int k = no_steps - 1; k >= 0; --k) {
+        float* out = bufs[cur];
+        HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
+        launch_exp_step_bwd(G, k == 0 ? v : steps + (int64_t)(k - 1) * field, out, k == 0, no_steps, C, vol, lin, st);
+        G = out;
+        cur ^= 1;
+    }
+    *result = const_cast<float*>(G);
+    return 0;
+}
+
+static void prescale_factors(Vol vol, int no_steps, float s[3]) {
+    const double p = 1.0 / (double)(1 << no_steps);
+    s[0] = (float)(2.0 / (double)(vol.D - 1) * p);  // channel/dim pairing of utils/util.py:426-427 (sic)
+    s[1] = (float)(2.0 / (double)(vol.H - 1) * p);
+    s[2] = (float)(2.0 / (double)(vol.W - 1) * p);
+}
+
+int irs_svf_exp_bwd(const float* v, const float* steps, const float* g_last, float* scratch, float* g_v, int no_steps,
+                    int C, int D, int H, int W, void* stream) {
+    if (!v || !steps || !g_last || !scratch || !g_v || !dims_ok(C, D, H, W) || no_steps < 1 || no_steps > 30)
+        return fail("irs_svf_exp_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const Vol vol = make_vol(D, H, W);
+    Lin lin;
+    if (cached_lin(D, H, W, st, &lin)) return fail("irs_svf_exp_bwd: identity grid allocation failed");
+    const int64_t field = (int64_t)C * 3 * vol.V;
+    float* res = nullptr;
+    if (exp_backward(v, steps, g_last, scratch, scratch + field, no_steps, C, vol, lin, st, &res)) return 1;
+    float s[3];
+    prescale_factors(vol, no_steps, s);
+    launch_scale_channels(res, g_v, s[0], s[1], s[2], C, vol.V, st);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+static int ffd_up(const float* v_cp, float* dense, float* tmp, int C, Vol vol, const int G[3], const SplineTaps spl[3],
+                  hipStream_t st) {
+    // axis order of utils/transformation.py:146-149: tensor axis 2 (D, cps[0]), 3 (H, cps[1]), 4 (W, cps[2])
+    const int64_t CC = (int64_t)C * 3;
+    float* t1 = tmp;
+    float* t2 = tmp + CC * vol.D * G[1] * G[2];
+    launch_ffd_axis(v_cp, t1, spl[0], false, CC, G[0], vol.D, (int64_t)G[1] * G[2], st);
+    launch_ffd_axis(t1, t2, spl[1], false, CC * vol.D, G[1], vol.H, G[2], st);
+    launch_ffd_axis(t2, dense, spl[2], false, CC * vol.D * vol.H, G[2], vol.W, 1, st);
+    return 0;
+}
+
+static int ffd_adjoint(const float* g_dense, float* g_cp, float* tmp, int C, Vol vol, const int G[3],
+                       const SplineTaps spl[3], hipStream_t st) {
+    const int64_t CC = (int64_t)C * 3;
+    float* t1 = tmp;
+    float* t2 = tmp + CC * vol.D * vol.H * G[2];
+    launch_ffd_axis(g_dense, t1, spl[2], true, CC * vol.D * vol.H, vol.W, G[2], 1, st);
+    launch_ffd_axis(t1, t2, spl[1], true, CC * vol.D, vol.H, G[1], G[2], st);
+    launch_ffd_axis(t2, g_cp, spl[0], true, CC, vol.D, G[0], (int64_t)G[1] * G[2], st);
+    return 0;
+}
+
+int irs_ffd_up(const float* v_cp, float* dense, float* tmp, int C, int D, int H, int W, int c0, int c1, int c2,
+               void* stream) {
+    if (!v_cp || !dense || !tmp || !dims_ok(C, D, H, W) || c0 < 1 || c1 < 1 || c2 < 1 || c0 > 8 || c1 > 8 || c2 > 8)
+        return fail("irs_ffd_up: bad arguments");
+    const Vol vol = make_vol(D, H, W);
+    const int G[3] = {control_points(D, c0), control_points(H, c1), control_points(W, c2)};
+    const SplineTaps spl[3] = {make_spline(c0), make_spline(c1), make_spline(c2)};
+    ffd_up(v_cp, dense, tmp, C, vol, G, spl, (hipStream_t)stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_ffd_adjoint(const float* g_dense, float* g_cp, float* tmp, int C, int D, int H, int W, int c0, int c1, int c2,
+                    void* stream) {
+    if (!g_dense || !g_cp || !tmp || !dims_ok(C, D, H, W) || c0 < 1 || c1 < 1 || c2 < 1 || c0 > 8 || c1 > 8 || c2 > 8)
+        return fail("irs_ffd_adjoint: bad arguments");
+    const Vol vol = make_vol(D, H, W);
+    const int G[3] = {control_points(D, c0), control_points(H, c1), control_points(W, c2)};
+    const SplineTaps spl[3] = {make_spline(c0), make_spline(c1), make_spline(c2)};
+    ffd_adjoint(g_dense, g_cp, tmp, C, vol, G, spl, (hipStream_t)stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_warp_fwd(const float* im, int Cim, const float* d_last, const float* unif, float alpha, float* warped, int C,
+                 int D, int H, int W, uint64_t seed, uint64_t iteration, void* stream) {
+    if (!im || !d_last || !warped || !dims_ok(C, D, H, W) || (Cim != 1 && Cim != C)) return fail("irs_warp_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const Vol vol = make_vol(D, H, W);
+    Lin lin;
+    if (cached_lin(D, H, W, st, &lin)) return fail("irs_warp_fwd: identity grid allocation failed");
+    launch_warp_fwd(im, Cim == 1 ? 0 : vol.V, d_last, unif, alpha, warped, C, vol, lin, seed, iteration, nullptr, st);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_warp_bwd(const float* im, int Cim, const float* d_last, const float* unif, float alpha, const float* g_warped,
+                 float* g_d, int C, int D, int H, int W, uint64_t seed, uint64_t iteration, void* stream) {
+    if (!im || !d_last || !g_warped || !g_d || !dims_ok(C, D, H, W) || (Cim != 1 && Cim != C))
+        return fail("irs_warp_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const Vol vol = make_vol(D, H, W);
+    Lin lin;
+    if (cached_lin(D, H, W, st, &lin)) return fail("irs_warp_bwd: identity grid allocation failed");
+    launch_warp_bwd(im, Cim == 1 ? 0 : vol.V, d_last, unif, alpha, g_warped, g_d, C, vol, lin, seed, iteration, nullptr, st);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_warp_transformation(const float* im, int Cim, const float* transformation, float* warped, int C, int D, int H,
+                            int W, void* stream) {
+    if (!im || !transformation || !warped || !dims_ok(C, D, H, W) || (Cim != 1 && Cim != C))
+        return fail("irs_warp_transformation: bad arguments");
+    const Vol vol = make_vol(D, H, W);
+    launch_warp_transformation(im, Cim == 1 ? 0 : vol.V, transformation, warped, C, vol, (hipStream_t)stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_warp_nearest_u8(const uint8_t* seg, int Cim, const float* transformation, uint8_t* out, int C, int D, int H,
+                        int W, void* stream) {
+    if (!seg || !transformation || !out || !dims_ok(C, D, H, W) || (Cim != 1 && Cim != C))
+        return fail("irs_warp_nearest_u8: bad arguments");
+    const Vol vol = make_vol(D, H, W);
+    launch_warp_nearest_u8(seg, Cim == 1 ? 0 : vol.V, transformation, out, C, vol, (hipStream_t)stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_warp_nearest_i16(const int16_t* seg, int Cim, const float* transformation, int16_t* out, int C, int D, int H,
+                         int W, void* stream) {
+    if (!seg || !transformation || !out || !dims_ok(C, D, H, W) || (Cim != 1 && Cim != C))
+        return fail("irs_warp_nearest_i16: bad arguments");
+    const Vol vol = make_vol(D, H, W);
+    launch_warp_nearest_i16(seg, Cim == 1 ? 0 : vol.V, transformation, out, C, vol, (hipStream_t)stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+static bool lcc_ok(int s, int D, int H, int W) { return (s == 1 || s == 2) && D > 2 * s && H > 2 * s && W > 2 * s; }
+
+int irs_lcc_normalise(const float* im, float* out, float* sigma_out, int s, int C, int D, int H, int W, void* stream) {
+    if (!im || !out || !dims_ok(C, D, H, W)) return fail("irs_lcc_normalise: bad arguments");
+    if (!lcc_ok(s, D, H, W)) return fail("irs_lcc_normalise: LCC half width must be 1 or 2 and smaller than half the volume");
+    launch_lcc_fwd(nullptr, 0, im, out, sigma_out, s, C, make_vol(D, H, W), (hipStream_t)stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_lcc_map_fwd(const float* fhat, int Cf, const float* warped, float* z, float* sigma_m, int s, int C, int D,
+                    int H, int W, void* stream) {
+    if (!fhat || !warped || !z || !sigma_m || !dims_ok(C, D, H, W) || (Cf != 1 && Cf != C))
+        return fail("irs_lcc_map_fwd: bad arguments");
+    if (!lcc_ok(s, D, H, W)) return fail("irs_lcc_map_fwd: LCC half width must be 1 or 2 and smaller than half the volume");
+    const Vol vol = make_vol(D, H, W);
+    launch_lcc_fwd(fhat, Cf == 1 ? 0 : vol.V, warped, z, sigma_m, s, C, vol, (hipStream_t)stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_lcc_map_bwd(const float* fhat, int Cf, const float* z, const float* sigma_m, const float* g_z, float* g_warped,
+                    int s, int C, int D, int H, int W, void* stream) {
+    if (!fhat || !z || !sigma_m || !g_z || !g_warped || !dims_ok(C, D, H, W) || (Cf != 1 && Cf != C))
+        return fail("irs_lcc_map_bwd: bad arguments");
+    if (!lcc_ok(s, D, H, W)) return fail("irs_lcc_map_bwd: LCC half width must be 1 or 2 and smaller than half the volume");
+    const Vol vol = make_vol(D, H, W);
+    for (int c = 0; c < C; ++c)
+        launch_data_bwd(IRS_DATA_GMM_LCC, fhat + (Cf == 1 ? 0 : (int64_t)c * vol.V), 0, z + (int64_t)c * vol.V,
+                        sigma_m + (int64_t)c * vol.V, nullptr, 0, g_z + (int64_t)c * vol.V, nullptr, c,
+                        g_warped + (int64_t)c * vol.V, nullptr, s, 1, vol, (hipStream_t)stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_reg_energy(const float* v, double* y_out, double* partials, int C, int D, int H, int W, void* stream) {
+    if (!v || !y_out || !partials || !dims_ok(C, D, H, W) || C > IRS_MAX_CHAINS) return fail("irs_reg_energy: bad arguments");
+    const Vol vol = make_vol(D, H, W);
+    launch_reg_energy(v, partials, C, vol, (hipStream_t)stream);
+    launch_reduce_partials(partials, energy_blocks(vol), C, y_out, (hipStream_t)stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_gradient_operator(const float* v, float* nabla, int transformation, int C, int D, int H, int W, void* stream) {
+    if (!v || !nabla || !dims_ok(C, D, H, W)) return fail("irs_gradient_operator: bad arguments");
+    launch_gradient_operator(v, nabla, transformation, C, make_vol(D, H, W), (hipStream_t)stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_log_det_jacobian(const float* transformation, float* log_det, long long* nan_count, int C, int D, int H, int W,
+                         void* stream) {
+    if (!transformation || !nan_count || !dims_ok(C, D, H, W)) return fail("irs_log_det_jacobian: bad arguments");
+    launch_log_det_jacobian(transformation, log_det, nan_count, C, make_vol(D, H, W), (hipStream_t)stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ================================================================================================
+// context
+// ================================================================================================
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int irs_create(const irs_config* cfg, irs_ctx** out) {
+    if (!cfg || !out) return fail("irs_create: null argument");
+    const int D = cfg->dims[0], H = cfg->dims[1], W = cfg->dims[2], C = cfg->no_chains;
+    if (!dims_ok(C, D, H, W) || C > IRS_MAX_CHAINS) return fail("irs_create: bad dims / chains (C <= %d)", IRS_MAX_CHAINS);
+    if (cfg->no_steps < 1 || cfg->no_steps > 30) return fail("irs_create: no_steps out of range");
+    if (cfg->sobolev_s < 0 || cfg->sobolev_s > IRS_MAX_HALF_WIDTH) return fail("irs_create: sobolev_s out of range");
+    if (cfg->data_loss != IRS_DATA_GMM_LCC && cfg->data_loss != IRS_DATA_SSD) return fail("irs_create: unknown data loss");
+    if (cfg->data_loss == IRS_DATA_GMM_LCC) {
+        if (!lcc_ok(cfg->lcc_s, D, H, W)) return fail("irs_create: LCC half width must be 1 or 2");
+        if (cfg->gmm_components < 1 || cfg->gmm_components > IRS_MAX_COMPONENTS) return fail("irs_create: 1..%d mixture components", IRS_MAX_COMPONENTS);
+    } else if (!(cfg->ssd_sigma > 0.0f)) return fail("irs_create: ssd_sigma must be positive");
+    if (cfg->reg_loss != IRS_REG_L2 && cfg->reg_loss != IRS_REG_LOGNORMAL) return fail("irs_create: unknown regulariser");
+    const bool any_cps = cfg->cps[0] || cfg->cps[1] || cfg->cps[2];
+    if (any_cps && (cfg->cps[0] < 1 || cfg->cps[1] < 1 || cfg->cps[2] < 1 || cfg->cps[0] > 8 || cfg->cps[1] > 8 || cfg->cps[2] > 8))
+        return fail("irs_create: control point spacing must be 1..8 on every axis");
+
+    irs_ctx* c = new (std::nothrow) irs_ctx();
+    if (!c) return fail("irs_create: out of host memory");
+    memset((void*)c, 0, sizeof(*c));
+    c->cfg = *cfg;
+    c->C = C;
+    c->vol = make_vol(D, H, W);
+    c->ffd = any_cps;
+    c->volv = c->ffd ? make_vol(control_points(D, cfg->cps[0]), control_points(H, cfg->cps[1]), control_points(W, cfg->cps[2]))
+                     : c->vol;
+    if (cfg->sobolev_s > 0 && (2 * cfg->sobolev_s >= c->volv.D || 2 * cfg->sobolev_s >= c->volv.H || 2 * cfg->sobolev_s >= c->volv.W)) {
+        delete c;
+        return fail("irs_create: velocity grid smaller than the Sobolev kernel");
+    }
+    c->sob.s = cfg->sobolev_s;
+    for (int i = 0; i <= 2 * cfg->sobolev_s; ++i) c->sob.k[i] = cfg->sobolev_kernel[i];
+    if (c->ffd)
+        for (int a = 0; a < 3; ++a) c->spl[a] = make_spline(cfg->cps[a]);
+
+    DevCfg& d = c->dcfg;
+    d.K = cfg->data_loss == IRS_DATA_GMM_LCC ? cfg->gmm_components : 1;
+    d.mode = cfg->data_loss;
+    d.vd = cfg->virtual_decimation;
+    d.C = C;
+    d.gmm_lr_log_std = cfg->gmm_lr_log_std;
+    d.gmm_lr_logits = cfg->gmm_lr_logits;
+    d.gmm_lr_decay = cfg->gmm_lr_decay;
+    d.beta1 = cfg->adam_beta1 > 0 ? cfg->adam_beta1 : 0.9f;
+    d.beta2 = cfg->adam_beta2 > 0 ? cfg->adam_beta2 : 0.999f;
+    d.eps = cfg->adam_eps > 0 ? cfg->adam_eps : 1e-8f;
+    d.scale_prior_loc = cfg->scale_prior_loc;
+    d.scale_prior_scale = cfg->scale_prior_scale;
+    for (int k = 0; k < IRS_MAX_COMPONENTS; ++k) d.conc[k] = cfg->dirichlet_concentration[k];
+    d.reg_loss = cfg->reg_loss;
+    d.reg_learnable = cfg->reg_learnable;
+    d.dof = cfg->dof;
+    d.reg_lr0 = cfg->reg_lr0;
+    d.reg_lr1 = cfg->reg_lr1;
+    d.reg_lr_decay = cfg->reg_lr_decay;
+    d.loc_prior_nu = cfg->loc_prior_nu;
+    d.loc_prior_w_reg = cfg->loc_prior_w_reg;
+    d.reg_scale_prior_loc = cfg->reg_scale_prior_loc;
+    d.reg_scale_prior_scale = cfg->reg_scale_prior_scale;
+    d.w_reg_prior_shape = cfg->w_reg_prior_shape;
+    d.w_reg_prior_rate = cfg->w_reg_prior_rate;
+
+    // ---- one slab for the whole workspace
+    const size_t fieldI = (size_t)C * 3 * c->vol.V * sizeof(float);   // image-grid field
+    const size_t fieldV = (size_t)C * 3 * c->volv.V * sizeof(float);  // velocity-grid field
+    const size_t imageI = (size_t)C * c->vol.V * sizeof(float);
+    const size_t ffd_tmp = c->ffd ? 2 * fieldI : 0;
+    c->nll_blocks = data_bwd_blocks(cfg->data_loss, c->vol);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t o_steps = take(fieldI * cfg->no_steps);
+    const size_t o_tmpA = take(fieldV > ffd_tmp ? fieldV : ffd_tmp);
+    const size_t o_tmpB = take(fieldV);
+    const size_t o_vs = take(fieldV);
+    const size_t o_gA = take(fieldI), o_gB = take(fieldI);
+    const size_t o_warped = take(imageI), o_z = take(imageI), o_sig = take(imageI), o_fhat = take(imageI), o_gM = take(imageI);
+    const size_t o_dense = take(c->ffd ? fieldI : 0);
+    const size_t o_stat = take(sizeof(double) * kMaxPartialBlocks * kStatVals);
+    const size_t o_energy = take(sizeof(double) * kMaxPartialBlocks * IRS_MAX_CHAINS);
+    const size_t o_nll = take(sizeof(double) * (size_t)c->nll_blocks * C);
+    const size_t o_state = take(sizeof(DevState));
+    c->slab_bytes = off;
+    if (hipMalloc((void**)&c->slab, off) != hipSuccess) {
+        delete c;
+        return fail("irs_create: hipMalloc of %zu workspace bytes failed", off);
+    }
+    c->steps = (float*)(c->slab + o_steps);
+    c->tmpA = (float*)(c->slab + o_tmpA);
+    c->tmpB = (float*)(c->slab + o_tmpB);
+    c->vs = (float*)(c->slab + o_vs);
+    c->gA = (float*)(c->slab + o_gA);
+    c->gB = (float*)(c->slab + o_gB);
+    c->warped = (float*)(c->slab + o_warped);
+    c->z = (float*)(c->slab + o_z);
+    c->sigM = (float*)(c->slab + o_sig);
+    c->fhat = (float*)(c->slab + o_fhat);
+    c->gM = (float*)(c->slab + o_gM);
+    c->dense = c->ffd ? (float*)(c->slab + o_dense) : nullptr;
+    c->stat_partials = (double*)(c->slab + o_stat);
+    c->energy_partials = (double*)(c->slab + o_energy);
+    c->nll_partials = (double*)(c->slab + o_nll);
+    c->state = (DevState*)(c->slab + o_state);
+
+    if (ensure_lin_tables(c->lin, D, H, W, nullptr)) {
+        (void)hipFree(c->slab);
+        delete c;
+        return fail("irs_create: identity grid allocation failed");
+    }
+    // initial hyper-parameters as the reference constructors set them (model/loss.py:49-50,191-192,298-303)
+    DevState init;
+    memset(&init, 0, sizeof(init));
+    init.K = d.K;
+    init.mode = d.mode;
+    init.ssd_inv_sigma = cfg->data_loss == IRS_DATA_SSD ? 1.0f / cfg->ssd_sigma : 0.0f;
+    if (cfg->reg_loss == IRS_REG_L2) init.st.reg_param[0] = log((double)cfg->w_reg);
+    // (RegLoss_LogNormal's loc / log_scale need digamma: the host wrapper sets them through irs_set_state)
+    for (int ch = 0; ch < IRS_MAX_CHAINS; ++ch) init.sc.alpha[ch] = 1.0;
+    hipError_t e = hipMemcpy(c->state, &init, sizeof(init), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_refresh_derived(c->state, c->dcfg, nullptr);
+        e = hipDeviceSynchronize();
+    }
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+        (void)hipFree(c->slab);
+        delete c;
+        return fail("irs_create: state initialisation failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return 0;
+}
+
+void irs_destroy(irs_ctx* c) {
+    if (!c) return;
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 6; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->lin.dev) (void)hipFree(c->lin.dev);
+    if (c->slab) (void)hipFree(c->slab);
+    delete c;
+}
+
+size_t irs_workspace_bytes(const irs_ctx* c) { return c ? c->slab_bytes : 0; }
+
+int irs_velocity_dims(const irs_ctx* c, int32_t out[3]) {
+    if (!c || !out) return fail("irs_velocity_dims: null argument");
+    out[0] = c->volv.D;
+    out[1] = c->volv.H;
+    out[2] = c->volv.W;
+    return 0;
+}
+
+int irs_set_fixed(irs_ctx* c, const float* fixed_im, int fixed_chains, void* stream) {
+    if (!c || !fixed_im || (fixed_chains != 1 && fixed_chains != c->C)) return fail("irs_set_fixed: bad arguments");
+    if (c->cfg.data_loss == IRS_DATA_GMM_LCC) {
+        launch_lcc_fwd(nullptr, 0, fixed_im, c->fhat, nullptr, c->cfg.lcc_s, fixed_chains, c->vol, (hipStream_t)stream);
+        LAUNCH_CHECK();
+    }
+    c->fhat_chains = fixed_chains;
+    c->fixed_set = true;
+    return 0;
+}
+
+int irs_get_state(irs_ctx* c, irs_state* out, void* stream) {
+    if (!c || !out) return fail("irs_get_state: null argument");
+    HIP_TRY(hipMemcpyAsync(out, &c->state->st, sizeof(irs_state), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int irs_set_state(irs_ctx* c, const irs_state* in, void* stream) {
+    if (!c || !in) return fail("irs_set_state: null argument");
+    HIP_TRY(hipMemcpyAsync(&c->state->st, in, sizeof(irs_state), hipMemcpyHostToDevice, (hipStream_t)stream));
+    launch_refresh_derived(c->state, c->dcfg, (hipStream_t)stream);
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int irs_get_scalars(irs_ctx* c, irs_scalars* out, void* stream) {
+    if (!c || !out) return fail("irs_get_scalars: null argument");
+    HIP_TRY(hipMemcpyAsync(out, &c->state->sc, sizeof(irs_scalars), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+// ================================================================================================
+// the transition
+// ================================================================================================
+
+static int check_io(const irs_ctx* c, const irs_io* io, const char* who) {
+    if (!c || !io) return fail("%s: null argument", who);
+    if (!io->fixed_im || !io->moving_im || !io->mask) return fail("%s: fixed_im, moving_im and mask are required", who);
+    auto ok = [&](int n) { return n == 1 || n == c->C; };
+    if (!ok(io->fixed_chains) || !ok(io->moving_chains) || !ok(io->mask_chains))
+        return fail("%s: *_chains must be 1 or no_chains", who);
+    if (c->cfg.data_loss == IRS_DATA_GMM_LCC && !c->fixed_set) return fail("%s: call irs_set_fixed first", who);
+    return 0;
+}
+
+// velocity (v + noise, smoothed) -> vs; dense velocity -> d_1..d_n; warp -> warped; residual -> z (+ sigM)
+static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_noise, bool with_jitter, float* vs,
+                        float* warped, float* z, int chains, hipStream_t st, int timed) {
+    const irs_config& cfg = c->cfg;
+    const int C = chains;
+    const uint64_t* it = &c->state->st.iteration;
+    // 1. SGLD perturbation + Sobolev smoothing
+    float* first = cfg.sobolev_s > 0 ? c->tmpA : vs;
+    if (with_noise) launch_perturb(v, io->sigma, io->eps, (float)sqrt(2.0 * (double)cfg.lr), first, C, c->volv, cfg.seed, 0, it, st);
+    else HIP_TRY(hipMemcpyAsync(first, v, (size_t)C * 3 * c->volv.V * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (cfg.sobolev_s > 0) {
+        launch_conv_axis(c->tmpA, c->tmpB, c->sob, 2, C * 3, c->volv, st);
+        launch_conv_axis(c->tmpB, c->tmpA, c->sob, 1, C * 3, c->volv, st);
+        launch_conv_axis(c->tmpA, vs, c->sob, 0, C * 3, c->volv, st);
+    }
+    // 2. dense velocity
+    const float* dense = vs;
+    if (c->ffd) {
+        const int G[3] = {c->volv.D, c->volv.H, c->volv.W};
+        ffd_up(vs, c->dense, c->tmpA, C, c->vol, G, c->spl, st);
+        dense = c->dense;
+    }
+    // 3. scaling and squaring
+    if (timed) HIP_TRY(hipEventRecord(c->ev[1], st));
+    const int64_t field = (int64_t)c->C * 3 * c->vol.V;
+    const Lin lin = c->lin.lin();
+    for (int k = 0; k < cfg.no_steps; ++k)
+        launch_exp_step_fwd(k == 0 ? dense : c->steps + (int64_t)(k - 1) * field, c->steps + (int64_t)k * field, k == 0,
+                            cfg.no_steps, C, c->vol, lin, st);
+    if (timed) HIP_TRY(hipEventRecord(c->ev[2], st));
+    const float* d_last = c->steps + (int64_t)(cfg.no_steps - 1) * field;
+    // 4. warp (+ jitter) and residual
+    const float alpha = with_jitter ? cfg.uniform_alpha : 0.0f;
+    launch_warp_fwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif, alpha, warped, C, c->vol, lin,
+                    cfg.seed, 0, it, st);
+    if (cfg.data_loss == IRS_DATA_GMM_LCC)
+        launch_lcc_fwd(c->fhat, c->fhat_chains == 1 ? 0 : c->vol.V, warped, z, c->sigM, cfg.lcc_s, C, c->vol, st);
+    else
+        launch_residual_ssd(io->fixed_im, io->fixed_chains == 1 ? 0 : c->vol.V, warped, z, C, c->vol, st);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int irs_gmm_init(irs_ctx* c, const irs_io* io, const float* v_sample, int warm_up, void* stream) {
+    if (check_io(c, io, "irs_gmm_init")) return 1;
+    if (c->cfg.data_loss != IRS_DATA_GMM_LCC) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    // trainer.py:529-547: one velocity sample (no Langevin noise, no jitter), batch of one
+    const size_t bytes = (size_t)3 * c->volv.V * sizeof(float);
+    if (v_sample) HIP_TRY(hipMemcpyAsync(c->gA, v_sample, bytes, hipMemcpyDeviceToDevice, st));
+    else HIP_TRY(hipMemsetAsync(c->gA, 0, bytes, st));
+    if (forward_pass(c, io, c->gA, false, false, c->vs, c->warped, c->z, 1, st, 0)) return 1;
+    launch_masked_moments(c->z, io->mask, c->stat_partials, c->vol, st);
+    launch_gmm_init_from_moments(c->state, c->stat_partials, stats_blocks(c->vol), c->dcfg, st);
+    launch_stats(c->cfg.virtual_decimation, c->z, io->mask, c->state, c->stat_partials, c->vol, st);
+    launch_chain_scalar(c->state, c->stat_partials, stats_blocks(c->vol), 0, 1, c->dcfg, st);  // alpha, fixed below
+    for (int i = 0; i < warm_up; ++i) {
+        launch_stats(0, c->z, io->mask, c->state, c->stat_partials, c->vol, st);
+        launch_chain_scalar(c->state, c->stat_partials, stats_blocks(c->vol), 0, 2, c->dcfg, st);
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int timed) {
+    if (check_io(c, io, "irs_transition")) return 1;
+    if (!io->v) return fail("irs_transition: v is required");
+    const irs_config& cfg = c->cfg;
+    const int C = c->C;
+    const Vol vol = c->vol, volv = c->volv;
+    const Lin lin = c->lin.lin();
+    float* vs = io->curr_state ? io->curr_state : c->vs;
+    float* warped = io->im_moving_warped ? io->im_moving_warped : c->warped;
+    float* z = io->residuals ? io->residuals : c->z;
+    const uint64_t* it = &c->state->st.iteration;
+
+    if (timed) HIP_TRY(hipEventRecord(c->ev[0], st));
+    if (forward_pass(c, io, io->v, true, cfg.uniform_alpha > 0.0f, vs, warped, z, C, st, timed)) return 1;
+    const int64_t field = (int64_t)C * 3 * vol.V;
+    const float* d_last = c->steps + (int64_t)(cfg.no_steps - 1) * field;
+    if (io->transformation || io->displacement) launch_svf_outputs(d_last, io->transformation, io->displacement, C, vol, lin, st);
+
+    // regulariser energy -> loss terms, coefficients, hyper-parameter step
+    launch_reg_energy(vs, c->energy_partials, C, volv, st);
+    launch_reg_scalar(c->state, c->energy_partials, energy_blocks(volv), c->dcfg, st);
+
+    // per chain, serially (trainer.py:316-327): VD factor -> GMM step -> data term with the UPDATED mixture
+    const int sb = stats_blocks(vol);
+    for (int ch = 0; ch < C; ++ch) {
+        const uint8_t* mask = io->mask + (io->mask_chains == 1 ? 0 : (int64_t)ch * vol.V);
+        const float* zc = z + (int64_t)ch * vol.V;
+        launch_stats(cfg.virtual_decimation, zc, mask, c->state, c->stat_partials, vol, st);
+        launch_chain_scalar(c->state, c->stat_partials, sb, ch, 3, c->dcfg, st);
+        const float* f = cfg.data_loss == IRS_DATA_GMM_LCC ? c->fhat + (c->fhat_chains == 1 ? 0 : (int64_t)ch * vol.V) : nullptr;
+        launch_data_bwd(cfg.data_loss, f, 0, zc, c->sigM + (int64_t)ch * vol.V, mask, 0, nullptr, c->state, ch,
+                        c->gM + (int64_t)ch * vol.V, c->nll_partials + (int64_t)ch * c->nll_blocks, cfg.lcc_s, 1, vol, st);
+    }
+    // back through the warp and the squaring steps
+    launch_warp_bwd(io->moving_im, io->moving_chains == 1 ? 0 : vol.V, d_last, io->unif,
+                    cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f, c->gM, c->gA, C, vol, lin, cfg.seed, 0, it, st);
+    LAUNCH_CHECK();
+    if (timed) HIP_TRY(hipEventRecord(c->ev[3], st));
+    const float* dense = c->ffd ? c->dense : vs;
+    float* g0 = nullptr;
+    {
+        // exp_backward ping-pongs between two buffers; the incoming gradient sits in gA, so start writing into gB
+        const float* G = c->gA;
+        float* bufs[2] = {c->gB, c->gA};
+        int cur = 0;
+        for (int k = cfg.no_steps - 1; k >= 0; --k) {
+            float* out = bufs[cur];
+            HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
+            launch_exp_step_bwd(G, k == 0 ? dense : c->steps + (int64_t)(k - 1) * field, out, k == 0, cfg.no_steps, C, vol,
+                                lin, st);
+            G = out;
+            cur ^= 1;
+        }
+        g0 = const_cast<float*>(G);
+    }
+    if (timed) HIP_TRY(hipEventRecord(c->ev[4], st));
+    float s[3];
+    prescale_factors(vol, cfg.no_steps, s);
+    if (c->ffd) {
+        float* scaled = g0 == c->gA ? c->gB : c->gA;
+        launch_scale_channels(g0, scaled, s[0], s[1], s[2], C, vol.V, st);
+        const int G[3] = {volv.D, volv.H, volv.W};
+        ffd_adjoint(scaled, c->tmpB, c->tmpA, C, vol, G, c->spl, st);
+        launch_sgld_update(io->v, io->sigma, c->tmpB, vs, c->state, cfg.lr, 1.0f, 1.0f, 1.0f, io->grad_v, C, volv, st);
+    } else {
+        launch_sgld_update(io->v, io->sigma, g0, vs, c->state, cfg.lr, s[0], s[1], s[2], io->grad_v, C, volv, st);
+    }
+    launch_finalize(c->state, c->nll_partials, c->nll_blocks, c->dcfg, true, st);
+    LAUNCH_CHECK();
+    if (timed) HIP_TRY(hipEventRecord(c->ev[5], st));
+    return 0;
+}
+
+int irs_transition(irs_ctx* c, const irs_io* io, void* stream) { return transition_impl(c, io, (hipStream_t)stream, 0); }
+
+int irs_transition_timed(irs_ctx* c, const irs_io* io, void* stream, float* ms_total, float* ms_exp) {
+    if (!ms_total || !ms_exp) return fail("irs_transition_timed: null output");
+    if (transition_impl(c, io, (hipStream_t)stream, 1)) return 1;
+    HIP_TRY(hipEventSynchronize(c->ev[5]));
+    float fwd = 0.0f, bwd = 0.0f;
+    HIP_TRY(hipEventElapsedTime(ms_total, c->ev[0], c->ev[5]));
+    HIP_TRY(hipEventElapsedTime(&fwd, c->ev[1], c->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&bwd, c->ev[3], c->ev[4]));
+    *ms_exp = fwd + bwd;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// Shared device helpers for the gfx950 kernels.  CDNA4 only: 64-wide wavefronts, no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/irsgmcmc.h"
+
+namespace irs {
+
+constexpr int kBlock = 256;        // 4 wavefronts
+constexpr int kWave = 64;
+constexpr int kMaxPartialBlocks = 2048;  // cap for per-block partial sums (reduced in fixed order)
+
+struct Vol {
+    int D, H, W;
+    int64_t V;  // D*H*W
+};
+
+__host__ __device__ inline Vol make_vol(int D, int H, int W) { return Vol{D, H, W, (int64_t)D * H * W}; }
+
+// identity-grid tables: linspace(-1, 1, n) per axis as torch's CPU kernel computes it
+// (utils/util.py:263-278).  x <-> W, y <-> H, z <-> D.
+struct Lin {
+    const float* x;
+    const float* y;
+    const float* z;
+};
+
+// ------------------------------------------------------------------------------------------------
+// trilinear sampling, ATen semantics (bilinear / border / align_corners=True).
+// Arithmetic order follows ATen's CPU grid_sampler_3d (no FMA contraction) so that the forward pass is
+// near bit-identical to the reference's CPU path: i = ((g + 1) / 2) * (n - 1); clip to [0, n-1] with a zero
+// gradient on and outside the border; weights (i0 + 1 - i) and (i - i0); corners accumulated x fastest.
+// ------------------------------------------------------------------------------------------------
+struct AxisTap {
+    int i0, i1;    // corner indices (i1 clamped; its weight is exactly 0 whenever it would be out of range)
+    float w0, w1;  // weights
+    float gmul;    // d(i)/d(g): (n-1)/2 strictly inside, 0 on / outside the border
+};
+
+__device__ __forceinline__ AxisTap axis_tap(float g, int n) {
+    AxisTap t;
+    const float nm1 = (float)(n - 1);
+    float i = __fmul_rn(__fmul_rn(__fadd_rn(g, 1.0f), 0.5f), nm1);
+    t.gmul = nm1 * 0.5f;
+    if (i <= 0.0f) {
+        i = 0.0f;
+        t.gmul = 0.0f;
+    } else if (i >= nm1) {
+        i = nm1;
+        t.gmul = 0.0f;
+    }
+    const float f = floorf(i);
+    t.i0 = (int)f;
+    t.i1 = min(t.i0 + 1, n - 1);
+    t.w1 = __fsub_rn(i, f);
+    t.w0 = __fsub_rn(__fadd_rn(f, 1.0f), i);
+    return t;
+}
+
+// transform_coordinates (utils/util.py:418-429): (v * 2) / (n - 1), then / 2^steps (utils/transformation.py:68)
+__device__ __forceinline__ float prescale(float v, float nm1, float inv_pow) {
+    return __fmul_rn(__fdiv_rn(__fmul_rn(v, 2.0f), nm1), inv_pow);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wavefront / block reductions (fp64 accumulators: 1e-5 relative on sums over up to 2^24 voxels needs
+// better than fp32 running sums)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// reduce NV values per thread across the block; result valid in thread 0.  smem: NV * (kBlock/kWave) doubles.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* smem) {
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = wave_sum(v[i]);
+        if (lane == 0) smem[i * (kBlock / kWave) + wid] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < kBlock / kWave; ++w) s += smem[i * (kBlock / kWave) + w];
+            v[i] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based RNG (in-kernel noise when the caller injects none).
+// counter = (index lo, index hi, iteration lo, stream id), key = seed.
+// ------------------------------------------------------------------------------------------------
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }  // [0, 1)
+
+// two standard normals from two 32-bit words (Box-Muller)
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    const float v = u01(b);
+    const float r = sqrtf(-2.0f * __logf(u));
+    float s, c;
+    __sincosf(6.28318530717958647692f * v, &s, &c);
+    n0 = r * c;
+    n1 = r * s;
+}
+
+}  // namespace irs

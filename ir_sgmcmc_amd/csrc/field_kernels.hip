@@ -1,0 +1,543 @@
+// gfx950 kernels for the velocity/displacement-field half of the SG-MCMC transition:
+//   SGLD perturbation + Sobolev smoothing   (reference utils/functions.py:76-109, utils/util.py:48-58,394-404)
+//   scaling and squaring forward / adjoint  (utils/transformation.py:63-76 and autograd through it)
+//   trilinear / nearest warps               (utils/registration.py:17-30, utils/util.py:44-53)
+//   cubic B-spline FFD up-sampling / adjoint (utils/transformation.py:105-153)
+// All of it is HBM/L2-bound gather/stencil work on planar fp32 fields (C,3,D,H,W); no MFMA by design.
+#include "kernels.h"
+
+namespace irs {
+
+// ------------------------------------------------------------------------------------------------
+// SGLD.forward: out = v + (amp * sigma) * eps          (utils/util.py:56-58; amp = sqrt(2 tau))
+// one thread per voxel per chain handles the three channels (one Philox call yields the 3 normals)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void perturb_kernel(const float* __restrict__ v, const float* __restrict__ sigma,
+                                                         const float* __restrict__ eps, float amp,
+                                                         float* __restrict__ out, int64_t V, uint64_t seed,
+                                                         uint64_t iteration, const uint64_t* __restrict__ dev_iter) {
+    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vox >= V) return;
+    const int chain = blockIdx.y;
+    const int64_t base = (int64_t)chain * 3 * V + vox;
+    float n[3];
+    if (eps) {
+        n[0] = eps[base];
+        n[1] = eps[base + V];
+        n[2] = eps[base + 2 * V];
+    } else {
+        const uint64_t it = dev_iter ? *dev_iter : iteration;
+        const uint64_t idx = (uint64_t)chain * (uint64_t)V + (uint64_t)vox;
+        const U4 r = philox4x32_10(U4{(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)it, 0x5347u ^ (uint32_t)(it >> 32)},
+                                   (uint32_t)seed, (uint32_t)(seed >> 32));
+        float spare;
+        box_muller(r.x, r.y, n[0], n[1]);
+        box_muller(r.z, r.w, n[2], spare);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int64_t i = base + c * V;
+        const float sg = sigma ? sigma[i] : 1.0f;
+        out[i] = __fadd_rn(v[i], __fmul_rn(__fmul_rn(amp, sg), n[c]));
+    }
+}
+
+void launch_perturb(const float* v, const float* sigma, const float* eps, float amp, float* out, int C, Vol vol,
+                    uint64_t seed, uint64_t iteration, const uint64_t* dev_iteration, hipStream_t st) {
+    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    hipLaunchKernelGGL(perturb_kernel, grid, dim3(kBlock), 0, st, v, sigma, eps, amp, out, vol.V, seed, iteration,
+                       dev_iteration);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one axis of the separable Sobolev filter with replicate padding (utils/util.py:400-404):
+// out(p) = sum_t k[t] in(clamp(p + t - s)) along AXIS (0 = x/W, 1 = y/H, 2 = z/D)
+// ------------------------------------------------------------------------------------------------
+template <int AXIS>
+__global__ __launch_bounds__(kBlock) void conv_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           Taps taps, Vol vol) {
+    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vox >= vol.V) return;
+    const int64_t base = (int64_t)blockIdx.y * vol.V;
+    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
+    const int pos = AXIS == 0 ? x : (AXIS == 1 ? y : z);
+    const int n = AXIS == 0 ? vol.W : (AXIS == 1 ? vol.H : vol.D);
+    const int64_t stride = AXIS == 0 ? 1 : (AXIS == 1 ? vol.W : (int64_t)vol.W * vol.H);
+    const float* row = in + base + vox - (int64_t)pos * stride;
+    float acc = 0.0f;
+    for (int t = 0; t <= 2 * taps.s; ++t) {
+        const int q = min(max(pos + t - taps.s, 0), n - 1);
+        acc = fmaf(taps.k[t], row[(int64_t)q * stride], acc);
+    }
+    out[base + vox] = acc;
+}
+
+void launch_conv_axis(const float* in, float* out, const Taps& taps, int axis, int CC, Vol vol, hipStream_t st) {
+    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), CC);
+    if (axis == 0) hipLaunchKernelGGL(conv_axis_kernel<0>, grid, dim3(kBlock), 0, st, in, out, taps, vol);
+    else if (axis == 1) hipLaunchKernelGGL(conv_axis_kernel<1>, grid, dim3(kBlock), 0, st, in, out, taps, vol);
+    else hipLaunchKernelGGL(conv_axis_kernel<2>, grid, dim3(kBlock), 0, st, in, out, taps, vol);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scaling and squaring, one step:  d_out = d + sample(d, id + d)        (utils/transformation.py:70-73)
+// PRESCALE: the input is the velocity in voxel units and d_0 = ((v * 2) / (n_c - 1)) / 2^steps is formed on load
+// (for the centre value and for every tap), so d_0 is never materialised.
+// ------------------------------------------------------------------------------------------------
+struct Scale3 {
+    float nm1[3];   // shape[2 + c] - 1 for channel c (the reference scales channel c by dims[c]: D, H, W order)
+    float inv_pow;  // 1 / 2^no_steps
+};
+
+template <bool PRESCALE>
+__device__ __forceinline__ float ld(const float* p, int64_t i, float nm1, float inv_pow) {
+    const float v = p[i];
+    return PRESCALE ? prescale(v, nm1, inv_pow) : v;
+}
+
+template <bool PRESCALE>
+__global__ __launch_bounds__(kBlock) void exp_step_fwd_kernel(const float* __restrict__ din, float* __restrict__ dout,
+                                                              Vol vol, Lin lin, Scale3 sc) {
+    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vox >= vol.V) return;
+    const int64_t V = vol.V;
+    const float* c0 = din + (int64_t)blockIdx.y * 3 * V;
+    const float* c1 = c0 + V;
+    const float* c2 = c1 + V;
+    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
+
+    const float d0 = ld<PRESCALE>(c0, vox, sc.nm1[0], sc.inv_pow);
+    const float d1 = ld<PRESCALE>(c1, vox, sc.nm1[1], sc.inv_pow);
+    const float d2 = ld<PRESCALE>(c2, vox, sc.nm1[2], sc.inv_pow);
+
+    const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
+    const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
+    const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
+
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+    for (int cz = 0; cz < 2; ++cz) {
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy) {
+            const int64_t rowoff = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W;
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
+                const int64_t idx = rowoff + (cx ? tx.i1 : tx.i0);
+                a0 = __fadd_rn(a0, __fmul_rn(ld<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow), w));
+                a1 = __fadd_rn(a1, __fmul_rn(ld<PRESCALE>(c1, idx, sc.nm1[1], sc.inv_pow), w));
+                a2 = __fadd_rn(a2, __fmul_rn(ld<PRESCALE>(c2, idx, sc.nm1[2], sc.inv_pow), w));
+            }
+        }
+    }
+    float* o = dout + (int64_t)blockIdx.y * 3 * V;
+    o[vox] = __fadd_rn(d0, a0);
+    o[vox + V] = __fadd_rn(d1, a1);
+    o[vox + 2 * V] = __fadd_rn(d2, a2);
+}
+
+static Scale3 make_scale(Vol vol, int no_steps) {
+    Scale3 s;
+    s.nm1[0] = (float)(vol.D - 1);  // channel 0 scaled by shape[2] - 1 (utils/util.py:426-427), sic
+    s.nm1[1] = (float)(vol.H - 1);
+    s.nm1[2] = (float)(vol.W - 1);
+    s.inv_pow = 1.0f / (float)(1 << no_steps);
+    return s;
+}
+
+void launch_exp_step_fwd(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
+                         hipStream_t st) {
+    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const Scale3 sc = make_scale(vol, no_steps);
+    if (prescale_in) hipLaunchKernelGGL(exp_step_fwd_kernel<true>, grid, dim3(kBlock), 0, st, din, dout, vol, lin, sc);
+    else hipLaunchKernelGGL(exp_step_fwd_kernel<false>, grid, dim3(kBlock), 0, st, din, dout, vol, lin, sc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint of one squaring step.  Given G = dL/d(d_out):
+//   g(x)      += G(x)                                    (identity path)
+//   g(corner) += w(corner) * G(x)                        (input-gradient of grid_sample: trilinear scatter)
+//   g_j(x)    += gmul_j * sum_c G_c(x) * d(sample_c)/d(i_j)   (grid-gradient; grid = id + d)
+// gout must be zero on entry; every contribution is a float atomic (memory-side on gfx950).
+// ------------------------------------------------------------------------------------------------
+template <bool PRESCALE>
+__global__ __launch_bounds__(kBlock) void exp_step_bwd_kernel(const float* __restrict__ G, const float* __restrict__ dk,
+                                                              float* __restrict__ gout, Vol vol, Lin lin, Scale3 sc) {
+    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vox >= vol.V) return;
+    const int64_t V = vol.V;
+    const int64_t cb = (int64_t)blockIdx.y * 3 * V;
+    const float* c0 = dk + cb;
+    const float* c1 = c0 + V;
+    const float* c2 = c1 + V;
+    float* g0 = gout + cb;
+    float* g1 = g0 + V;
+    float* g2 = g1 + V;
+    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
+
+    const float G0 = G[cb + vox], G1 = G[cb + V + vox], G2 = G[cb + 2 * V + vox];
+    const float d0 = ld<PRESCALE>(c0, vox, sc.nm1[0], sc.inv_pow);
+    const float d1 = ld<PRESCALE>(c1, vox, sc.nm1[1], sc.inv_pow);
+    const float d2 = ld<PRESCALE>(c2, vox, sc.nm1[2], sc.inv_pow);
+
+    const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
+    const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
+    const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
+
+    float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+#pragma unroll
+    for (int cz = 0; cz < 2; ++cz) {
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy) {
+            const int64_t rowoff = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W;
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
+                const int64_t idx = rowoff + (cx ? tx.i1 : tx.i0);
+                const float v0 = ld<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow);
+                const float v1 = ld<PRESCALE>(c1, idx, sc.nm1[1], sc.inv_pow);
+                const float v2 = ld<PRESCALE>(c2, idx, sc.nm1[2], sc.inv_pow);
+                const float dot = v0 * G0 + v1 * G1 + v2 * G2;
+                gix += (cx ? dot : -dot) * (wy * wz);
+                giy += (cy ? dot : -dot) * (wx * wz);
+                giz += (cz ? dot : -dot) * (wx * wy);
+                const float w = wx * wy * wz;
+                if (w != 0.0f) {
+                    atomicAdd(g0 + idx, w * G0);
+                    atomicAdd(g1 + idx, w * G1);
+                    atomicAdd(g2 + idx, w * G2);
+                }
+            }
+        }
+    }
+    atomicAdd(g0 + vox, G0 + tx.gmul * gix);
+    atomicAdd(g1 + vox, G1 + ty.gmul * giy);
+    atomicAdd(g2 + vox, G2 + tz.gmul * giz);
+}
+
+void launch_exp_step_bwd(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
+                         Lin lin, hipStream_t st) {
+    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const Scale3 sc = make_scale(vol, no_steps);
+    if (prescale_in) hipLaunchKernelGGL(exp_step_bwd_kernel<true>, grid, dim3(kBlock), 0, st, G, dk, gout, vol, lin, sc);
+    else hipLaunchKernelGGL(exp_step_bwd_kernel<false>, grid, dim3(kBlock), 0, st, G, dk, gout, vol, lin, sc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// transformation = id + d, displacement = (d * (n_c - 1)) / 2     (utils/transformation.py:75-76)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void svf_outputs_kernel(const float* __restrict__ d, float* __restrict__ transf,
+                                                             float* __restrict__ disp, Vol vol, Lin lin, Scale3 sc) {
+    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vox >= vol.V) return;
+    const int64_t cb = (int64_t)blockIdx.y * 3 * vol.V;
+    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
+    const float idv[3] = {lin.x[x], lin.y[y], lin.z[z]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float dv = d[cb + c * vol.V + vox];
+        if (transf) transf[cb + c * vol.V + vox] = __fadd_rn(idv[c], dv);
+        if (disp) disp[cb + c * vol.V + vox] = __fmul_rn(__fmul_rn(dv, sc.nm1[c]), 0.5f);
+    }
+}
+
+void launch_svf_outputs(const float* d, float* transformation, float* displacement, int C, Vol vol, Lin lin,
+                        hipStream_t st) {
+    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    hipLaunchKernelGGL(svf_outputs_kernel, grid, dim3(kBlock), 0, st, d, transformation, displacement, vol, lin,
+                       make_scale(vol, 0));
+}
+
+// ------------------------------------------------------------------------------------------------
+// warp of the moving image at id + d (+ uniform jitter, utils/util.py:44-53) and its grid-gradient
+// ------------------------------------------------------------------------------------------------
+struct Jitter {
+    float alpha;       // <= 0: disabled
+    float nm1[3];      // transform_coordinates scaling of the jitter, same (sic) channel/dim pairing
+    uint64_t seed, iteration;
+    const uint64_t* dev_iter;
+};
+
+__device__ __forceinline__ void grid_point(const float* __restrict__ d, const float* __restrict__ unif, const Jitter& jt,
+                                           int64_t cb3, int chain, int64_t vox, Vol vol, Lin lin, int x, int y, int z,
+                                           float (&g)[3]) {
+    g[0] = __fadd_rn(lin.x[x], d[cb3 + vox]);
+    g[1] = __fadd_rn(lin.y[y], d[cb3 + vol.V + vox]);
+    g[2] = __fadd_rn(lin.z[z], d[cb3 + 2 * vol.V + vox]);
+    if (jt.alpha > 0.0f) {
+        float u[3];
+        if (unif) {
+            u[0] = unif[cb3 + vox];
+            u[1] = unif[cb3 + vol.V + vox];
+            u[2] = unif[cb3 + 2 * vol.V + vox];
+        } else {
+            const uint64_t it = jt.dev_iter ? *jt.dev_iter : jt.iteration;
+            const uint64_t idx = (uint64_t)chain * (uint64_t)vol.V + (uint64_t)vox;
+            const U4 r = philox4x32_10(U4{(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)it, 0x554Eu ^ (uint32_t)(it >> 32)},
+                                       (uint32_t)jt.seed, (uint32_t)(jt.seed >> 32));
+            u[0] = u01(r.x);
+            u[1] = u01(r.y);
+            u[2] = u01(r.z);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float nz = __fadd_rn(__fmul_rn(-2.0f * jt.alpha, u[c]), jt.alpha);  // -2 a u + a
+            g[c] = __fadd_rn(g[c], __fdiv_rn(__fmul_rn(nz, 2.0f), jt.nm1[c]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void warp_fwd_kernel(const float* __restrict__ im, int64_t im_stride,
+                                                          const float* __restrict__ d, const float* __restrict__ unif,
+                                                          Jitter jt, float* __restrict__ out, Vol vol, Lin lin) {
+    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vox >= vol.V) return;
+    const int chain = blockIdx.y;
+    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
+    float g[3];
+    grid_point(d, unif, jt, (int64_t)chain * 3 * vol.V, chain, vox, vol, lin, x, y, z, g);
+    const AxisTap tx = axis_tap(g[0], vol.W), ty = axis_tap(g[1], vol.H), tz = axis_tap(g[2], vol.D);
+    const float* src = im + (int64_t)chain * im_stride;
+    float acc = 0.0f;
+#pragma unroll
+    for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy) {
+            const int64_t rowoff = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W;
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
+                acc = __fadd_rn(acc, __fmul_rn(src[rowoff + (cx ? tx.i1 : tx.i0)], w));
+            }
+        }
+    out[(int64_t)chain * vol.V + vox] = acc;
+}
+
+static Jitter make_jitter(float alpha, Vol vol, uint64_t seed, uint64_t iteration, const uint64_t* dev_iter) {
+    Jitter j;
+    j.alpha = alpha;
+    j.nm1[0] = (float)(vol.D - 1);
+    j.nm1[1] = (float)(vol.H - 1);
+    j.nm1[2] = (float)(vol.W - 1);
+    j.seed = seed;
+    j.iteration = iteration;
+    j.dev_iter = dev_iter;
+    return j;
+}
+
+void launch_warp_fwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha, float* out,
+                     int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration, const uint64_t* dev_iteration,
+                     hipStream_t st) {
+    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    hipLaunchKernelGGL(warp_fwd_kernel, grid, dim3(kBlock), 0, st, im, im_stride, d, unif,
+                       make_jitter(alpha, vol, seed, iteration, dev_iteration), out, vol, lin);
+}
+
+__global__ __launch_bounds__(kBlock) void warp_bwd_kernel(const float* __restrict__ im, int64_t im_stride,
+                                                          const float* __restrict__ d, const float* __restrict__ unif,
+                                                          Jitter jt, const float* __restrict__ gw,
+                                                          float* __restrict__ gd, Vol vol, Lin lin) {
+    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vox >= vol.V) return;
+    const int chain = blockIdx.y;
+    const int64_t cb3 = (int64_t)chain * 3 * vol.V;
+    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
+    float g[3];
+    grid_point(d, unif, jt, cb3, chain, vox, vol, lin, x, y, z, g);
+    const AxisTap tx = axis_tap(g[0], vol.W), ty = axis_tap(g[1], vol.H), tz = axis_tap(g[2], vol.D);
+    const float* src = im + (int64_t)chain * im_stride;
+    float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+#pragma unroll
+    for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy) {
+            const int64_t rowoff = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W;
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
+                const float val = src[rowoff + (cx ? tx.i1 : tx.i0)];
+                gix += (cx ? val : -val) * (wy * wz);
+                giy += (cy ? val : -val) * (wx * wz);
+                giz += (cz ? val : -val) * (wx * wy);
+            }
+        }
+    const float go = gw[(int64_t)chain * vol.V + vox];
+    gd[cb3 + vox] = tx.gmul * gix * go;
+    gd[cb3 + vol.V + vox] = ty.gmul * giy * go;
+    gd[cb3 + 2 * vol.V + vox] = tz.gmul * giz * go;
+}
+
+void launch_warp_bwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha,
+                     const float* g_warped, float* g_d, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
+                     const uint64_t* dev_iteration, hipStream_t st) {
+    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    hipLaunchKernelGGL(warp_bwd_kernel, grid, dim3(kBlock), 0, st, im, im_stride, d, unif,
+                       make_jitter(alpha, vol, seed, iteration, dev_iteration), g_warped, g_d, vol, lin);
+}
+
+// RegistrationModule.forward on an explicit transformation tensor (C,3,D,H,W) in [-1,1]
+template <typename T, bool NEAREST>
+__global__ __launch_bounds__(kBlock) void warp_transformation_kernel(const T* __restrict__ im, int64_t im_stride,
+                                                                     const float* __restrict__ t, T* __restrict__ out,
+                                                                     Vol vol) {
+    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vox >= vol.V) return;
+    const int chain = blockIdx.y;
+    const int64_t cb3 = (int64_t)chain * 3 * vol.V;
+    const T* src = im + (int64_t)chain * im_stride;
+    const float gx = t[cb3 + vox], gy = t[cb3 + vol.V + vox], gz = t[cb3 + 2 * vol.V + vox];
+    if (NEAREST) {
+        // ATen nearest: unnormalise, clip to the border, round half to even (nearbyint), in-bounds by construction
+        auto nearest = [](float g, int n) {
+            const float nm1 = (float)(n - 1);
+            float i = __fmul_rn(__fmul_rn(__fadd_rn(g, 1.0f), 0.5f), nm1);
+            i = fminf(fmaxf(i, 0.0f), nm1);
+            return (int)nearbyintf(i);
+        };
+        const int xi = nearest(gx, vol.W), yi = nearest(gy, vol.H), zi = nearest(gz, vol.D);
+        out[(int64_t)chain * vol.V + vox] = src[((int64_t)zi * vol.H + yi) * vol.W + xi];
+    } else {
+        const AxisTap tx = axis_tap(gx, vol.W), ty = axis_tap(gy, vol.H), tz = axis_tap(gz, vol.D);
+        float acc = 0.0f;
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy) {
+                const int64_t rowoff = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W;
+#pragma unroll
+                for (int cx = 0; cx < 2; ++cx) {
+                    const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
+                    acc = __fadd_rn(acc, __fmul_rn((float)src[rowoff + (cx ? tx.i1 : tx.i0)], w));
+                }
+            }
+        out[(int64_t)chain * vol.V + vox] = (T)acc;
+    }
+}
+
+void launch_warp_transformation(const float* im, int64_t im_stride, const float* t, float* out, int C, Vol vol,
+                                hipStream_t st) {
+    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    hipLaunchKernelGGL((warp_transformation_kernel<float, false>), grid, dim3(kBlock), 0, st, im, im_stride, t, out, vol);
+}
+void launch_warp_nearest_u8(const uint8_t* im, int64_t im_stride, const float* t, uint8_t* out, int C, Vol vol,
+                            hipStream_t st) {
+    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    hipLaunchKernelGGL((warp_transformation_kernel<uint8_t, true>), grid, dim3(kBlock), 0, st, im, im_stride, t, out, vol);
+}
+void launch_warp_nearest_i16(const int16_t* im, int64_t im_stride, const float* t, int16_t* out, int C, Vol vol,
+                             hipStream_t st) {
+    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    hipLaunchKernelGGL((warp_transformation_kernel<int16_t, true>), grid, dim3(kBlock), 0, st, im, im_stride, t, out, vol);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cubic B-spline FFD, one axis.  Arrays are viewed as [outer][n][inner].
+//   up      : out[o][x][i] = sum_j in[o][j][i] * k[x + 3c - 1 - j c],   j = floor(x/c) .. floor(x/c)+3
+//   adjoint : out[o][j][i] = sum_x in[o][x][i] * k[x + 3c - 1 - j c],   x = (j-3)c+1 .. (j+1)c-1
+// which is conv_transpose1d(stride c, padding 2c-1) followed by the crop [c : c+N] of
+// utils/transformation.py:146-153, and its transpose.
+// ------------------------------------------------------------------------------------------------
+template <bool ADJ>
+__global__ __launch_bounds__(kBlock) void ffd_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          SplineTaps taps, int64_t outer, int n_in, int n_out,
+                                                          int64_t inner) {
+    const int64_t total = outer * n_out * inner;
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= total) return;
+    const int64_t i = e % inner;
+    const int p = (int)((e / inner) % n_out);
+    const int64_t o = e / (inner * n_out);
+    const float* src = in + o * n_in * inner + i;
+    const int c = taps.cps;
+    float acc = 0.0f;
+    if (!ADJ) {
+        const int j0 = p / c;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = j0 + jj;
+            if (j < n_in) acc = fmaf(src[(int64_t)j * inner], taps.k[p + 3 * c - 1 - j * c], acc);
+        }
+    } else {
+        const int lo = max((p - 3) * c + 1, 0), hi = min((p + 1) * c - 1, n_in - 1);
+        for (int xq = lo; xq <= hi; ++xq) acc = fmaf(src[(int64_t)xq * inner], taps.k[xq + 3 * c - 1 - p * c], acc);
+    }
+    out[e] = acc;
+}
+
+void launch_ffd_axis(const float* in, float* out, const SplineTaps& taps, bool adjoint, int64_t outer, int n_in,
+                     int n_out, int64_t inner, hipStream_t st) {
+    const int64_t total = outer * n_out * inner;
+    dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
+    if (adjoint) hipLaunchKernelGGL(ffd_axis_kernel<true>, grid, dim3(kBlock), 0, st, in, out, taps, outer, n_in, n_out, inner);
+    else hipLaunchKernelGGL(ffd_axis_kernel<false>, grid, dim3(kBlock), 0, st, in, out, taps, outer, n_in, n_out, inner);
+}
+
+// out[c] = in[c] * s_c  (chain rule of the prescale: d_0 = v * 2/(n_c-1) / 2^steps)
+__global__ __launch_bounds__(kBlock) void scale_channels_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                float s0, float s1, float s2, int64_t V) {
+    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vox >= V) return;
+    const int64_t cb = (int64_t)blockIdx.y * 3 * V;
+    out[cb + vox] = in[cb + vox] * s0;
+    out[cb + V + vox] = in[cb + V + vox] * s1;
+    out[cb + 2 * V + vox] = in[cb + 2 * V + vox] * s2;
+}
+
+void launch_scale_channels(const float* in, float* out, float s0, float s1, float s2, int C, int64_t V, hipStream_t st) {
+    dim3 grid((unsigned)((V + kBlock - 1) / kBlock), C);
+    hipLaunchKernelGGL(scale_channels_kernel, grid, dim3(kBlock), 0, st, in, out, s0, s1, s2, V);
+}
+
+// ------------------------------------------------------------------------------------------------
+// identity-grid tables: torch.linspace(-1, 1, n) as the CPU kernel evaluates it
+// (start + step*i below the midpoint, end - step*(n-1-i) above; ATen RangeFactories)
+// ------------------------------------------------------------------------------------------------
+static void fill_linspace(float* dst, int n) {
+    const float step = (1.0f - (-1.0f)) / (float)(n - 1);
+    const int half = n / 2;
+    for (int i = 0; i < n; ++i) dst[i] = i < half ? (-1.0f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
+}
+
+int ensure_lin_tables(LinTables& t, int D, int H, int W, hipStream_t st) {
+    if (t.dev && t.D == D && t.H == H && t.W == W) return 0;
+    if (t.dev) (void)hipFree(t.dev);
+    t.dev = nullptr;
+    const size_t n = (size_t)D + H + W;
+    float* host = (float*)malloc(n * sizeof(float));
+    if (!host) return 1;
+    fill_linspace(host, W);
+    fill_linspace(host + W, H);
+    fill_linspace(host + W + H, D);
+    hipError_t e = hipMalloc((void**)&t.dev, n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(t.dev, host, n * sizeof(float), hipMemcpyHostToDevice);
+    free(host);
+    if (e != hipSuccess) {
+        t.dev = nullptr;
+        return 1;
+    }
+    t.D = D;
+    t.H = H;
+    t.W = W;
+    (void)st;
+    return 0;
+}
+
+int cached_lin(int D, int H, int W, hipStream_t st, Lin* out) {
+    static LinTables cache[8];
+    static int next = 0;
+    for (auto& c : cache)
+        if (c.dev && c.D == D && c.H == H && c.W == W) {
+            *out = c.lin();
+            return 0;
+        }
+    LinTables& slot = cache[next];
+    next = (next + 1) % 8;
+    if (slot.dev) {  // evicting a table that an in-flight kernel might read: drain first
+        (void)hipDeviceSynchronize();
+    }
+    if (ensure_lin_tables(slot, D, H, W, st)) return 1;
+    *out = slot.lin();
+    return 0;
+}
+
+}  // namespace irs

@@ -1,0 +1,78 @@
+// Host-side launchers of the gfx950 kernels (internal; the public surface is include/irsgmcmc.h).
+#pragma once
+#include "common.h"
+
+namespace irs {
+
+struct Taps {
+    float k[2 * IRS_MAX_HALF_WIDTH + 1];
+    int s;
+};
+
+struct SplineTaps {
+    float k[32];  // sampled cubic B-spline, 4*cps - 1 taps (cps <= 8)
+    int cps;
+};
+
+// identity-grid tables live in device memory; built once per (D,H,W)
+struct LinTables {
+    float* dev = nullptr;  // [W | H | D]
+    int D = 0, H = 0, W = 0;
+    Lin lin() const { return Lin{dev, dev + W, dev + W + H}; }
+};
+int ensure_lin_tables(LinTables& t, int D, int H, int W, hipStream_t st);
+// process-wide cache used by the stateless operators
+int cached_lin(int D, int H, int W, hipStream_t st, Lin* out);
+
+// ---- field_kernels.hip
+void launch_perturb(const float* v, const float* sigma, const float* eps, float amp, float* out, int C, Vol vol,
+                    uint64_t seed, uint64_t iteration, const uint64_t* dev_iteration, hipStream_t st);
+void launch_conv_axis(const float* in, float* out, const Taps& taps, int axis, int CC, Vol vol, hipStream_t st);
+void launch_exp_step_fwd(const float* din, float* dout, bool prescale, int no_steps, int C, Vol vol, Lin lin,
+                         hipStream_t st);
+void launch_exp_step_bwd(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
+                         Lin lin, hipStream_t st);
+void launch_svf_outputs(const float* d, float* transformation, float* displacement, int C, Vol vol, Lin lin,
+                        hipStream_t st);
+void launch_warp_fwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha, float* out,
+                     int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration, const uint64_t* dev_iteration,
+                     hipStream_t st);
+void launch_warp_bwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha,
+                     const float* g_warped, float* g_d, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
+                     const uint64_t* dev_iteration, hipStream_t st);
+void launch_warp_transformation(const float* im, int64_t im_stride, const float* t, float* out, int C, Vol vol,
+                                hipStream_t st);
+void launch_warp_nearest_u8(const uint8_t* im, int64_t im_stride, const float* t, uint8_t* out, int C, Vol vol,
+                            hipStream_t st);
+void launch_warp_nearest_i16(const int16_t* im, int64_t im_stride, const float* t, int16_t* out, int C, Vol vol,
+                             hipStream_t st);
+void launch_ffd_axis(const float* in, float* out, const SplineTaps& taps, bool adjoint, int64_t outer, int n_in,
+                     int n_out, int64_t inner, hipStream_t st);
+void launch_scale_channels(const float* in, float* out, float s0, float s1, float s2, int C, int64_t V, hipStream_t st);
+
+// ---- data_kernels.hip
+void launch_lcc_fwd(const float* fhat, int64_t fhat_stride, const float* im, float* z, float* sigma_out, int s, int C,
+                    Vol vol, hipStream_t st);
+struct GmmDev;  // device-side mixture parameters (scalar_kernels.hip)
+// data term + its gradient w.r.t. the warped image (LCC adjoint fused); mode: IRS_DATA_*
+void launch_data_bwd(int mode, const float* fhat_or_fixed, int64_t f_stride, const float* z, const float* sigma_m,
+                     const uint8_t* mask, int64_t mask_stride, const float* g_z_override, const void* dev_state,
+                     int chain, float* g_warped, double* nll_partials, int s, int C_launch, Vol vol, hipStream_t st);
+void launch_stats(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, Vol vol,
+                  hipStream_t st);
+void launch_residual_ssd(const float* fixed, int64_t f_stride, const float* warped, float* z, int C, Vol vol,
+                         hipStream_t st);
+int data_bwd_blocks(int mode, Vol vol);
+void launch_masked_moments(const float* z, const uint8_t* mask, double* partials, Vol vol, hipStream_t st);
+void launch_reg_energy(const float* v, double* partials, int C, Vol vol, hipStream_t st);
+void launch_reduce_partials(const double* partials, int nblocks, int nvals, double* out, hipStream_t st);
+void launch_sgld_update(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
+                        float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st);
+void launch_gradient_operator(const float* v, float* nabla, int transformation, int C, Vol vol, hipStream_t st);
+void launch_log_det_jacobian(const float* t, float* log_det, long long* nan_count, int C, Vol vol, hipStream_t st);
+int stats_blocks(Vol vol);
+int energy_blocks(Vol vol);
+
+// ---- scalar_kernels.hip
+struct DevState;  // full definition in scalar_kernels.h
+}  // namespace irs

@@ -1,0 +1,101 @@
+// Device-resident hyper-parameter state and the single-workgroup "scalar" kernels that replace the
+// reference's host-side scalar autograd (trainer.py:68-77, 316-339; optimizers/adam_rate_decay.py) so that a
+// whole transition runs without a host round trip (the reference syncs at trainer.py:308).
+#pragma once
+#include "common.h"
+
+namespace irs {
+
+constexpr int kStatVals = 5 + 2 * IRS_MAX_COMPONENTS;  // n, sum x^2, 3 lag-1 products, K dNLL/dlog_std, K resp. sums
+
+struct DevState {
+    irs_state st;  // parameters + Adam moments (host-visible layout)
+    // mixture constants derived from st (refreshed whenever the parameters change)
+    float A[IRS_MAX_COMPONENTS];          // log pi_k - log sigma_k - 0.5 log(2 pi)
+    float inv_sigma[IRS_MAX_COMPONENTS];  // exp(-log sigma_k)
+    int K;
+    int mode;  // IRS_DATA_*
+    float ssd_inv_sigma;
+    irs_scalars sc;
+    double coef[IRS_MAX_CHAINS];  // d(reg loss)/d(energy) per chain, consumed by the update kernel
+    double moments[3];            // scratch: n, sum z, sum z^2 (GMM initialisation)
+};
+
+struct DevCfg {
+    int K, mode, vd, C;
+    float gmm_lr_log_std, gmm_lr_logits, gmm_lr_decay, beta1, beta2, eps;
+    float scale_prior_loc, scale_prior_scale;
+    float conc[IRS_MAX_COMPONENTS];
+    int reg_loss, reg_learnable;
+    double dof;
+    float reg_lr0, reg_lr1, reg_lr_decay;
+    float loc_prior_nu, loc_prior_w_reg, reg_scale_prior_loc, reg_scale_prior_scale;
+    double w_reg_prior_shape, w_reg_prior_rate;
+};
+
+// per-voxel mixture evaluation shared by the statistics and the data-term kernels
+struct MixEval {
+    float nll;  // -log p(z)
+    float gz;   // d(-log p)/dz = sum_k r_k z / sigma_k^2
+    float x;    // VD-rescaled residual: sum_k r_k (z / sigma_k)^2   (utils/util.py:330-347, closed form)
+};
+
+template <bool WANT_RESP>
+__device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict__ s, float* resp, float* q) {
+    MixEval e;
+    if (s->mode == IRS_DATA_SSD) {
+        const float u = z * s->ssd_inv_sigma;
+        e.x = u * u;
+        e.nll = 0.5f * e.x;
+        e.gz = u * s->ssd_inv_sigma;
+        return e;
+    }
+    const int K = s->K;
+    float t[IRS_MAX_COMPONENTS], qq[IRS_MAX_COMPONENTS];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < IRS_MAX_COMPONENTS; ++k) {
+        if (k < K) {
+            const float u = z * s->inv_sigma[k];
+            qq[k] = u * u;
+            t[k] = s->A[k] - 0.5f * qq[k];
+            m = fmaxf(m, t[k]);
+        }
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < IRS_MAX_COMPONENTS; ++k) {
+        if (k < K) {
+            t[k] = __expf(t[k] - m);
+            sum += t[k];
+        }
+    }
+    const float inv = 1.0f / sum;
+    e.nll = -(m + __logf(sum));
+    e.x = 0.0f;
+    e.gz = 0.0f;
+#pragma unroll
+    for (int k = 0; k < IRS_MAX_COMPONENTS; ++k) {
+        if (k < K) {
+            const float r = t[k] * inv;
+            e.x += r * qq[k];
+            e.gz += r * z * s->inv_sigma[k] * s->inv_sigma[k];
+            if (WANT_RESP) {
+                resp[k] = r;
+                q[k] = qq[k];
+            }
+        }
+    }
+    return e;
+}
+
+void launch_refresh_derived(DevState* s, DevCfg cfg, hipStream_t st);
+// op bit 0: recompute the VD factor alpha; bit 1: take one GMM Adam step (with the stored alpha)
+void launch_chain_scalar(DevState* s, const double* stat_partials, int nblocks, int chain, int op, DevCfg cfg,
+                         hipStream_t st);
+void launch_reg_scalar(DevState* s, const double* energy_partials, int nblocks, DevCfg cfg, hipStream_t st);
+void launch_finalize(DevState* s, const double* nll_partials, int nblocks_per_chain, DevCfg cfg, bool advance,
+                     hipStream_t st);
+void launch_gmm_init_from_moments(DevState* s, const double* moment_partials, int nblocks, DevCfg cfg, hipStream_t st);
+
+}  // namespace irs

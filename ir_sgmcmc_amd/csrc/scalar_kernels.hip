@@ -1,0 +1,243 @@
+// Single-workgroup kernels for the hyper-parameter side of the transition: deterministic (fixed-order)
+// reduction of per-block partial sums in fp64, the virtual-decimation factor, the GMM Adam step, the
+// regulariser energy terms / coefficients / Adam step, and the loss bookkeeping.
+// Reference: trainer/trainer.py:68-77,316-339,507-514; utils/util.py:446-485; optimizers/adam_rate_decay.py:32-99;
+// model/loss.py:172-312; model/distributions.py.
+#include "scalar_kernels.h"
+
+namespace irs {
+
+// out[j] (j < nvals) = sum_b partials[b * nvals + j], same order every run.  All threads must call.
+template <int NV>
+__device__ void reduce_partials(const double* __restrict__ partials, int nblocks, int nvals, double (&out)[NV],
+                                double* smem) {
+    double acc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (j < nvals) acc[j] += partials[(int64_t)b * nvals + j];
+    }
+    block_sum<NV>(acc, smem);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) out[j] = acc[j];  // valid in thread 0
+}
+
+__device__ void refresh_derived(DevState* s, const DevCfg& cfg) {
+    s->K = cfg.K;
+    s->mode = cfg.mode;
+    // log_softmax(logits + 1e-2) (model/loss.py:67-69), fp32 like the reference
+    float m = -3.0e38f;
+    for (int k = 0; k < cfg.K; ++k) m = fmaxf(m, s->st.gmm_logits[k] + 1e-2f);
+    float sum = 0.0f;
+    for (int k = 0; k < cfg.K; ++k) sum += expf(s->st.gmm_logits[k] + 1e-2f - m);
+    const float lse = m + logf(sum);
+    for (int k = 0; k < cfg.K; ++k) {
+        const float lp = s->st.gmm_logits[k] + 1e-2f - lse;
+        s->A[k] = (lp - s->st.gmm_log_std[k]) - 0.91893853320467274178f;
+        s->inv_sigma[k] = expf(-1.0f * s->st.gmm_log_std[k]);
+    }
+}
+
+// optimizers/adam_rate_decay.py:32-99 for one scalar parameter (the state is never re-initialised on this path):
+// clr = lr / (1 + step * lr_decay); bias corrections count from step 0
+__device__ double adam_step_decay(double p, double g, double& m, double& v, int64_t step_before, double lr,
+                                  double lr_decay, double b1, double b2, double eps) {
+    const double clr = lr / (1.0 + (double)step_before * lr_decay);
+    const double t = (double)(step_before + 1);
+    const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+    m = b1 * m + (1.0 - b1) * g;
+    v = b2 * v + (1.0 - b2) * g * g;
+    const double denom = sqrt(v) / sqrt(bc2) + eps;
+    return p - (clr / bc1) * m / denom;
+}
+
+__global__ __launch_bounds__(kBlock) void refresh_kernel(DevState* s, DevCfg cfg) {
+    if (threadIdx.x == 0) refresh_derived(s, cfg);
+}
+
+void launch_refresh_derived(DevState* s, DevCfg cfg, hipStream_t st) {
+    hipLaunchKernelGGL(refresh_kernel, dim3(1), dim3(kBlock), 0, st, s, cfg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per chain: VD factor (utils/util.py:446-485) and one _step_GMM (trainer.py:68-77)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const double* __restrict__ partials,
+                                                              int nblocks, int chain, int op, DevCfg cfg) {
+    __shared__ double smem[kStatVals * (kBlock / kWave)];
+    double r[kStatVals];
+    reduce_partials<kStatVals>(partials, nblocks, kStatVals, r, smem);
+    if (threadIdx.x != 0) return;
+
+    const double n = r[0];
+    double alpha = (op & 1) ? 1.0 : s->sc.alpha[chain];
+    if (cfg.vd && (op & 1)) {
+        const double var = r[1] / n;
+        double prod = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            const double corr = (r[2 + a] / n) / var;
+            prod *= fmin(-2.0 / 3.14159265358979323846 * log(corr), 1.0);
+        }
+        alpha = sqrt(prod);  // NaN if a lag-1 correlation is negative, as in the reference
+    }
+    s->sc.alpha[chain] = alpha;
+    s->sc.n_mask[chain] = n;
+
+    if (cfg.mode == IRS_DATA_GMM_LCC && (op & 2)) {
+        const int K = cfg.K;
+        const double* Gs = r + 5;
+        const double* Gl = r + 5 + IRS_MAX_COMPONENTS;
+        // proportions pi = softmax(logits + 1e-2)
+        double pi[IRS_MAX_COMPONENTS], mx = -1e300, sum = 0.0, csum = 0.0;
+        for (int k = 0; k < K; ++k) mx = fmax(mx, (double)s->st.gmm_logits[k]);
+        for (int k = 0; k < K; ++k) sum += exp((double)s->st.gmm_logits[k] - mx);
+        for (int k = 0; k < K; ++k) {
+            pi[k] = exp((double)s->st.gmm_logits[k] - mx) / sum;
+            csum += (double)cfg.conc[k] - 1.0;
+        }
+        const double sp2 = (double)cfg.scale_prior_scale * (double)cfg.scale_prior_scale;
+        const int64_t step0 = s->st.gmm_adam_step[0], step1 = s->st.gmm_adam_step[1];
+        for (int k = 0; k < K; ++k) {
+            // d/dlog_std_k [alpha NLL - log N(log_std; loc, scale)]
+            const double g_ls = alpha * Gs[k] + ((double)s->st.gmm_log_std[k] - (double)cfg.scale_prior_loc) / sp2;
+            // d/dlogit_k [alpha NLL - log Dir(log pi)]
+            const double g_lg = alpha * (-Gl[k] + pi[k] * n) + (-((double)cfg.conc[k] - 1.0) + pi[k] * csum);
+            s->st.gmm_log_std[k] = (float)adam_step_decay((double)s->st.gmm_log_std[k], g_ls, s->st.gmm_adam_m[0][k],
+                                                          s->st.gmm_adam_v[0][k], step0, cfg.gmm_lr_log_std,
+                                                          cfg.gmm_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
+            s->st.gmm_logits[k] = (float)adam_step_decay((double)s->st.gmm_logits[k], g_lg, s->st.gmm_adam_m[1][k],
+                                                         s->st.gmm_adam_v[1][k], step1, cfg.gmm_lr_logits,
+                                                         cfg.gmm_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
+        }
+        s->st.gmm_adam_step[0] = step0 + 1;
+        s->st.gmm_adam_step[1] = step1 + 1;
+        refresh_derived(s, cfg);
+    }
+}
+
+void launch_chain_scalar(DevState* s, const double* stat_partials, int nblocks, int chain, int op, DevCfg cfg,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(chain_scalar_kernel, dim3(1), dim3(kBlock), 0, st, s, stat_partials, nblocks, chain, op, cfg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// regulariser: energies -> loss terms, d(loss)/d(energy) coefficients, Adam step on its hyper-parameters
+// energy_partials: [C][nblocks]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void reg_scalar_kernel(DevState* s, const double* __restrict__ partials,
+                                                            int nblocks, DevCfg cfg) {
+    __shared__ double smem[kBlock / kWave];
+    __shared__ double ysh[IRS_MAX_CHAINS];
+    for (int c = 0; c < cfg.C; ++c) {
+        double acc[1] = {0.0};
+        for (int b = threadIdx.x; b < nblocks; b += kBlock) acc[0] += partials[(int64_t)c * nblocks + b];
+        block_sum<1>(acc, smem);
+        if (threadIdx.x == 0) ysh[c] = acc[0];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+
+    const double dof = cfg.dof;
+    if (cfg.reg_loss == IRS_REG_L2) {
+        // model/loss.py:197-198: 0.5 w y - 0.5 dof log w
+        const double lw = s->st.reg_param[0], w = exp(lw);
+        double g_lw = 0.0;
+        for (int c = 0; c < cfg.C; ++c) {
+            const double y = ysh[c];
+            s->sc.reg_energy[c] = y;
+            s->sc.reg_term[c] = 0.5 * w * y - 0.5 * dof * lw;
+            s->coef[c] = 0.5 * w;
+            g_lw += 0.5 * w * y - 0.5 * dof;
+        }
+        if (cfg.reg_learnable) {
+            // minus LogPrecisionExpGammaPrior(log w): d/dx [shape log rate + (shape-1) x - rate e^x - lgamma + x]
+            g_lw -= cfg.w_reg_prior_shape - cfg.w_reg_prior_rate * w;
+            const int64_t st0 = s->st.reg_adam_step[0];
+            s->st.reg_param[0] = adam_step_decay(lw, g_lw, s->st.reg_adam_m[0], s->st.reg_adam_v[0], st0, cfg.reg_lr0,
+                                                 cfg.reg_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
+            s->st.reg_adam_step[0] = st0 + 1;
+        }
+    } else {
+        // model/loss.py:266-312: log y + log s + 0.5 ((log y - loc)/s)^2 + (dof/2 - 1) log y
+        const double loc = s->st.reg_param[0], ls = s->st.reg_param[1], sc = exp(ls);
+        double g_loc = 0.0, g_ls = 0.0;
+        for (int c = 0; c < cfg.C; ++c) {
+            const double y = ysh[c], ly = log(y), u = (ly - loc) / sc;
+            s->sc.reg_energy[c] = y;
+            s->sc.reg_term[c] = ly + ls + 0.5 * u * u + (0.5 * dof - 1.0) * ly;
+            double dly = 1.0 + u / sc + (0.5 * dof - 1.0);
+            if (cfg.reg_learnable) {
+                // minus LogEnergyExpGammaPrior evaluated AT log y (trainer.py:336): -(a - 1) - 1 + b y
+                const double a = 0.5 * (double)cfg.loc_prior_nu * dof, b = 0.5 * (double)cfg.loc_prior_nu * (double)cfg.loc_prior_w_reg;
+                dly += -a + b * y;
+            }
+            s->coef[c] = dly / y;
+            g_loc += -u / sc;
+            g_ls += 1.0 - u * u;
+        }
+        if (cfg.reg_learnable) {
+            const double ps = (double)cfg.reg_scale_prior_scale;
+            g_ls += (ls - (double)cfg.reg_scale_prior_loc) / (ps * ps);  // minus LogScaleNormalPrior(log_scale)
+            const int64_t st0 = s->st.reg_adam_step[0], st1 = s->st.reg_adam_step[1];
+            s->st.reg_param[0] = adam_step_decay(loc, g_loc, s->st.reg_adam_m[0], s->st.reg_adam_v[0], st0, cfg.reg_lr0,
+                                                 cfg.reg_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
+            s->st.reg_param[1] = adam_step_decay(ls, g_ls, s->st.reg_adam_m[1], s->st.reg_adam_v[1], st1, cfg.reg_lr1,
+                                                 cfg.reg_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
+            s->st.reg_adam_step[0] = st0 + 1;
+            s->st.reg_adam_step[1] = st1 + 1;
+        }
+    }
+}
+
+void launch_reg_scalar(DevState* s, const double* energy_partials, int nblocks, DevCfg cfg, hipStream_t st) {
+    hipLaunchKernelGGL(reg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, s, energy_partials, nblocks, cfg);
+}
+
+// data_term[c] = alpha_c * sum(-log p(z_c)) with the parameters in force for chain c; advance the Philox counter
+__global__ __launch_bounds__(kBlock) void finalize_kernel(DevState* s, const double* __restrict__ partials,
+                                                          int nblocks_per_chain, DevCfg cfg, int advance) {
+    __shared__ double smem[kBlock / kWave];
+    for (int c = 0; c < cfg.C; ++c) {
+        double acc[1] = {0.0};
+        for (int b = threadIdx.x; b < nblocks_per_chain; b += kBlock) acc[0] += partials[(int64_t)c * nblocks_per_chain + b];
+        block_sum<1>(acc, smem);
+        if (threadIdx.x == 0) s->sc.data_term[c] = s->sc.alpha[c] * acc[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && advance) s->st.iteration += 1;
+}
+
+void launch_finalize(DevState* s, const double* nll_partials, int nblocks_per_chain, DevCfg cfg, bool advance,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, st, s, nll_partials, nblocks_per_chain, cfg,
+                       advance ? 1 : 0);
+}
+
+// GMM.init_parameters (model/loss.py:61-65) from the unbiased std of the masked residuals (trainer.py:537-541)
+__global__ __launch_bounds__(kBlock) void gmm_init_kernel(DevState* s, const double* __restrict__ partials, int nblocks,
+                                                          DevCfg cfg) {
+    __shared__ double smem[3 * (kBlock / kWave)];
+    double r[3];
+    reduce_partials<3>(partials, nblocks, 3, r, smem);
+    if (threadIdx.x != 0) return;
+    const double n = r[0], mean = r[1] / n;
+    const double var = (r[2] - n * mean * mean) / (n - 1.0);
+    const float sd = (float)sqrt(var);
+    s->moments[0] = n;
+    s->moments[1] = mean;
+    s->moments[2] = (double)sd;
+    const float lo = logf(sd / 100.0f), hi = logf(sd * 5.0f);
+    const int K = cfg.K;
+    // torch.linspace(lo, hi, K): start + step*i below the midpoint, end - step*(K-1-i) above
+    const float step = K > 1 ? (hi - lo) / (float)(K - 1) : 0.0f;
+    for (int k = 0; k < K; ++k) s->st.gmm_log_std[k] = k < K / 2 ? lo + step * (float)k : hi - step * (float)(K - 1 - k);
+    refresh_derived(s, cfg);
+}
+
+void launch_gmm_init_from_moments(DevState* s, const double* moment_partials, int nblocks, DevCfg cfg, hipStream_t st) {
+    hipLaunchKernelGGL(gmm_init_kernel, dim3(1), dim3(kBlock), 0, st, s, moment_partials, nblocks, cfg);
+}
+
+}  // namespace irs

@@ -1,0 +1,186 @@
+"""`TransitionEngine`: Python owner of one `irs_ctx` (include/irsgmcmc.h) -- the fused SG-MCMC transition.
+
+This is what `Trainer._SGLD_transition` (ir_sgmcmc_amd/trainer/trainer.py) drives.  All tensors stay on the GPU; the
+hyper-parameters (GMM, regulariser, Adam moments) live in a small device struct and are only copied to the host when
+somebody asks for them (`state()`, `scalars()`), so a transition needs no host synchronisation at all.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Sequence, Tuple
+
+import torch
+from scipy.special import digamma
+
+from . import _lib as L
+from .ops import control_grid_size, sobolev_kernel_1d
+
+
+@dataclass
+class EngineConfig:
+    """Flat mirror of the config.json keys the transition depends on (configs/*/config.json of the reference)."""
+    dims: Tuple[int, int, int]
+    no_chains: int = 1
+    cps: Optional[Tuple[int, int, int]] = None          # transformation_module: SVFFD_3D args.cps
+    no_steps: int = 12
+    sobolev_s: int = 3                                    # Sobolev_grad.s (0 = disabled)
+    sobolev_lambda: float = 0.5
+    lr: float = 0.4                                       # optimizer_SG_MCMC.args.lr
+    uniform_noise: float = 0.1                            # trainer.uniform_noise.magnitude (0 = disabled)
+    virtual_decimation: bool = True
+    data_loss: str = 'GMM'                                # 'GMM' (reference) | 'SSD' (builder-defined)
+    gmm_components: int = 4
+    lcc_s: int = 1
+    ssd_sigma: float = 0.1
+    gmm_lr_log_std: float = 0.2
+    gmm_lr_logits: float = 0.2
+    gmm_lr_decay: float = 0.001
+    scale_prior: Tuple[float, float] = (0.0, 2.3)
+    dirichlet_alpha: Sequence[float] = field(default_factory=lambda: [0.5])
+    reg_loss: str = 'RegLoss_L2'
+    w_reg: float = 1.4
+    reg_learnable: bool = False
+    reg_lr: Tuple[float, float] = (0.01, 0.01)
+    reg_lr_decay: float = 0.001
+    loc_prior_nu: float = 1.0
+    loc_prior_w_reg: Optional[float] = None
+    reg_scale_prior: Tuple[float, float] = (2.8, 5.0)
+    seed: int = 0
+
+    @property
+    def dims_v(self):
+        return control_grid_size(self.dims, self.cps) if self.cps else tuple(self.dims)
+
+    @property
+    def dof(self):
+        return float(self.dims[0] * self.dims[1] * self.dims[2]) * 3.0  # parse_config.py:120,128
+
+
+def lognormal_init(w_reg, dof, nu=1.0):
+    """loc0 = digamma(nu dof / 2) - log(nu w / 2), log_scale0 = log 4 + log loc0 (model/loss.py:298-303)."""
+    loc = float(digamma(0.5 * nu * dof)) - math.log(0.5 * nu * w_reg)
+    return loc, math.log(4.0) + math.log(loc)
+
+
+class TransitionEngine:
+    def __init__(self, cfg: EngineConfig, device='cuda:0'):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.lib = L.load()
+        c = L.IrsConfig()
+        c.dims[:] = list(cfg.dims)
+        c.cps[:] = list(cfg.cps) if cfg.cps else [0, 0, 0]
+        c.no_chains, c.no_steps = cfg.no_chains, cfg.no_steps
+        c.sobolev_s = cfg.sobolev_s or 0
+        if c.sobolev_s:
+            k = sobolev_kernel_1d(cfg.sobolev_s, cfg.sobolev_lambda)
+            for i, x in enumerate(k):
+                c.sobolev_kernel[i] = float(x)
+        c.lr = cfg.lr
+        c.uniform_alpha = cfg.uniform_noise or 0.0
+        c.virtual_decimation = int(cfg.virtual_decimation)
+        c.data_loss = L.IRS_DATA_GMM_LCC if cfg.data_loss == 'GMM' else L.IRS_DATA_SSD
+        c.lcc_s, c.gmm_components, c.ssd_sigma = cfg.lcc_s, cfg.gmm_components, cfg.ssd_sigma
+        c.gmm_lr_log_std, c.gmm_lr_logits, c.gmm_lr_decay = cfg.gmm_lr_log_std, cfg.gmm_lr_logits, cfg.gmm_lr_decay
+        c.adam_beta1, c.adam_beta2, c.adam_eps = 0.9, 0.999, 1e-8
+        c.scale_prior_loc, c.scale_prior_scale = cfg.scale_prior
+        conc = list(cfg.dirichlet_alpha)
+        if len(conc) == 1:
+            conc = conc * cfg.gmm_components
+        for i, x in enumerate(conc):
+            c.dirichlet_concentration[i] = float(x)
+        c.reg_loss = {'RegLoss_L2': L.IRS_REG_L2, 'RegLoss_LogNormal': L.IRS_REG_LOGNORMAL}[cfg.reg_loss]
+        c.reg_learnable = int(cfg.reg_learnable)
+        c.w_reg, c.dof = cfg.w_reg, cfg.dof
+        c.reg_lr0, c.reg_lr1, c.reg_lr_decay = cfg.reg_lr[0], cfg.reg_lr[1], cfg.reg_lr_decay
+        c.loc_prior_nu = cfg.loc_prior_nu
+        c.loc_prior_w_reg = cfg.w_reg if cfg.loc_prior_w_reg is None else cfg.loc_prior_w_reg
+        c.reg_scale_prior_loc, c.reg_scale_prior_scale = cfg.reg_scale_prior
+        shape = 0.5 * cfg.dof  # parse_config.py:136-140
+        c.w_reg_prior_shape, c.w_reg_prior_rate = shape, 1.0 / shape
+        c.seed = cfg.seed
+        self._c = c
+        ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.irs_create(C.byref(c), C.byref(ctx)))
+        self._ctx = ctx
+        self._keep = {}
+        if cfg.reg_loss == 'RegLoss_LogNormal':
+            st = self.state()
+            st.reg_param[0], st.reg_param[1] = lognormal_init(cfg.w_reg, cfg.dof)
+            self.set_state(st)
+
+    def __del__(self):
+        ctx, self._ctx = getattr(self, '_ctx', None), None
+        if ctx:
+            try:
+                self.lib.irs_destroy(ctx)
+            except Exception:
+                pass
+
+    # ---------------------------------------------------------------- small state
+    @property
+    def workspace_bytes(self):
+        return int(self.lib.irs_workspace_bytes(self._ctx))
+
+    def state(self):
+        st = L.IrsState()
+        L.check(self.lib.irs_get_state(self._ctx, C.byref(st), L.stream_ptr()))
+        return st
+
+    def set_state(self, st):
+        L.check(self.lib.irs_set_state(self._ctx, C.byref(st), L.stream_ptr()))
+
+    def scalars(self):
+        sc = L.IrsScalars()
+        L.check(self.lib.irs_get_scalars(self._ctx, C.byref(sc), L.stream_ptr()))
+        n = self.cfg.no_chains
+        return {k: [getattr(sc, k)[i] for i in range(n)] for k in ('alpha', 'data_term', 'reg_term', 'reg_energy', 'n_mask')}
+
+    # ---------------------------------------------------------------- data
+    def _io(self, fixed, moving, v, sigma=None, eps=None, unif=None, outputs=None):
+        io = L.IrsIO()
+        f_im, m_im, mask = fixed['im'], moving['im'], fixed['mask']
+        io.fixed_im, io.moving_im = L.dev_ptr(f_im, torch.float32), L.dev_ptr(m_im, torch.float32)
+        io.mask = L.dev_ptr(mask, torch.bool)
+        io.fixed_chains, io.moving_chains, io.mask_chains = f_im.shape[0], m_im.shape[0], mask.shape[0]
+        io.v = L.dev_ptr(v, torch.float32, allow_none=True)
+        io.sigma = L.dev_ptr(sigma, torch.float32, allow_none=True)
+        io.eps = L.dev_ptr(eps, torch.float32, allow_none=True)
+        io.unif = L.dev_ptr(unif, torch.float32, allow_none=True)
+        for k in ('curr_state', 'im_moving_warped', 'residuals', 'displacement', 'transformation', 'grad_v'):
+            t = (outputs or {}).get(k)
+            setattr(io, k, L.dev_ptr(t, torch.float32, allow_none=True))
+        return io
+
+    @staticmethod
+    def _base(t):
+        """`fixed['im'].expand(C, ...)` views (trainer.py:361-362) share one volume: hand the library the (1,...) base."""
+        if t.dim() == 5 and t.stride(0) == 0 and t.shape[0] > 1:
+            t = t[:1]
+        return t.contiguous()
+
+    def prepare(self, fixed, moving):
+        """Normalise dict inputs (collapse expanded chains) and pre-normalise the fixed image for the LCC map."""
+        fixed = {k: self._base(v) for k, v in fixed.items() if k in ('im', 'mask')}
+        moving = {k: self._base(v) for k, v in moving.items() if k in ('im',)}
+        self._keep['fixed'], self._keep['moving'] = fixed, moving
+        L.check(self.lib.irs_set_fixed(self._ctx, L.dev_ptr(fixed['im'], torch.float32), fixed['im'].shape[0],
+                                       L.stream_ptr()))
+        return fixed, moving
+
+    def gmm_init(self, fixed, moving, v_sample=None, warm_up=25):
+        """Trainer.__GMM_init (trainer.py:529-547)."""
+        io = self._io(fixed, moving, None)
+        L.check(self.lib.irs_gmm_init(self._ctx, C.byref(io), L.dev_ptr(v_sample, torch.float32, allow_none=True),
+                                      warm_up, L.stream_ptr()))
+
+    def transition(self, fixed, moving, v, sigma=None, eps=None, unif=None, outputs=None, timed=False):
+        """One `_SGLD_transition`; updates `v` in place.  outputs: dict of preallocated tensors to fill."""
+        io = self._io(fixed, moving, v, sigma, eps, unif, outputs)
+        if timed:
+            tot, ex = C.c_float(), C.c_float()
+            L.check(self.lib.irs_transition_timed(self._ctx, C.byref(io), L.stream_ptr(), C.byref(tot), C.byref(ex)))
+            return tot.value, ex.value
+        L.check(self.lib.irs_transition(self._ctx, C.byref(io), L.stream_ptr()))
+        return None

@@ -1,0 +1,165 @@
+"""Operator-level parity of the HIP kernels (through the C ABI) against the CPU oracle.  GPU only."""
+import math
+
+import pytest
+import torch
+
+from ir_sgmcmc_amd import ops as G
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(t):
+    return t.to(DEV).contiguous()
+
+
+def maxdiff(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+def smooth_field(C, dims, amp, seed):
+    g = torch.Generator().manual_seed(seed)
+    return O.separable_conv3d_replicate(amp * torch.randn(C, 3, *dims, generator=g), O.sobolev_kernel_1d(3, 0.5)).contiguous()
+
+
+@pytest.mark.parametrize('dims', [(16, 16, 16), (12, 20, 28)])
+@pytest.mark.parametrize('s', [1, 3])
+def test_perturb_smooth(dims, s):
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(2, 3, *dims, generator=g)
+    sigma = torch.rand(2, 3, *dims, generator=g) + 0.5
+    eps = torch.randn(2, 3, *dims, generator=g)
+    k = G.sobolev_kernel_1d(s, 0.5)
+    ref = O.separable_conv3d_replicate(O.langevin_perturb(v, sigma, 0.4, eps), k)
+    out = G.perturb_smooth(dev(v), k, dev(sigma), dev(eps), tau=0.4)
+    assert maxdiff(out, ref) < 2e-6
+    # smoothing only, all-ones 3-tap kernel -> 27 (reference tests/test_utils.py:101-151)
+    ones = torch.zeros(2, 3, 16, 16, 16)
+    ones[0, 1], ones[1, 2] = 1.0, 1.0
+    out = G.perturb_smooth(dev(ones), [1.0, 1.0, 1.0])
+    assert maxdiff(out, 27.0 * ones) < 1e-4
+
+
+def test_philox_noise_statistics():
+    v = torch.zeros(1, 3, 64, 64, 64, device=DEV)
+    a = G.perturb_smooth(v, None, tau=0.5, seed=7, iteration=3)   # sqrt(2 tau) = 1 -> N(0,1)
+    b = G.perturb_smooth(v, None, tau=0.5, seed=7, iteration=3)
+    c = G.perturb_smooth(v, None, tau=0.5, seed=7, iteration=4)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    x = a.double().flatten()
+    n = x.numel()
+    assert abs(float(x.mean())) < 5.0 / math.sqrt(n)
+    assert abs(float(x.var()) - 1.0) < 5.0 * math.sqrt(2.0 / n)
+    assert abs(float((x ** 4).mean()) - 3.0) < 0.05
+    # channels / neighbours uncorrelated
+    assert abs(float((a[0, 0] * a[0, 1]).double().mean())) < 5.0 / math.sqrt(n / 3)
+    assert abs(float((a[0, 0, :, :, 1:] * a[0, 0, :, :, :-1]).double().mean())) < 5.0 / math.sqrt(n / 3)
+
+
+@pytest.mark.parametrize('dims,amp', [((16, 16, 16), 2.0), ((16, 16, 16), 25.0), ((10, 14, 22), 6.0), ((32, 32, 32), 5.0)])
+def test_svf_exp_forward(dims, amp):
+    v = smooth_field(2, dims, amp, 1)
+    t_ref, d_ref, steps_ref = O.svf_exp(v, 12, keep_steps=True)
+    t, d, steps = G.svf_exp_fwd(dev(v), 12)
+    assert maxdiff(steps[0], steps_ref[1]) < 1e-9 + 1e-6 * float(steps_ref[1].abs().max())
+    assert maxdiff(steps[-1], steps_ref[-1]) < 2e-6 * max(1.0, float(steps_ref[-1].abs().max()))
+    assert maxdiff(d, d_ref) < 1e-4   # north-star tolerance on the displacement (voxels)
+    assert maxdiff(d, d_ref) < 2e-5 * max(1.0, float(d_ref.abs().max()))
+    assert maxdiff(t, t_ref) < 1e-5
+
+
+@pytest.mark.parametrize('dims,amp', [((16, 16, 16), 2.0), ((16, 16, 16), 25.0), ((10, 14, 22), 6.0)])
+def test_svf_exp_backward(dims, amp):
+    v = smooth_field(1, dims, amp, 2).requires_grad_(True)
+    g = torch.Generator().manual_seed(3)
+    g_last = torch.randn(1, 3, *dims, generator=g)
+    _, _, steps_ref = O.svf_exp(v, 12, keep_steps=True)
+    gv_ref, = torch.autograd.grad(steps_ref[-1], v, g_last)
+    _, _, steps = G.svf_exp_fwd(dev(v.detach()), 12, want_outputs=False)
+    gv = G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last))
+    assert maxdiff(gv, gv_ref) < 2e-5 * float(gv_ref.abs().max())
+
+
+@pytest.mark.parametrize('N,cps', [(16, 4), (16, 2), (17, 4), (20, 3)])
+def test_ffd_up_and_adjoint(N, cps):
+    dims, c = (N,) * 3, (cps,) * 3
+    Gd = O.control_grid_size(dims, c)
+    g = torch.Generator().manual_seed(4)
+    v = torch.randn(2, 3, *Gd, generator=g).requires_grad_(True)
+    ref = O.ffd_upsample(v, dims, c)
+    out = G.ffd_up(dev(v.detach()), dims, c)
+    assert maxdiff(out, ref) < 2e-6
+    gd = torch.randn(2, 3, *dims, generator=g)
+    gref, = torch.autograd.grad(ref, v, gd)
+    gout = G.ffd_adjoint(dev(gd), c)
+    assert maxdiff(gout, gref) < 1e-5
+
+
+@pytest.mark.parametrize('alpha', [0.0, 0.1])
+def test_warp_forward_backward(alpha):
+    dims = (14, 18, 22)
+    g = torch.Generator().manual_seed(5)
+    im = torch.rand(1, 1, *dims, generator=g)
+    v = smooth_field(2, dims, 8.0, 6)
+    t_ref, _, steps = O.svf_exp(v, 12, keep_steps=True)
+    d_last = steps[-1].clone().requires_grad_(True)
+    unif = torch.rand(2, 3, *dims, generator=g) if alpha > 0 else None
+    grid = O.identity_grid(dims).permute(0, 4, 1, 2, 3) + d_last
+    if alpha > 0:
+        grid = O.jitter_grid(grid, alpha, unif)
+    ref = O.warp_trilinear(im.expand(2, -1, -1, -1, -1), grid)
+    out = G.warp_displacement(dev(im), dev(d_last.detach()), dev(unif) if alpha > 0 else None, alpha)
+    assert maxdiff(out, ref) < 2e-6
+    gw = torch.randn(2, 1, *dims, generator=g)
+    gref, = torch.autograd.grad(ref, d_last, gw)
+    gout = G.warp_displacement_bwd(dev(im), dev(d_last.detach()), dev(gw), dev(unif) if alpha > 0 else None, alpha)
+    assert maxdiff(gout, gref) < 2e-5 * float(gref.abs().max())
+    # public RegistrationModule path on an explicit transformation, float + nearest
+    out2 = G.warp(dev(im), dev(t_ref))
+    assert maxdiff(out2, O.warp_trilinear(im.expand(2, -1, -1, -1, -1), t_ref)) < 2e-6
+    seg = (torch.rand(1, 1, *dims, generator=g) * 50).to(torch.int16)
+    assert torch.equal(G.warp(dev(seg), dev(t_ref)).cpu(), O.warp_nearest(seg.expand(2, -1, -1, -1, -1), t_ref))
+    msk = torch.rand(1, 1, *dims, generator=g) > 0.5
+    assert torch.equal(G.warp(dev(msk), dev(t_ref)).cpu(), O.warp_nearest(msk.expand(2, -1, -1, -1, -1), t_ref))
+    with pytest.raises(NotImplementedError):
+        G.warp(dev(im).double(), dev(t_ref))
+
+
+@pytest.mark.parametrize('dims', [(16, 16, 16), (12, 20, 40), (9, 8, 33)])
+@pytest.mark.parametrize('s', [1, 2])
+def test_lcc_forward_backward(dims, s):
+    g = torch.Generator().manual_seed(7)
+    F = torch.rand(1, 1, *dims, generator=g)
+    M = (torch.rand(2, 1, *dims, generator=g)).requires_grad_(True)
+    fhat_ref, _, _ = O.lcc_normalise(F, s)
+    fhat, sig = G.lcc_normalise(dev(F), s, want_sigma=True)
+    assert maxdiff(fhat, fhat_ref) < 2e-5
+    z_ref = O.lcc_map(F.expand(2, -1, -1, -1, -1), M, s)
+    z, sigm = G.lcc_map_fwd(fhat, dev(M.detach()), s)
+    assert maxdiff(z, z_ref) < 5e-5
+    gz = torch.randn(2, 1, *dims, generator=g)
+    gref, = torch.autograd.grad(z_ref, M, gz)
+    gout = G.lcc_map_bwd(fhat, z, sigm, dev(gz), s)
+    assert maxdiff(gout, gref) < 1e-4 * float(gref.abs().max())
+
+
+def test_reg_energy_gradient_operator_and_det_j():
+    dims = (10, 12, 14)
+    v = smooth_field(2, dims, 3.0, 8)
+    assert torch.allclose(G.reg_energy(dev(v)).cpu(), O.reg_energy(v).double(), rtol=1e-6)
+    assert maxdiff(G.gradient_operator(dev(v)), O.forward_differences(v)) < 1e-6
+    # reference tests/test_diff.py: uniform field -> 0, identity -> log det J = 0, 2x stretch -> log 8
+    u = torch.zeros(1, 3, 16, 16, 16)
+    u[0, 0], u[0, 1], u[0, 2] = 5.0, 4.0, 2.0
+    assert float(G.gradient_operator(dev(u)).abs().max()) < 1e-4
+    ident = O.identity_grid((16, 16, 16)).permute(0, 4, 1, 2, 3).contiguous()
+    cnt, ld = G.log_det_jacobian(dev(ident))
+    assert int(cnt[0]) == 0 and float(ld.abs().max()) < 1e-4
+    cnt, ld = G.log_det_jacobian(dev(ident + (ident + 1.0)))
+    assert int(cnt[0]) == 0 and float((ld - math.log(8.0)).abs().max()) < 1e-4
+    t, _ = O.svf_exp(smooth_field(1, (16, 16, 16), 60.0, 9))  # folds somewhere
+    cnt, ld = G.log_det_jacobian(dev(t))
+    ld_ref = O.det_jacobian(O.forward_differences(t, transformation=True)).log()
+    assert int(cnt[0]) == int(torch.isnan(ld_ref).sum())
