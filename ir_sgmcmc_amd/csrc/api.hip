@@ -159,9 +159,9 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
 
 static void prescale_factors(Vol vol, int no_steps, float s[3]) {
     const double p = 1.0 / (double)(1 << no_steps);
-    s[0] = (float)(2.0 / (double)(vol.D - 1) * p);  // channel/dim pairing of utils/util.py:426-427 (sic)
+    s[0] = (float)(2.0 / (double)(vol.W - 1) * p);  // x <-> W, y <-> H, z <-> D
     s[1] = (float)(2.0 / (double)(vol.H - 1) * p);
-    s[2] = (float)(2.0 / (double)(vol.W - 1) * p);
+    s[2] = (float)(2.0 / (double)(vol.D - 1) * p);
 }
 
 int irs_svf_exp_bwd(const float* v, const float* steps, const float* g_last, float* scratch, float* g_v, int no_steps,

@@ -85,7 +85,8 @@ void launch_conv_axis(const float* in, float* out, const Taps& taps, int axis, i
 // (for the centre value and for every tap), so d_0 is never materialised.
 // ------------------------------------------------------------------------------------------------
 struct Scale3 {
-    float nm1[3];   // shape[2 + c] - 1 for channel c (the reference scales channel c by dims[c]: D, H, W order)
+    float nm1[3];   // axis length - 1 for channel c: x <-> W, y <-> H, z <-> D (the reference pairs channel c with
+                    // shape[2 + c], which is the same thing for the cubic volumes it supports)
     float inv_pow;  // 1 / 2^no_steps
 };
 
@@ -138,9 +139,9 @@ __global__ __launch_bounds__(kBlock) void exp_step_fwd_kernel(const float* __res
 
 static Scale3 make_scale(Vol vol, int no_steps) {
     Scale3 s;
-    s.nm1[0] = (float)(vol.D - 1);  // channel 0 scaled by shape[2] - 1 (utils/util.py:426-427), sic
+    s.nm1[0] = (float)(vol.W - 1);
     s.nm1[1] = (float)(vol.H - 1);
-    s.nm1[2] = (float)(vol.W - 1);
+    s.nm1[2] = (float)(vol.D - 1);
     s.inv_pow = 1.0f / (float)(1 << no_steps);
     return s;
 }
@@ -253,7 +254,7 @@ void launch_svf_outputs(const float* d, float* transformation, float* displaceme
 // ------------------------------------------------------------------------------------------------
 struct Jitter {
     float alpha;       // <= 0: disabled
-    float nm1[3];      // transform_coordinates scaling of the jitter, same (sic) channel/dim pairing
+    float nm1[3];      // transform_coordinates scaling of the jitter (x <-> W, y <-> H, z <-> D)
     uint64_t seed, iteration;
     const uint64_t* dev_iter;
 };
@@ -316,9 +317,9 @@ __global__ __launch_bounds__(kBlock) void warp_fwd_kernel(const float* __restric
 static Jitter make_jitter(float alpha, Vol vol, uint64_t seed, uint64_t iteration, const uint64_t* dev_iter) {
     Jitter j;
     j.alpha = alpha;
-    j.nm1[0] = (float)(vol.D - 1);
+    j.nm1[0] = (float)(vol.W - 1);
     j.nm1[1] = (float)(vol.H - 1);
-    j.nm1[2] = (float)(vol.W - 1);
+    j.nm1[2] = (float)(vol.D - 1);
     j.seed = seed;
     j.iteration = iteration;
     j.dev_iter = dev_iter;

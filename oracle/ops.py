@@ -105,11 +105,14 @@ class _SobolevStraightThrough(torch.autograd.Function):
 
 
 def identity_grid(dims):
-    """(1, D, H, W, 3) grid in [-1, 1]; channel 0 = x runs along the LAST tensor axis.
+    """(1, D, H, W, 3) grid in [-1, 1] for dims = (D, H, W); channel 0 = x runs along the LAST tensor axis.
 
-    utils/util.py:263-278 (nx, ny, nz = dims[0], dims[1], dims[2]; cubic volumes in practice).
+    utils/util.py:263-278.  The reference reads `nx, ny, nz = dims[0], dims[1], dims[2]` and therefore only works
+    for cubic volumes (all its configs and tests are cubic; anything else raises a shape error at
+    utils/transformation.py:71).  For cubic volumes this function is identical; for non-cubic ones it is the
+    consistent generalisation (x <-> W, y <-> H, z <-> D) -- builder-defined, no reference behaviour exists.
     """
-    nx, ny, nz = dims[0], dims[1], dims[2]
+    nz, ny, nx = dims[0], dims[1], dims[2]
     x = torch.linspace(-1, 1, steps=nx).view(1, 1, nx).expand(nz, ny, nx)
     y = torch.linspace(-1, 1, steps=ny).view(1, ny, 1).expand(nz, ny, nx)
     z = torch.linspace(-1, 1, steps=nz).view(nz, 1, 1).expand(nz, ny, nx)
@@ -117,14 +120,16 @@ def identity_grid(dims):
 
 
 def to_normalised(field):
-    """voxel units -> [-1, 1] units; channel i scaled by 2 / (shape[2 + i] - 1)  (utils/util.py:418-429)."""
-    scale = torch.tensor([2.0 / float(n - 1) for n in field.shape[2:]], dtype=field.dtype)
+    """voxel units -> [-1, 1] units (utils/util.py:418-429).  The reference scales channel i by 2 / (shape[2 + i] - 1),
+    which pairs x with D: harmless for the cubic volumes it supports; here channel c is paired with its own axis
+    (x <-> W, y <-> H, z <-> D), identical for cubic volumes."""
+    scale = torch.tensor([2.0 / float(n - 1) for n in reversed(field.shape[2:])], dtype=field.dtype)
     return field * scale.view(1, -1, 1, 1, 1)
 
 
 def to_voxels(field):
-    """[-1, 1] units -> voxel units (utils/util.py:432-443)."""
-    scale = torch.tensor([float(n - 1) / 2.0 for n in field.shape[2:]], dtype=field.dtype)
+    """[-1, 1] units -> voxel units (utils/util.py:432-443); same axis pairing as `to_normalised`."""
+    scale = torch.tensor([float(n - 1) / 2.0 for n in reversed(field.shape[2:])], dtype=field.dtype)
     return field * scale.view(1, -1, 1, 1, 1)
 
 

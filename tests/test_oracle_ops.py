@@ -116,7 +116,7 @@ def test_explicit_trilinear_matches_aten(scale):
     torch.manual_seed(0)
     B, Cn, D, H, W = 2, 3, 7, 9, 11
     inp = torch.randn(B, Cn, D, H, W, requires_grad=True)
-    grid = (ops.identity_grid((W, H, D)) + scale * 0.2 * torch.randn(B, D, H, W, 3)).requires_grad_(True)
+    grid = (ops.identity_grid((D, H, W)) + scale * 0.2 * torch.randn(B, D, H, W, 3)).requires_grad_(True)
     # exercise exact-border and out-of-range coordinates
     with torch.no_grad():
         grid[0, 0, 0, :, 0] = 1.0
