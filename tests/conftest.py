@@ -25,3 +25,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+# ---- parity report: every GPU parity test records its worst deviation next to the tolerance it was held to;
+# written to gpurun_out/parity_report.json at session end (copied into profiles/ for the record)
+PARITY = {}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import json
+    if not PARITY:
+        return
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'parity_report.json'), 'w') as f:
+        json.dump(PARITY, f, indent=1, sort_keys=True)
