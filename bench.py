@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- SG-MCMC transitions/s of the HIP path on synthetic volumes (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 256] [--loss gmm|ssd]
+
+A "step" is one full `_SGLD_transition` (noise + Sobolev, 12-step scaling and squaring, warp, LCC/GMM data term with
+virtual decimation, regulariser, backward, SGLD update) over one synthetic fixed/moving pair resident in HBM, with
+in-kernel Philox noise.  One process per GPU; for N > 1 the driver launches this file under torch.distributed.run and
+every rank samples its own chain of the same pair (no data-path collective: chains only share hyper-parameters in the
+reference, trainer.py:316-327) -> weak scaling in chains; value = all ranks' transitions / max-over-ranks wall time.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the adjoint of one squaring step): algorithmic
+bytes per launch (36 B/voxel: read dL/dd_{k+1} 12 + read d_k 12 + write dL/dd_k 12) over its average duration measured
+with HIP events on the launch stream inside `irs_transition_timed`.  `cpu_baseline` times the CPU oracle (torch, all
+host cores) on a bounded sample and is a reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+BYTES_PER_VOXEL = {'gmm': 878.0, 'ssd': 854.0}  # algorithmic bytes / voxel / chain / transition
+BWD_STEP_BYTES_PER_VOXEL = 36.0
+FWD_STEP_BYTES_PER_VOXEL = 24.0
+
+
+def cpu_baseline(n_small, reps, loss):
+    """the CPU oracle (op-for-op the reference's ATen sequence) on a bounded sample, all host cores"""
+    import torch
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    from oracle import OracleChain, OracleConfig
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    dims = (n_small,) * 3
+    cfg = OracleConfig(dims=dims, data_loss='GMM' if loss == 'gmm' else 'SSD', virtual_decimation=(loss == 'gmm'))
+    f1, m1 = synthetic_pair(dims, seed=0)
+    fixed = {k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'}
+    moving = {k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'}
+    ch = OracleChain(cfg)
+    ch.init_gmm(fixed, moving)
+    g = torch.Generator().manual_seed(0)
+    eps = torch.randn(1, 3, *dims, generator=g)
+    unif = torch.rand(1, 3, *dims, generator=g)
+    ch.transition(fixed, moving, eps, unif)  # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ch.transition(fixed, moving, eps, unif)
+    dt = (time.perf_counter() - t0) / reps
+    return dt, cores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--size', type=int, default=256, help='volume edge N (N^3 voxels)')
+    ap.add_argument('--loss', choices=['gmm', 'ssd'], default='gmm')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-size', type=int, default=128)
+    ap.add_argument('--cpu-reps', type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    from ir_sgmcmc_amd.engine import EngineConfig, TransitionEngine
+
+    N = args.size
+    dims = (N, N, N)
+    V = N ** 3
+    cfg = EngineConfig(dims=dims, no_chains=1, data_loss='GMM' if args.loss == 'gmm' else 'SSD',
+                       virtual_decimation=(args.loss == 'gmm'), reg_loss='RegLoss_L2', w_reg=1.4, seed=1234 + rank)
+    eng = TransitionEngine(cfg, dev)
+    f1, m1 = synthetic_pair(dims, seed=0)
+    fixed = {k: v.unsqueeze(0).to(dev) for k, v in f1.items() if k != 'seg'}
+    moving = {k: v.unsqueeze(0).to(dev) for k, v in m1.items() if k != 'seg'}
+    fixed, moving = eng.prepare(fixed, moving)
+    eng.gmm_init(fixed, moving)
+    v = torch.zeros(1, 3, *dims, device=dev)  # MCMC_init: identity (trainer.py:596-598)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        eng.transition(fixed, moving, v)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.transition(fixed, moving, v)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(v).all()), 'chain diverged'
+
+    # per-stage HIP-event timings (outside the timed region), averaged over a few transitions
+    reps = max(3, min(10, args.steps))
+    acc = None
+    for _ in range(reps):
+        tm = eng.transition(fixed, moving, v, timed=True)
+        acc = tm if acc is None else {k: acc[k] + tm[k] for k in tm}
+    tm = {k: x / reps for k, x in acc.items()}
+    steps = cfg.no_steps
+    bwd_kernel_ms = tm['exp_bwd_kernel_ms'] / steps
+    fwd_kernel_ms = tm['exp_fwd_ms'] / steps
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * args.steps / elapsed
+        achieved = BWD_STEP_BYTES_PER_VOXEL * V / (bwd_kernel_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'SG-MCMC transitions/sec (full _SGLD_transition, 1 chain per GPU)', 'value': value,
+            'unit': 'transitions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{N}^3 synthetic pair, SVF_3D 12 steps, '
+                                   + ('GMM(K=4)/LCC(s=1) + virtual decimation' if args.loss == 'gmm' else 'SSD')
+                                   + ', RegLoss_L2 w=1.4, Sobolev s=3, uniform noise 0.1, SGLD lr 0.4, Philox noise',
+                       'volume': [N, N, N], 'chains_per_gpu': 1, 'parallelism': f'{world} independent chain(s)'},
+            'roofline': {'bound': 'hbm', 'kernel': 'exp_step_bwd_kernel (adjoint of one squaring step)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'algorithmic_bytes_per_launch': BWD_STEP_BYTES_PER_VOXEL * V,
+                         'avg_launch_ms': bwd_kernel_ms},
+            'transition_roofline': {'algorithmic_bytes': BYTES_PER_VOXEL[args.loss] * V,
+                                    'achieved_GBps': BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9,
+                                    'frac_of_8TBps': BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            'exp_step_fwd': {'avg_launch_ms': fwd_kernel_ms,
+                             'achieved_GBps': FWD_STEP_BYTES_PER_VOXEL * V / (fwd_kernel_ms * 1e-3) / 1e9},
+            'stage_ms': tm, 'workspace_GB': eng.workspace_bytes / 1e9,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            n_small = min(args.cpu_size, N)
+            dt, cores = cpu_baseline(n_small, args.cpu_reps, args.loss)
+            scale = (N / n_small) ** 3
+            out['cpu_baseline'] = {'value': 1.0 / (dt * scale), 'unit': 'transitions/s', 'cores': cores, 'kind': 'port',
+                                   'sample': f'{args.cpu_reps} transitions of the torch-CPU oracle at {n_small}^3 '
+                                             f'({dt:.2f} s each, {cores} threads), scaled by voxel count x{scale:.0f} to {N}^3'}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -179,7 +179,7 @@ typedef struct irs_io {
     float* residuals;        /* (C,1,D,H,W) dense z */
     float* displacement;     /* (C,3,D,H,W) voxels */
     float* transformation;   /* (C,3,D,H,W) [-1,1] */
-    float* grad_v;           /* (C,3,Dv,Hv,Wv) dL/dv before the sigma^2 / lr scaling (debug / parity) */
+    float* grad_v;           /* (C,3,Dv,Hv,Wv) v.grad of the reference: sigma^2 * dL/dv_s (debug / parity) */
 } irs_io;
 
 typedef struct irs_ctx irs_ctx;
@@ -205,9 +205,18 @@ int irs_gmm_init(irs_ctx* ctx, const irs_io* io, const float* v_sample, int warm
 /* one SG-MCMC transition; asynchronous, graph-capturable (no allocation, no host sync) */
 int irs_transition(irs_ctx* ctx, const irs_io* io, void* stream);
 
-/* timing hook for bench.py: average duration in ms of the dominant kernel family (scaling-and-squaring
- * forward+backward) measured with hipEvents on `stream` over the LAST call of irs_transition_timed. blocking. */
-int irs_transition_timed(irs_ctx* ctx, const irs_io* io, void* stream, float* ms_total, float* ms_exp);
+/* timing hook for bench.py: the same transition with hipEvents recorded on `stream` around the stages; blocking.
+ * All times in milliseconds for THIS call. */
+typedef struct irs_timings {
+    float total_ms;            /* whole transition */
+    float exp_fwd_ms;          /* the no_steps scaling-and-squaring forward launches */
+    float exp_bwd_kernel_ms;   /* sum over the no_steps adjoint-step KERNEL launches only (events around each launch) */
+    float exp_bwd_total_ms;    /* adjoint loop including the gradient-buffer memsets */
+    float smooth_ms;           /* perturbation + Sobolev smoothing (+ FFD up-sampling) */
+    float data_ms;             /* warp, LCC map, statistics, GMM step, data term + adjoints, warp backward */
+    float update_ms;           /* gradient assembly + SGLD update + bookkeeping */
+} irs_timings;
+int irs_transition_timed(irs_ctx* ctx, const irs_io* io, void* stream, irs_timings* out);
 
 const char* irs_last_error(void);
 const char* irs_version(void);

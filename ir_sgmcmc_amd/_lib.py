@@ -63,6 +63,11 @@ class IrsIO(C.Structure):
     ]
 
 
+class IrsTimings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ('total_ms', 'exp_fwd_ms', 'exp_bwd_kernel_ms', 'exp_bwd_total_ms', 'smooth_ms',
+                                         'data_ms', 'update_ms')]
+
+
 _P, _I, _F, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must match include/irsgmcmc.h exactly
@@ -94,7 +99,7 @@ SIGNATURES = {
     'irs_get_scalars': [_P, C.POINTER(IrsScalars), _P],
     'irs_gmm_init': [_P, C.POINTER(IrsIO), _P, _I, _P],
     'irs_transition': [_P, C.POINTER(IrsIO), _P],
-    'irs_transition_timed': [_P, C.POINTER(IrsIO), _P, C.POINTER(C.c_float), C.POINTER(C.c_float)],
+    'irs_transition_timed': [_P, C.POINTER(IrsIO), _P, C.POINTER(IrsTimings)],
     'irs_last_error': [],
     'irs_version': [],
 }

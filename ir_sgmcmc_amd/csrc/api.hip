@@ -78,7 +78,8 @@ struct irs_ctx {
     int fhat_chains;
     bool fixed_set;
     int nll_blocks;
-    hipEvent_t ev[6];
+    hipEvent_t ev[8];
+    hipEvent_t ev_bwd[64];
 };
 
 extern "C" {
@@ -470,7 +471,8 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
         launch_refresh_derived(c->state, c->dcfg, nullptr);
         e = hipDeviceSynchronize();
     }
-    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 64 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev_bwd[i]);
     if (e != hipSuccess) {
         (void)hipFree(c->slab);
         delete c;
@@ -483,8 +485,10 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
 void irs_destroy(irs_ctx* c) {
     if (!c) return;
     (void)hipDeviceSynchronize();
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 8; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 64; ++i)
+        if (c->ev_bwd[i]) (void)hipEventDestroy(c->ev_bwd[i]);
     if (c->lin.dev) (void)hipFree(c->lin.dev);
     if (c->slab) (void)hipFree(c->slab);
     delete c;
@@ -660,8 +664,10 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
         for (int k = cfg.no_steps - 1; k >= 0; --k) {
             float* out = bufs[cur];
             HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
+            if (timed) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k], st));
             launch_exp_step_bwd(G, k == 0 ? dense : c->steps + (int64_t)(k - 1) * field, out, k == 0, cfg.no_steps, C, vol,
                                 lin, st);
+            if (timed) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k + 1], st));
             G = out;
             cur ^= 1;
         }
@@ -687,15 +693,23 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
 
 int irs_transition(irs_ctx* c, const irs_io* io, void* stream) { return transition_impl(c, io, (hipStream_t)stream, 0); }
 
-int irs_transition_timed(irs_ctx* c, const irs_io* io, void* stream, float* ms_total, float* ms_exp) {
-    if (!ms_total || !ms_exp) return fail("irs_transition_timed: null output");
+int irs_transition_timed(irs_ctx* c, const irs_io* io, void* stream, irs_timings* out) {
+    if (!out) return fail("irs_transition_timed: null output");
+    if (c && c->cfg.no_steps > 32) return fail("irs_transition_timed: at most 32 steps");
     if (transition_impl(c, io, (hipStream_t)stream, 1)) return 1;
     HIP_TRY(hipEventSynchronize(c->ev[5]));
-    float fwd = 0.0f, bwd = 0.0f;
-    HIP_TRY(hipEventElapsedTime(ms_total, c->ev[0], c->ev[5]));
-    HIP_TRY(hipEventElapsedTime(&fwd, c->ev[1], c->ev[2]));
-    HIP_TRY(hipEventElapsedTime(&bwd, c->ev[3], c->ev[4]));
-    *ms_exp = fwd + bwd;
+    memset(out, 0, sizeof(*out));
+    HIP_TRY(hipEventElapsedTime(&out->total_ms, c->ev[0], c->ev[5]));
+    HIP_TRY(hipEventElapsedTime(&out->smooth_ms, c->ev[0], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&out->exp_fwd_ms, c->ev[1], c->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&out->data_ms, c->ev[2], c->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&out->exp_bwd_total_ms, c->ev[3], c->ev[4]));
+    HIP_TRY(hipEventElapsedTime(&out->update_ms, c->ev[4], c->ev[5]));
+    for (int k = 0; k < c->cfg.no_steps; ++k) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_bwd[2 * k], c->ev_bwd[2 * k + 1]));
+        out->exp_bwd_kernel_ms += ms;
+    }
     return 0;
 }
 

@@ -489,9 +489,10 @@ __global__ __launch_bounds__(kBlock) void sgld_update_kernel(float* __restrict__
         const float* f = v_s + cb + c * vol.V;
         const float lap = dtd_axis(f, p, x, vol.W, 1) + dtd_axis(f, p, y, vol.H, vol.W) + dtd_axis(f, p, z, vol.D, plane);
         const float gr = g[i] * sc[c] + coef2 * lap;
-        if (grad_out) grad_out[i] = gr;
         const float sg = sigma ? sigma[i] : 1.0f;
-        v[i] = v[i] - lr * (sg * sg * gr);
+        const float gs = sg * sg * gr;  // SGLD.backward: sigma^2 * grad (utils/functions.py:83-84) == v.grad in the reference
+        if (grad_out) grad_out[i] = gs;
+        v[i] = v[i] - lr * gs;
     }
 }
 

@@ -179,8 +179,8 @@ class TransitionEngine:
         """One `_SGLD_transition`; updates `v` in place.  outputs: dict of preallocated tensors to fill."""
         io = self._io(fixed, moving, v, sigma, eps, unif, outputs)
         if timed:
-            tot, ex = C.c_float(), C.c_float()
-            L.check(self.lib.irs_transition_timed(self._ctx, C.byref(io), L.stream_ptr(), C.byref(tot), C.byref(ex)))
-            return tot.value, ex.value
+            tm = L.IrsTimings()
+            L.check(self.lib.irs_transition_timed(self._ctx, C.byref(io), L.stream_ptr(), C.byref(tm)))
+            return {n: getattr(tm, n) for n, _ in tm._fields_}
         L.check(self.lib.irs_transition(self._ctx, C.byref(io), L.stream_ptr()))
         return None

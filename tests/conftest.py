@@ -27,13 +27,11 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-# ---- parity report: every GPU parity test records its worst deviation next to the tolerance it was held to;
-# written to gpurun_out/parity_report.json at session end (copied into profiles/ for the record)
-PARITY = {}
-
-
+# ---- parity report: every GPU parity test records its worst deviation next to the tolerance it was held to
+# (tests/_report.py); written to gpurun_out/parity_report.json at session end and copied into profiles/
 def pytest_sessionfinish(session, exitstatus):
     import json
+    from tests._report import PARITY
     if not PARITY:
         return
     out = os.path.join(ROOT, 'gpurun_out')
