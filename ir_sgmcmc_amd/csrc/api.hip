@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -56,6 +57,22 @@ SplineTaps make_spline(int cps) {
     return t;
 }
 
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// LDS halo of the staged displacement box per squaring step: |d_k| ~ |d_n| / 2^(n-k), so all but the last few steps
+// move less than a voxel and a 1-voxel halo keeps every tap in LDS; the last steps get 2.  Taps that still fall
+// outside are fetched from global memory, so this is a speed knob only.  IRS_EXP_HALO=1|2 overrides it.
+int exp_halo(int k, int no_steps) {
+    const int forced = env_int("IRS_EXP_HALO", 0);
+    if (forced) return forced;
+    return k >= no_steps - 3 ? 2 : 1;
+}
+
+bool use_lds_exp() { return env_int("IRS_EXP_LDS", 1) != 0; }
+
 int control_points(int n, int cps) { return (int)ceil((double)(n - 1) / (double)cps) + 1 + 2; }  // utils/util.py:61-69
 
 }  // namespace
@@ -74,6 +91,7 @@ struct irs_ctx {
     // workspace views
     float *steps, *tmpA, *tmpB, *vs, *gA, *gB, *warped, *z, *sigM, *fhat, *gM, *dense;
     double *stat_partials, *energy_partials, *nll_partials;
+    unsigned* dmax;  // [no_steps][C][4] max |d_k| in voxels per axis (float bits), by-product of the forward steps
     DevState* state;
     int fhat_chains;
     bool fixed_set;
@@ -132,9 +150,12 @@ int irs_svf_exp_fwd(const float* v, float* steps, float* transformation, float* 
     Lin lin;
     if (cached_lin(D, H, W, st, &lin)) return fail("irs_svf_exp_fwd: identity grid allocation failed");
     const int64_t field = (int64_t)C * 3 * vol.V;
-    for (int k = 0; k < no_steps; ++k)
-        launch_exp_step_fwd(k == 0 ? v : steps + (int64_t)(k - 1) * field, steps + (int64_t)k * field, k == 0, no_steps, C,
-                            vol, lin, st);
+    for (int k = 0; k < no_steps; ++k) {
+        const float* in = k == 0 ? v : steps + (int64_t)(k - 1) * field;
+        if (use_lds_exp()) launch_exp_step_fwd_lds(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, nullptr,
+                                                   exp_halo(k, no_steps), st);
+        else launch_exp_step_fwd(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, st);
+    }
     if (transformation || displacement)
         launch_svf_outputs(steps + (int64_t)(no_steps - 1) * field, transformation, displacement, C, vol, lin, st);
     LAUNCH_CHECK();
@@ -147,10 +168,22 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
     const float* G = g_last;
     float* bufs[2] = {gA, gB};
     int cur = 0;
+    static unsigned* dmax = nullptr;  // process-wide scratch for the stateless operator: [32 steps][8 chains][4]
+    if (!dmax) HIP_TRY(hipMalloc((void**)&dmax, sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32));
+    if (C > IRS_MAX_CHAINS || no_steps > 32) return fail("irs_svf_exp_bwd: at most %d chains / 32 steps", IRS_MAX_CHAINS);
+    const bool lds = use_lds_exp();
+    if (lds) HIP_TRY(hipMemsetAsync(dmax, 0, sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32, st));
     for (int k = no_steps - 1; k >= 0; --k) {
         float* out = bufs[cur];
-        HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
-        launch_exp_step_bwd(G, k == 0 ? v : steps + (int64_t)(k - 1) * field, out, k == 0, no_steps, C, vol, lin, st);
+        const float* dk = k == 0 ? v : steps + (int64_t)(k - 1) * field;
+        if (lds) {
+            launch_field_absmax(dk, k == 0, no_steps, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, C, vol, st);
+            launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4,
+                                    exp_halo(k, no_steps), st);
+        } else {
+            HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
+            launch_exp_step_bwd(G, dk, out, k == 0, no_steps, C, vol, lin, st);
+        }
         G = out;
         cur ^= 1;
     }
@@ -429,6 +462,7 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
     const size_t o_stat = take(sizeof(double) * kMaxPartialBlocks * kStatVals);
     const size_t o_energy = take(sizeof(double) * kMaxPartialBlocks * IRS_MAX_CHAINS);
     const size_t o_nll = take(sizeof(double) * (size_t)c->nll_blocks * C);
+    const size_t o_dmax = take(sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32);
     const size_t o_state = take(sizeof(DevState));
     c->slab_bytes = off;
     if (hipMalloc((void**)&c->slab, off) != hipSuccess) {
@@ -450,6 +484,7 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
     c->stat_partials = (double*)(c->slab + o_stat);
     c->energy_partials = (double*)(c->slab + o_energy);
     c->nll_partials = (double*)(c->slab + o_nll);
+    c->dmax = (unsigned*)(c->slab + o_dmax);
     c->state = (DevState*)(c->slab + o_state);
 
     if (ensure_lin_tables(c->lin, D, H, W, nullptr)) {
@@ -578,9 +613,15 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     if (timed) HIP_TRY(hipEventRecord(c->ev[1], st));
     const int64_t field = (int64_t)c->C * 3 * c->vol.V;
     const Lin lin = c->lin.lin();
-    for (int k = 0; k < cfg.no_steps; ++k)
-        launch_exp_step_fwd(k == 0 ? dense : c->steps + (int64_t)(k - 1) * field, c->steps + (int64_t)k * field, k == 0,
-                            cfg.no_steps, C, c->vol, lin, st);
+    const bool lds = use_lds_exp();
+    if (lds) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * cfg.no_steps, st));
+    for (int k = 0; k < cfg.no_steps; ++k) {
+        const float* in = k == 0 ? dense : c->steps + (int64_t)(k - 1) * field;
+        float* out = c->steps + (int64_t)k * field;
+        if (lds) launch_exp_step_fwd_lds(in, out, k == 0, cfg.no_steps, C, c->vol, lin, c->dmax + (int64_t)k * c->C * 4,
+                                         exp_halo(k, cfg.no_steps), st);
+        else launch_exp_step_fwd(in, out, k == 0, cfg.no_steps, C, c->vol, lin, st);
+    }
     if (timed) HIP_TRY(hipEventRecord(c->ev[2], st));
     const float* d_last = c->steps + (int64_t)(cfg.no_steps - 1) * field;
     // 4. warp (+ jitter) and residual
@@ -663,10 +704,13 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
         int cur = 0;
         for (int k = cfg.no_steps - 1; k >= 0; --k) {
             float* out = bufs[cur];
-            HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
+            const float* dk = k == 0 ? dense : c->steps + (int64_t)(k - 1) * field;
+            const bool lds = use_lds_exp();
+            if (!lds) HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
             if (timed) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k], st));
-            launch_exp_step_bwd(G, k == 0 ? dense : c->steps + (int64_t)(k - 1) * field, out, k == 0, cfg.no_steps, C, vol,
-                                lin, st);
+            if (lds) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, c->dmax + (int64_t)k * C * 4,
+                                             exp_halo(k, cfg.no_steps), st);
+            else launch_exp_step_bwd(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, st);
             if (timed) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k + 1], st));
             G = out;
             cur ^= 1;

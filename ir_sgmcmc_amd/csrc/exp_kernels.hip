@@ -1,0 +1,391 @@
+// LDS-tiled scaling-and-squaring step and its adjoint for gfx950 (the dominant kernels: 720 of the 878 algorithmic
+// bytes per voxel of a transition).  Reference semantics: utils/transformation.py:70-73 and autograd through it.
+//
+// Forward  d_out = d + sample(d, id + d):  a 32x8x8 output tile per 512-thread workgroup; d (3 channels) over the tile
+//   plus a halo of HF voxels is staged in LDS with coalesced row loads, the 8 trilinear taps come from LDS whenever the
+//   sampling position stays inside the staged box and from global memory otherwise (any displacement is handled;
+//   only speed depends on the halo).  As a by-product the per-chain max |d| (voxels, per axis) is reduced with one
+//   atomicMax per wavefront -- the adjoint needs it to size its source region.
+//
+// Adjoint  g = G + (grid-gradient) + (trilinear scatter of G):  "owner computes".  Each workgroup owns the OUTPUT tile
+//   and keeps its three accumulator planes in LDS; it walks every source voxel that can reach the tile (tile +/-
+//   (ceil(max|d|) + 1), known from the forward pass), recomputes that voxel's trilinear weights and adds the corner
+//   contributions that land inside the tile with LDS atomics (ds_add_f32).  No global atomics, no zero-fill of the
+//   output, plain coalesced stores; results are deterministic up to the order of LDS adds.
+#include "kernels.h"
+
+namespace irs {
+
+constexpr int ETX = 32, ETY = 8, ETZ = 8, ETN = ETX * ETY * ETZ;
+constexpr int kExpBlock = 512;
+
+struct Scale3L {
+    float nm1[3];
+    float inv_pow;
+};
+
+template <bool PRESCALE>
+__device__ __forceinline__ float ldp(const float* __restrict__ p, int64_t i, float nm1, float inv_pow) {
+    const float v = p[i];
+    return PRESCALE ? prescale(v, nm1, inv_pow) : v;
+}
+
+__device__ __forceinline__ void atomic_max_nonneg(unsigned* addr, float v) {
+    // non-negative floats order like their bit patterns
+    atomicMax(addr, __float_as_uint(v));
+}
+
+template <int H>
+struct ExpBox {
+    static constexpr int SX = ETX + 2 * H, SY = ETY + 2 * H, SZ = ETZ + 2 * H, SN = SX * SY * SZ;
+};
+
+// stage d (3 channels, optionally prescaled) over tile +/- H into LDS; coordinates are clamped to the volume
+template <bool PRESCALE, int H>
+__device__ __forceinline__ void stage_field(const float* __restrict__ c0, float* __restrict__ lds, int ox, int oy, int oz,
+                                            const Vol vol, const Scale3L sc) {
+    using B = ExpBox<H>;
+    for (int i = threadIdx.x; i < B::SN; i += kExpBlock) {
+        const int lx = i % B::SX, ly = (i / B::SX) % B::SY, lz = i / (B::SX * B::SY);
+        const int gx = min(max(ox - H + lx, 0), vol.W - 1), gy = min(max(oy - H + ly, 0), vol.H - 1),
+                  gz = min(max(oz - H + lz, 0), vol.D - 1);
+        const int64_t g = ((int64_t)gz * vol.H + gy) * vol.W + gx;
+        lds[i] = ldp<PRESCALE>(c0, g, sc.nm1[0], sc.inv_pow);
+        lds[B::SN + i] = ldp<PRESCALE>(c0 + vol.V, g, sc.nm1[1], sc.inv_pow);
+        lds[2 * B::SN + i] = ldp<PRESCALE>(c0 + 2 * vol.V, g, sc.nm1[2], sc.inv_pow);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward step
+// ------------------------------------------------------------------------------------------------
+template <bool PRESCALE, int H>
+__global__ __launch_bounds__(kExpBlock) void exp_fwd_lds_kernel(const float* __restrict__ din, float* __restrict__ dout,
+                                                                Vol vol, Lin lin, Scale3L sc, unsigned* __restrict__ dmax,
+                                                                int tiles_z) {
+    using B = ExpBox<H>;
+    __shared__ float lds[3 * B::SN];
+    const int chain = blockIdx.z / tiles_z;
+    const int ox = blockIdx.x * ETX, oy = blockIdx.y * ETY, oz = (blockIdx.z % tiles_z) * ETZ;
+    const int64_t V = vol.V;
+    const float* c0 = din + (int64_t)chain * 3 * V;
+    const float* c1 = c0 + V;
+    const float* c2 = c1 + V;
+    float* o = dout + (int64_t)chain * 3 * V;
+
+    stage_field<PRESCALE, H>(c0, lds, ox, oy, oz, vol, sc);
+    __syncthreads();
+
+    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
+    for (int i = threadIdx.x; i < ETN; i += kExpBlock) {
+        const int lx = i % ETX, ly = (i / ETX) % ETY, lz = i / (ETX * ETY);
+        const int x = ox + lx, y = oy + ly, z = oz + lz;
+        if (x >= vol.W || y >= vol.H || z >= vol.D) continue;
+        const int ctr = ((lz + H) * B::SY + (ly + H)) * B::SX + (lx + H);
+        const float d0 = lds[ctr], d1 = lds[B::SN + ctr], d2 = lds[2 * B::SN + ctr];
+        m0 = fmaxf(m0, fabsf(d0));
+        m1 = fmaxf(m1, fabsf(d1));
+        m2 = fmaxf(m2, fabsf(d2));
+        const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
+        const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
+        const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
+        // local coordinates of the corner taps inside the staged box
+        const int bx0 = tx.i0 - (ox - H), bx1 = tx.i1 - (ox - H);
+        const int by0 = ty.i0 - (oy - H), by1 = ty.i1 - (oy - H);
+        const int bz0 = tz.i0 - (oz - H), bz1 = tz.i1 - (oz - H);
+        const bool in_lds = bx0 >= 0 && bx1 < B::SX && by0 >= 0 && by1 < B::SY && bz0 >= 0 && bz1 < B::SZ;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+        if (in_lds) {
+#pragma unroll
+            for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+                for (int cy = 0; cy < 2; ++cy) {
+                    const int row = ((cz ? bz1 : bz0) * B::SY + (cy ? by1 : by0)) * B::SX;
+#pragma unroll
+                    for (int cx = 0; cx < 2; ++cx) {
+                        const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
+                        const int idx = row + (cx ? bx1 : bx0);
+                        a0 = __fadd_rn(a0, __fmul_rn(lds[idx], w));
+                        a1 = __fadd_rn(a1, __fmul_rn(lds[B::SN + idx], w));
+                        a2 = __fadd_rn(a2, __fmul_rn(lds[2 * B::SN + idx], w));
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+                for (int cy = 0; cy < 2; ++cy) {
+                    const int64_t rowoff = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W;
+#pragma unroll
+                    for (int cx = 0; cx < 2; ++cx) {
+                        const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
+                        const int64_t idx = rowoff + (cx ? tx.i1 : tx.i0);
+                        a0 = __fadd_rn(a0, __fmul_rn(ldp<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow), w));
+                        a1 = __fadd_rn(a1, __fmul_rn(ldp<PRESCALE>(c1, idx, sc.nm1[1], sc.inv_pow), w));
+                        a2 = __fadd_rn(a2, __fmul_rn(ldp<PRESCALE>(c2, idx, sc.nm1[2], sc.inv_pow), w));
+                    }
+                }
+        }
+        const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
+        o[g] = __fadd_rn(d0, a0);
+        o[g + V] = __fadd_rn(d1, a1);
+        o[g + 2 * V] = __fadd_rn(d2, a2);
+    }
+    if (dmax) {
+        // max |d_k| in voxels per axis (normalised -> voxels: * (n - 1) / 2).  Reduced over the workgroup first, and the
+        // atomic is skipped when the published bound already covers it (the bound only grows, so a stale read is safe):
+        // thousands of same-address atomics per launch would serialise at the memory side.
+        __shared__ float red[3 * (kExpBlock / kWave)];
+        m0 *= 0.5f * sc.nm1[0];
+        m1 *= 0.5f * sc.nm1[1];
+        m2 *= 0.5f * sc.nm1[2];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            m0 = fmaxf(m0, __shfl_down(m0, off, kWave));
+            m1 = fmaxf(m1, __shfl_down(m1, off, kWave));
+            m2 = fmaxf(m2, __shfl_down(m2, off, kWave));
+        }
+        const int wid = threadIdx.x / kWave;
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            red[wid] = m0;
+            red[(kExpBlock / kWave) + wid] = m1;
+            red[2 * (kExpBlock / kWave) + wid] = m2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float m = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kExpBlock / kWave; ++w) m = fmaxf(m, red[threadIdx.x * (kExpBlock / kWave) + w]);
+            unsigned* slot = dmax + chain * 4 + threadIdx.x;
+            if (__float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_nonneg(slot, m);
+        }
+    }
+}
+
+static Scale3L make_scale_l(Vol vol, int no_steps) {
+    Scale3L s;
+    s.nm1[0] = (float)(vol.W - 1);
+    s.nm1[1] = (float)(vol.H - 1);
+    s.nm1[2] = (float)(vol.D - 1);
+    s.inv_pow = 1.0f / (float)(1 << no_steps);
+    return s;
+}
+
+static dim3 exp_grid(Vol vol, int C, int* tiles_z) {
+    *tiles_z = (vol.D + ETZ - 1) / ETZ;
+    return dim3((vol.W + ETX - 1) / ETX, (vol.H + ETY - 1) / ETY, (unsigned)(*tiles_z * C));
+}
+
+void launch_exp_step_fwd_lds(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
+                             unsigned* dmax, int halo, hipStream_t st) {
+    int tz;
+    const dim3 grid = exp_grid(vol, C, &tz);
+    const Scale3L sc = make_scale_l(vol, no_steps);
+#define IRS_FWD(P, HH) hipLaunchKernelGGL((exp_fwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, din, dout, vol, lin, sc, dmax, tz)
+    if (prescale_in) {
+        if (halo <= 1) IRS_FWD(true, 1); else IRS_FWD(true, 2);
+    } else {
+        if (halo <= 1) IRS_FWD(false, 1); else IRS_FWD(false, 2);
+    }
+#undef IRS_FWD
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint step (owner computes)
+// ------------------------------------------------------------------------------------------------
+// one source voxel: scatter its corner contributions that land in the owned tile; for the tile's own voxels also the
+// identity path and the grid-gradient.  d0..d2 is the source's displacement (already read).
+template <bool PRESCALE, int H>
+__device__ __forceinline__ void adjoint_source(const int x, const int y, const int z, const float d0, const float d1,
+                                               const float d2, const int ox, const int oy, const int oz,
+                                               const float* __restrict__ Gc, const float* __restrict__ c0,
+                                               const float* __restrict__ lds, float* __restrict__ acc, const Vol vol,
+                                               const Lin lin, const Scale3L sc) {
+    using B = ExpBox<H>;
+    const int64_t V = vol.V;
+    const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
+    const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
+    const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
+    // tile-local corner coordinates; a corner contributes iff it lies inside the owned tile
+    const int ax0 = tx.i0 - ox, ax1 = tx.i1 - ox, ay0 = ty.i0 - oy, ay1 = ty.i1 - oy, az0 = tz.i0 - oz, az1 = tz.i1 - oz;
+    const bool self_in = (unsigned)(x - ox) < (unsigned)ETX && (unsigned)(y - oy) < (unsigned)ETY && (unsigned)(z - oz) < (unsigned)ETZ;
+    const bool any = ax1 >= 0 && ax0 < ETX && ay1 >= 0 && ay0 < ETY && az1 >= 0 && az0 < ETZ;
+    if (!any && !self_in) return;
+    const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
+    const float G0 = Gc[g], G1 = Gc[V + g], G2 = Gc[2 * V + g];
+    if (any) {
+        // per-axis weights with out-of-tile corners zeroed: the scatter becomes 8 unconditional-weight products
+        const float wx0 = (unsigned)ax0 < (unsigned)ETX ? tx.w0 : 0.0f, wx1 = (unsigned)ax1 < (unsigned)ETX ? tx.w1 : 0.0f;
+        const float wy0 = (unsigned)ay0 < (unsigned)ETY ? ty.w0 : 0.0f, wy1 = (unsigned)ay1 < (unsigned)ETY ? ty.w1 : 0.0f;
+        const float wz0 = (unsigned)az0 < (unsigned)ETZ ? tz.w0 : 0.0f, wz1 = (unsigned)az1 < (unsigned)ETZ ? tz.w1 : 0.0f;
+        const int cxa = min(max(ax0, 0), ETX - 1), cxb = min(max(ax1, 0), ETX - 1);
+        const int cya = min(max(ay0, 0), ETY - 1) * ETX, cyb = min(max(ay1, 0), ETY - 1) * ETX;
+        const int cza = min(max(az0, 0), ETZ - 1) * (ETX * ETY), czb = min(max(az1, 0), ETZ - 1) * (ETX * ETY);
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy) {
+                const float wyz = (cy ? wy1 : wy0) * (cz ? wz1 : wz0);
+                if (wyz == 0.0f) continue;
+                const int row = (cz ? czb : cza) + (cy ? cyb : cya);
+#pragma unroll
+                for (int cx = 0; cx < 2; ++cx) {
+                    const float w = (cx ? wx1 : wx0) * wyz;
+                    if (w == 0.0f) continue;
+                    const int t = row + (cx ? cxb : cxa);
+                    atomicAdd(&acc[t], w * G0);
+                    atomicAdd(&acc[ETN + t], w * G1);
+                    atomicAdd(&acc[2 * ETN + t], w * G2);
+                }
+            }
+    }
+    if (self_in) {
+        // identity path + grid-gradient; the tap values come from the staged box when the position stays inside it
+        const int bx0 = tx.i0 - (ox - H), bx1 = tx.i1 - (ox - H);
+        const int by0 = ty.i0 - (oy - H), by1 = ty.i1 - (oy - H);
+        const int bz0 = tz.i0 - (oz - H), bz1 = tz.i1 - (oz - H);
+        const bool in_lds = bx0 >= 0 && bx1 < B::SX && by0 >= 0 && by1 < B::SY && bz0 >= 0 && bz1 < B::SZ;
+        float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                for (int cx = 0; cx < 2; ++cx) {
+                    float v0, v1, v2;
+                    if (in_lds) {
+                        const int idx = ((cz ? bz1 : bz0) * B::SY + (cy ? by1 : by0)) * B::SX + (cx ? bx1 : bx0);
+                        v0 = lds[idx];
+                        v1 = lds[B::SN + idx];
+                        v2 = lds[2 * B::SN + idx];
+                    } else {
+                        const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
+                        v0 = ldp<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow);
+                        v1 = ldp<PRESCALE>(c0 + V, idx, sc.nm1[1], sc.inv_pow);
+                        v2 = ldp<PRESCALE>(c0 + 2 * V, idx, sc.nm1[2], sc.inv_pow);
+                    }
+                    const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
+                    const float dot = v0 * G0 + v1 * G1 + v2 * G2;
+                    gix += (cx ? dot : -dot) * (wy * wz);
+                    giy += (cy ? dot : -dot) * (wx * wz);
+                    giz += (cz ? dot : -dot) * (wx * wy);
+                }
+        const int t = ((z - oz) * ETY + (y - oy)) * ETX + (x - ox);
+        atomicAdd(&acc[t], G0 + tx.gmul * gix);
+        atomicAdd(&acc[ETN + t], G1 + ty.gmul * giy);
+        atomicAdd(&acc[2 * ETN + t], G2 + tz.gmul * giz);
+    }
+}
+
+template <bool PRESCALE, int H>
+__global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __restrict__ G, const float* __restrict__ dk,
+                                                                float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
+                                                                const unsigned* __restrict__ dmax, int tiles_z) {
+    using B = ExpBox<H>;
+    __shared__ float lds[3 * B::SN];
+    __shared__ float acc[3 * ETN];
+    const int chain = blockIdx.z / tiles_z;
+    const int ox = blockIdx.x * ETX, oy = blockIdx.y * ETY, oz = (blockIdx.z % tiles_z) * ETZ;
+    const int64_t V = vol.V;
+    const int64_t cb = (int64_t)chain * 3 * V;
+    const float* c0 = dk + cb;
+    const float* Gc = G + cb;
+
+    stage_field<PRESCALE, H>(c0, lds, ox, oy, oz, vol, sc);
+    for (int i = threadIdx.x; i < 3 * ETN; i += kExpBlock) acc[i] = 0.0f;
+
+    // source halo: a voxel at distance h from the tile can reach it iff h <= floor(max|d|) + 1 (corner = floor(x+d) + {0,1})
+    const int hx = (int)floorf(__uint_as_float(dmax[chain * 4 + 0])) + 1;
+    const int hy = (int)floorf(__uint_as_float(dmax[chain * 4 + 1])) + 1;
+    const int hz = (int)floorf(__uint_as_float(dmax[chain * 4 + 2])) + 1;
+    __syncthreads();
+
+    if (hx <= H && hy <= H && hz <= H) {
+        // fast path: every source sits in the staged box (compile-time extents, displacement straight from LDS)
+        for (int i = threadIdx.x; i < B::SN; i += kExpBlock) {
+            const int lx = i % B::SX, ly = (i / B::SX) % B::SY, lz = i / (B::SX * B::SY);
+            const int x = ox - H + lx, y = oy - H + ly, z = oz - H + lz;
+            if ((unsigned)x >= (unsigned)vol.W || (unsigned)y >= (unsigned)vol.H || (unsigned)z >= (unsigned)vol.D) continue;
+            adjoint_source<PRESCALE, H>(x, y, z, lds[i], lds[B::SN + i], lds[2 * B::SN + i], ox, oy, oz, Gc, c0, lds, acc, vol,
+                                        lin, sc);
+        }
+    } else {
+        // general path: run-time source box, displacements from global memory outside the staged box
+        const int sx0 = max(ox - hx, 0), sx1 = min(ox + ETX - 1 + hx, vol.W - 1);
+        const int sy0 = max(oy - hy, 0), sy1 = min(oy + ETY - 1 + hy, vol.H - 1);
+        const int sz0 = max(oz - hz, 0), sz1 = min(oz + ETZ - 1 + hz, vol.D - 1);
+        const int ex = sx1 - sx0 + 1, ey = sy1 - sy0 + 1, ez = sz1 - sz0 + 1;
+        const int nS = ex * ey * ez;
+        for (int i = threadIdx.x; i < nS; i += kExpBlock) {
+            const int x = sx0 + i % ex, y = sy0 + (i / ex) % ey, z = sz0 + i / (ex * ey);
+            const int bx = x - (ox - H), by = y - (oy - H), bz = z - (oz - H);
+            float d0, d1, d2;
+            if ((unsigned)bx < (unsigned)B::SX && (unsigned)by < (unsigned)B::SY && (unsigned)bz < (unsigned)B::SZ) {
+                const int ctr = (bz * B::SY + by) * B::SX + bx;
+                d0 = lds[ctr];
+                d1 = lds[B::SN + ctr];
+                d2 = lds[2 * B::SN + ctr];
+            } else {
+                const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
+                d0 = ldp<PRESCALE>(c0, g, sc.nm1[0], sc.inv_pow);
+                d1 = ldp<PRESCALE>(c0 + V, g, sc.nm1[1], sc.inv_pow);
+                d2 = ldp<PRESCALE>(c0 + 2 * V, g, sc.nm1[2], sc.inv_pow);
+            }
+            adjoint_source<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, Gc, c0, lds, acc, vol, lin, sc);
+        }
+    }
+    __syncthreads();
+    float* o = gout + cb;
+    for (int i = threadIdx.x; i < ETN; i += kExpBlock) {
+        const int lx = i % ETX, ly = (i / ETX) % ETY, lz = i / (ETX * ETY);
+        const int x = ox + lx, y = oy + ly, z = oz + lz;
+        if (x >= vol.W || y >= vol.H || z >= vol.D) continue;
+        const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
+        o[g] = acc[i];
+        o[g + V] = acc[ETN + i];
+        o[g + 2 * V] = acc[2 * ETN + i];
+    }
+}
+
+void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
+                             Lin lin, const unsigned* dmax, int halo, hipStream_t st) {
+    int tz;
+    const dim3 grid = exp_grid(vol, C, &tz);
+    const Scale3L sc = make_scale_l(vol, no_steps);
+#define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz)
+    if (prescale_in) {
+        if (halo <= 1) IRS_BWD(true, 1); else IRS_BWD(true, 2);
+    } else {
+        if (halo <= 1) IRS_BWD(false, 1); else IRS_BWD(false, 2);
+    }
+#undef IRS_BWD
+}
+
+// per-chain max |d| (voxels, per axis) of a field -- used by the stateless adjoint, which has no forward by-product
+template <bool PRESCALE>
+__global__ __launch_bounds__(kBlock) void field_absmax_kernel(const float* __restrict__ d, unsigned* __restrict__ dmax,
+                                                              Vol vol, Scale3L sc) {
+    const int chain = blockIdx.y;
+    const float* c0 = d + (int64_t)chain * 3 * vol.V;
+    float m[3] = {0.0f, 0.0f, 0.0f};
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < vol.V; v += (int64_t)gridDim.x * kBlock)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m[c] = fmaxf(m[c], fabsf(ldp<PRESCALE>(c0 + c * vol.V, v, sc.nm1[c], sc.inv_pow)));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        m[c] *= 0.5f * sc.nm1[c];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) m[c] = fmaxf(m[c], __shfl_down(m[c], off, kWave));
+        if ((threadIdx.x & (kWave - 1)) == 0) atomic_max_nonneg(dmax + chain * 4 + c, m[c]);
+    }
+}
+
+void launch_field_absmax(const float* d, bool prescale_in, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st) {
+    const int64_t b = (vol.V + kBlock - 1) / kBlock;
+    dim3 grid((unsigned)(b < 1024 ? b : 1024), C);
+    const Scale3L sc = make_scale_l(vol, no_steps);
+    if (prescale_in) hipLaunchKernelGGL(field_absmax_kernel<true>, grid, dim3(kBlock), 0, st, d, dmax, vol, sc);
+    else hipLaunchKernelGGL(field_absmax_kernel<false>, grid, dim3(kBlock), 0, st, d, dmax, vol, sc);
+}
+
+}  // namespace irs

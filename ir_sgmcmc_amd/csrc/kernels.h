@@ -50,6 +50,13 @@ void launch_ffd_axis(const float* in, float* out, const SplineTaps& taps, bool a
                      int n_out, int64_t inner, hipStream_t st);
 void launch_scale_channels(const float* in, float* out, float s0, float s1, float s2, int C, int64_t V, hipStream_t st);
 
+// ---- exp_kernels.hip (LDS-tiled squaring step + owner-computes adjoint)
+void launch_exp_step_fwd_lds(const float* din, float* dout, bool prescale, int no_steps, int C, Vol vol, Lin lin,
+                             unsigned* dmax, int halo, hipStream_t st);
+void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
+                             Lin lin, const unsigned* dmax, int halo, hipStream_t st);
+void launch_field_absmax(const float* d, bool prescale, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st);
+
 // ---- data_kernels.hip
 void launch_lcc_fwd(const float* fhat, int64_t fhat_stride, const float* im, float* z, float* sigma_out, int s, int C,
                     Vol vol, hipStream_t st);

@@ -1,0 +1,42 @@
+"""Data loaders with the reference's contract (data_loader/data_loaders.py, data_loader/datasets.py:107-145):
+iterating yields ONE (fixed, moving, var_params_q_v) triple; fixed/moving are dicts with 'im' float32, 'mask' bool,
+'seg' int16 of shape (1, 1, D, H, W); var_params_q_v has 'mu', 'log_var', 'u' of shape (1, 3, *dims_v)."""
+from ..ops import control_grid_size
+from .synthetic import init_var_params, synthetic_pair
+
+
+class SyntheticDataLoader:
+    """deterministic Gaussian-blob pair; the reference ships no image data"""
+
+    def __init__(self, dims, sigma_v_init=0.5, u_v_init=0.1, cps=None, save_dirs=None, seed=0, **_unused):
+        self.dims = tuple(dims)
+        self.cps = tuple(cps) if cps else None
+        self.save_dirs = save_dirs
+        self.sigma_v_init, self.u_v_init, self.seed = sigma_v_init, u_v_init, seed
+        self.im_spacing = None
+
+    @property
+    def dims_v(self):
+        return control_grid_size(self.dims, self.cps) if self.cps else self.dims
+
+    def __len__(self):
+        return 1
+
+    def __iter__(self):
+        fixed, moving = synthetic_pair(self.dims, seed=self.seed)
+        fixed = {k: v.unsqueeze(0) for k, v in fixed.items()}
+        moving = {k: v.unsqueeze(0) for k, v in moving.items()}
+        vp = {k: v.unsqueeze(0) for k, v in init_var_params(self.dims_v, self.sigma_v_init, self.u_v_init).items()}
+        yield fixed, moving, vp
+
+
+class BiobankDataLoader(SyntheticDataLoader):
+    """The reference's loader reads .nii.gz with SimpleITK from `data_dir` (data_loader/datasets.py:70-105).  Image
+    file i/o is a "next" row of the scope table and SimpleITK is not available here, so a
+    config that names BiobankDataLoader resolves to the synthetic pair of the same `dims` with a warning."""
+
+    def __init__(self, data_dir=None, dims=None, sigma_v_init=0.5, u_v_init=0.1, cps=None, save_dirs=None, **kw):
+        import logging
+        logging.getLogger('default').warning(
+            f'BiobankDataLoader: reading {data_dir!r} needs SimpleITK (out of scope); using the synthetic pair at {dims}')
+        super().__init__(dims, sigma_v_init, u_v_init, cps, save_dirs, **kw)
