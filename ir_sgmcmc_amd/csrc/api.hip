@@ -152,7 +152,7 @@ int irs_svf_exp_fwd(const float* v, float* steps, float* transformation, float* 
     const int64_t field = (int64_t)C * 3 * vol.V;
     for (int k = 0; k < no_steps; ++k) {
         const float* in = k == 0 ? v : steps + (int64_t)(k - 1) * field;
-        if (use_lds_exp()) launch_exp_step_fwd_lds(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, nullptr,
+        if (use_lds_exp()) launch_exp_step_fwd_lds(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, nullptr, nullptr,
                                                    exp_halo(k, no_steps), st);
         else launch_exp_step_fwd(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, st);
     }
@@ -178,8 +178,9 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
         const float* dk = k == 0 ? v : steps + (int64_t)(k - 1) * field;
         if (lds) {
             launch_field_absmax(dk, k == 0, no_steps, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, C, vol, st);
-            launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4,
-                                    exp_halo(k, no_steps), st);
+            const int rad = env_int("IRS_EXP_GATHER", 2);
+            if (rad) launch_exp_step_bwd_gather(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, st);
+            launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, rad, st);
         } else {
             HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
             launch_exp_step_bwd(G, dk, out, k == 0, no_steps, C, vol, lin, st);
@@ -614,12 +615,15 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     const int64_t field = (int64_t)c->C * 3 * c->vol.V;
     const Lin lin = c->lin.lin();
     const bool lds = use_lds_exp();
-    if (lds) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * cfg.no_steps, st));
+    if (lds) {
+        HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (cfg.no_steps + 1), st));
+        launch_field_absmax(dense, true, cfg.no_steps, c->dmax, C, c->vol, st);  // bound of d_0
+    }
     for (int k = 0; k < cfg.no_steps; ++k) {
         const float* in = k == 0 ? dense : c->steps + (int64_t)(k - 1) * field;
         float* out = c->steps + (int64_t)k * field;
         if (lds) launch_exp_step_fwd_lds(in, out, k == 0, cfg.no_steps, C, c->vol, lin, c->dmax + (int64_t)k * c->C * 4,
-                                         exp_halo(k, cfg.no_steps), st);
+                                         c->dmax + (int64_t)(k + 1) * c->C * 4, 0, st);
         else launch_exp_step_fwd(in, out, k == 0, cfg.no_steps, C, c->vol, lin, st);
     }
     if (timed) HIP_TRY(hipEventRecord(c->ev[2], st));
@@ -708,8 +712,12 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
             const bool lds = use_lds_exp();
             if (!lds) HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
             if (timed) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k], st));
-            if (lds) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, c->dmax + (int64_t)k * C * 4,
-                                             exp_halo(k, cfg.no_steps), st);
+            if (lds) {
+                const unsigned* dm = c->dmax + (int64_t)k * C * 4;
+                const int rad = env_int("IRS_EXP_GATHER", 2);  // largest gather radius to launch (0: scatter only)
+                if (rad) launch_exp_step_bwd_gather(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, st);
+                launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, st);
+            }
             else launch_exp_step_bwd(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, st);
             if (timed) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k + 1], st));
             G = out;

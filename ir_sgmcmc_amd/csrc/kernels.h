@@ -52,9 +52,13 @@ void launch_scale_channels(const float* in, float* out, float s0, float s1, floa
 
 // ---- exp_kernels.hip (LDS-tiled squaring step + owner-computes adjoint)
 void launch_exp_step_fwd_lds(const float* din, float* dout, bool prescale, int no_steps, int C, Vol vol, Lin lin,
-                             unsigned* dmax, int halo, hipStream_t st);
+                             const unsigned* dmax_in, unsigned* dmax_out, int halo, hipStream_t st);
+// the adjoint is launched as a pair: the gather kernel does the work when max|d_k| < radius, otherwise it exits at once
+// and the (LDS-atomic) scatter kernel, which skips launches the gather kernel owns, does it; decided on the device
+void launch_exp_step_bwd_gather(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
+                                Lin lin, const unsigned* dmax, int radius, hipStream_t st);
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
-                             Lin lin, const unsigned* dmax, int halo, hipStream_t st);
+                             Lin lin, const unsigned* dmax, int halo, int gather_radius, hipStream_t st);
 void launch_field_absmax(const float* d, bool prescale, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st);
 
 // ---- data_kernels.hip
