@@ -3,6 +3,13 @@ import torch
 
 PARITY = {}
 
+# Gradient tolerance, relative to max|grad|.  The north star states tolerances for the loss (1e-5 relative) and the
+# displacement field (1e-4); for the gradient the yardstick is the reference itself: its fp32 autograd through the 12
+# grid_sample calls deviates 1e-4 .. 1.7e-2 (relative) from an fp64 evaluation of the same chain, growing as the
+# displacement shrinks and the volume grows (measured in this container, DESIGN.md "Numerics").  The HIP path is held
+# to 1e-3 of the reference's fp32 values -- inside that band -- and typically lands at 1e-6 .. 7e-4.
+GRAD_RTOL = 1e-3
+
 
 def check(test, key, a, b, tol):
     a = torch.as_tensor(a).detach().double().cpu()
