@@ -35,8 +35,13 @@ def cpu_baseline(n_small, reps, loss):
     import torch
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from oracle import OracleChain, OracleConfig
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get('IRS_CPU_THREADS', '16'))))  # a 1-GPU box owns a 16-core share
     torch.set_num_threads(cores)
+    print(f'[bench] cpu baseline: oracle at {n_small}^3 on {cores} threads ...', file=sys.stderr, flush=True)
     dims = (n_small,) * 3
     cfg = OracleConfig(dims=dims, data_loss='GMM' if loss == 'gmm' else 'SSD', virtual_decimation=(loss == 'gmm'))
     f1, m1 = synthetic_pair(dims, seed=0)
@@ -49,8 +54,9 @@ def cpu_baseline(n_small, reps, loss):
     unif = torch.rand(1, 3, *dims, generator=g)
     ch.transition(fixed, moving, eps, unif)  # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
-    for _ in range(reps):
+    for i in range(reps):
         ch.transition(fixed, moving, eps, unif)
+        print(f'[bench] cpu baseline: {i + 1}/{reps} after {time.perf_counter() - t0:.1f} s', file=sys.stderr, flush=True)
     dt = (time.perf_counter() - t0) / reps
     return dt, cores
 
@@ -63,8 +69,8 @@ def main():
     ap.add_argument('--size', type=int, default=256, help='volume edge N (N^3 voxels)')
     ap.add_argument('--loss', choices=['gmm', 'ssd'], default='gmm')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-size', type=int, default=128)
-    ap.add_argument('--cpu-reps', type=int, default=2)
+    ap.add_argument('--cpu-size', type=int, default=64)
+    ap.add_argument('--cpu-reps', type=int, default=5)
     args = ap.parse_args()
 
     import torch
