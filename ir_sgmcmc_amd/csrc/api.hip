@@ -212,7 +212,7 @@ int irs_svf_exp_bwd(const float* v, const float* steps, const float* g_last, flo
     if (exp_backward(v, steps, g_last, scratch, scratch + field, no_steps, C, vol, lin, st, &res)) return 1;
     float s[3];
     prescale_factors(vol, no_steps, s);
-    launch_scale_channels(res, g_v, s[0], s[1], s[2], C, vol.V, st);
+    launch_scale_channels(res, g_v, s[0], s[1], s[2], C, vol, st);
     LAUNCH_CHECK();
     return 0;
 }
@@ -730,7 +730,7 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     prescale_factors(vol, cfg.no_steps, s);
     if (c->ffd) {
         float* scaled = g0 == c->gA ? c->gB : c->gA;
-        launch_scale_channels(g0, scaled, s[0], s[1], s[2], C, vol.V, st);
+        launch_scale_channels(g0, scaled, s[0], s[1], s[2], C, vol, st);
         const int G[3] = {volv.D, volv.H, volv.W};
         ffd_adjoint(scaled, c->tmpB, c->tmpA, C, vol, G, c->spl, st);
         launch_sgld_update(io->v, io->sigma, c->tmpB, vs, c->state, cfg.lr, 1.0f, 1.0f, 1.0f, io->grad_v, C, volv, st);

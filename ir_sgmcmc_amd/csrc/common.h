@@ -18,6 +18,33 @@ struct Vol {
 
 __host__ __device__ inline Vol make_vol(int D, int H, int W) { return Vol{D, H, W, (int64_t)D * H * W}; }
 
+inline dim3 vox_grid(const Vol& vol, int planes) {
+    return dim3((unsigned)((vol.W + 63) / 64), (unsigned)((vol.H + 3) / 4), (unsigned)(vol.D * planes));
+}
+
+// Division-free voxel mapping for the pointwise kernels: 256-thread blocks laid out 64 (x) x 4 (y),
+// grid = (ceil(W/64), ceil(H/4), D * planes) where a "plane" is a chain or a (chain, channel) pair.
+// (A flat 1-D index needs three 64-bit divisions per thread -- hundreds of instructions in kernels that move 20-50 bytes.)
+#define IRS_VOXEL(vol, PLANE, X, Y, Z, VOX)                                   \
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63);                        \
+    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);                         \
+    const int PLANE = blockIdx.z / (vol).D;                                    \
+    const int Z = blockIdx.z - PLANE * (vol).D;                                \
+    if (X >= (vol).W || Y >= (vol).H) return;                                  \
+    const int64_t VOX = ((int64_t)Z * (vol).H + Y) * (vol).W + X
+
+// Grid-stride loop over the rows of a volume for the reduction kernels: each wavefront of a 256-thread block walks
+// rows (y, z) and its lanes stride along x, so the only division is one 32-bit one per row.
+#define IRS_ROWS_BEGIN(vol, X, Y, Z, VOX)                                                                             \
+    for (int row_ = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); row_ < (vol).H * (vol).D;                     \
+         row_ += gridDim.x * (kBlock / kWave)) {                                                                       \
+        const int Z = row_ / (vol).H, Y = row_ - Z * (vol).H;                                                          \
+        for (int X = threadIdx.x & 63; X < (vol).W; X += kWave) {                                                      \
+            const int64_t VOX = ((int64_t)Z * (vol).H + Y) * (vol).W + X;
+#define IRS_ROWS_END \
+        }            \
+    }
+
 // identity-grid tables: linspace(-1, 1, n) per axis as torch's CPU kernel computes it
 // (utils/util.py:263-278).  x <-> W, y <-> H, z <-> D.
 struct Lin {

@@ -278,7 +278,8 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(const float* __restrict
     const float alpha = (float)state->sc.alpha[chain];
     const float is = state->ssd_inv_sigma;
     double acc[1] = {0.0};
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < vol.V; v += (int64_t)gridDim.x * kBlock) {
+    IRS_ROWS_BEGIN(vol, x, y, zc, v)
+        (void)y; (void)zc;
         float g = 0.0f;
         if (mask[v]) {
             const float u = z[v] * is;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(const float* __restrict
             g = -alpha * u * is;
         }
         g_m[v] = g;
-    }
+    IRS_ROWS_END
     block_sum<1>(acc, smem);
     if (threadIdx.x == 0) nll_out[blockIdx.x] = acc[0];
 }
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void stats_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < kStatVals; ++j) acc[j] = 0.0;
     const int64_t plane = (int64_t)vol.W * vol.H;
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < vol.V; v += (int64_t)gridDim.x * kBlock) {
+    IRS_ROWS_BEGIN(vol, x, y, zc, v)
         if (!mask[v]) continue;
         float resp[IRS_MAX_COMPONENTS], q[IRS_MAX_COMPONENTS];
         const MixEval e = mix_eval<true>(z[v], state, resp, q);
@@ -347,13 +348,12 @@ __global__ __launch_bounds__(kBlock) void stats_kernel(const float* __restrict__
                 }
         }
         if (want_vd) {
-            const int x = (int)(v % vol.W), y = (int)((v / vol.W) % vol.H), zc = (int)(v / plane);
             // lag-1 neighbours along D (reference "cov_x", dim 2), H (dim 3), W (dim 4)
             if (zc + 1 < vol.D && mask[v + plane]) acc[2] += (double)(e.x * mix_eval<false>(z[v + plane], state, nullptr, nullptr).x);
             if (y + 1 < vol.H && mask[v + vol.W]) acc[3] += (double)(e.x * mix_eval<false>(z[v + vol.W], state, nullptr, nullptr).x);
             if (x + 1 < vol.W && mask[v + 1]) acc[4] += (double)(e.x * mix_eval<false>(z[v + 1], state, nullptr, nullptr).x);
         }
-    }
+    IRS_ROWS_END
     block_sum<kStatVals>(acc, smem);
     if (threadIdx.x == 0)
 #pragma unroll
@@ -374,17 +374,16 @@ void launch_stats(int want_vd, const float* z, const uint8_t* mask, const void* 
 // SSD residual z = F - M o phi (builder-defined data term)
 __global__ __launch_bounds__(kBlock) void residual_ssd_kernel(const float* __restrict__ fixed, int64_t f_stride,
                                                               const float* __restrict__ warped, float* __restrict__ z,
-                                                              int64_t V) {
-    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (p >= V) return;
-    const int64_t i = (int64_t)blockIdx.y * V + p;
-    z[i] = fixed[(int64_t)blockIdx.y * f_stride + p] - warped[i];
+                                                              Vol vol) {
+    IRS_VOXEL(vol, chain, x, y, zz, p);
+    (void)x; (void)y; (void)zz;
+    const int64_t i = (int64_t)chain * vol.V + p;
+    z[i] = fixed[(int64_t)chain * f_stride + p] - warped[i];
 }
 
 void launch_residual_ssd(const float* fixed, int64_t f_stride, const float* warped, float* z, int C, Vol vol,
                          hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
-    hipLaunchKernelGGL(residual_ssd_kernel, grid, dim3(kBlock), 0, st, fixed, f_stride, warped, z, vol.V);
+    hipLaunchKernelGGL(residual_ssd_kernel, vox_grid(vol, C), dim3(kBlock), 0, st, fixed, f_stride, warped, z, vol);
 }
 
 // n, sum z, sum z^2 over the mask (GMM initialisation, trainer.py:537-541); partials: [blocks][3]
@@ -393,13 +392,15 @@ __global__ __launch_bounds__(kBlock) void masked_moments_kernel(const float* __r
                                                                 double* __restrict__ partials, Vol vol) {
     __shared__ double smem[3 * (kBlock / kWave)];
     double acc[3] = {0.0, 0.0, 0.0};
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < vol.V; v += (int64_t)gridDim.x * kBlock)
+    IRS_ROWS_BEGIN(vol, x, y, zc, v)
+        (void)x; (void)y; (void)zc;
         if (mask[v]) {
             const double zz = (double)z[v];
             acc[0] += 1.0;
             acc[1] += zz;
             acc[2] += zz * zz;
         }
+    IRS_ROWS_END
     block_sum<3>(acc, smem);
     if (threadIdx.x == 0)
         for (int j = 0; j < 3; ++j) partials[(int64_t)blockIdx.x * 3 + j] = acc[j];
@@ -419,8 +420,7 @@ __global__ __launch_bounds__(kBlock) void reg_energy_kernel(const float* __restr
     const int64_t plane = (int64_t)vol.W * vol.H;
     const float* f = v + (int64_t)blockIdx.y * 3 * vol.V;
     double acc[1] = {0.0};
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < vol.V; p += (int64_t)gridDim.x * kBlock) {
-        const int x = (int)(p % vol.W), y = (int)((p / vol.W) % vol.H), z = (int)(p / plane);
+    IRS_ROWS_BEGIN(vol, x, y, z, p)
         float e = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void reg_energy_kernel(const float* __restr
             if (z + 1 < vol.D) { const float d = fc[p + plane] - v0; e += (z + 2 == vol.D ? 2.0f : 1.0f) * d * d; }
         }
         acc[0] += (double)e;
-    }
+    IRS_ROWS_END
     block_sum<1>(acc, smem);
     if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = acc[0];
 }
@@ -475,12 +475,9 @@ __global__ __launch_bounds__(kBlock) void sgld_update_kernel(float* __restrict__
                                                              const float* __restrict__ g, const float* __restrict__ v_s,
                                                              const DevState* __restrict__ state, float lr, float s0,
                                                              float s1, float s2, float* __restrict__ grad_out, Vol vol) {
-    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (p >= vol.V) return;
-    const int chain = blockIdx.y;
+    IRS_VOXEL(vol, chain, x, y, z, p);
     const int64_t cb = (int64_t)chain * 3 * vol.V;
     const int64_t plane = (int64_t)vol.W * vol.H;
-    const int x = (int)(p % vol.W), y = (int)((p / vol.W) % vol.H), z = (int)(p / plane);
     const float coef2 = 2.0f * (float)state->coef[chain];
     const float sc[3] = {s0, s1, s2};
 #pragma unroll
@@ -498,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void sgld_update_kernel(float* __restrict__
 
 void launch_sgld_update(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
                         float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL(sgld_update_kernel, grid, dim3(kBlock), 0, st, v, sigma, g_d0, v_s, (const DevState*)dev_state, lr,
                        s0, s1, s2, grad_out, vol);
 }
@@ -512,11 +509,9 @@ __device__ __forceinline__ float fwd_diff(const float* __restrict__ f, int64_t p
 
 __global__ __launch_bounds__(kBlock) void gradient_operator_kernel(const float* __restrict__ v, float* __restrict__ nabla,
                                                                    int transformation, Vol vol) {
-    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (p >= vol.V) return;
-    const int64_t cb = (int64_t)blockIdx.y * 3 * vol.V;
+    IRS_VOXEL(vol, chain, x, y, z, p);
+    const int64_t cb = (int64_t)chain * 3 * vol.V;
     const int64_t plane = (int64_t)vol.W * vol.H;
-    const int x = (int)(p % vol.W), y = (int)((p / vol.W) % vol.H), z = (int)(p / plane);
     const float sp[3] = {2.0f / (float)(vol.W - 1), 2.0f / (float)(vol.H - 1), 2.0f / (float)(vol.D - 1)};
 #pragma unroll
     for (int comp = 0; comp < 3; ++comp) {
@@ -525,13 +520,13 @@ __global__ __launch_bounds__(kBlock) void gradient_operator_kernel(const float* 
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             if (transformation) d[a] = d[a] / sp[a];
-            nabla[(((int64_t)blockIdx.y * 3 + a) * vol.V + p) * 3 + comp] = d[a];
+            nabla[(((int64_t)chain * 3 + a) * vol.V + p) * 3 + comp] = d[a];
         }
     }
 }
 
 void launch_gradient_operator(const float* v, float* nabla, int transformation, int C, Vol vol, hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL(gradient_operator_kernel, grid, dim3(kBlock), 0, st, v, nabla, transformation, vol);
 }
 
@@ -539,12 +534,13 @@ void launch_gradient_operator(const float* v, float* nabla, int transformation, 
 // utils/util.py:72-91,209-212) and the count of NaNs (= folded voxels) per chain
 __global__ __launch_bounds__(kBlock) void log_det_kernel(const float* __restrict__ t, float* __restrict__ log_det,
                                                          long long* __restrict__ nan_count, Vol vol) {
-    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int chain = blockIdx.z / vol.D, z = blockIdx.z - chain * vol.D;
     int bad = 0;
-    if (p < vol.V) {
-        const int64_t cb = (int64_t)blockIdx.y * 3 * vol.V;
+    if (x < vol.W && y < vol.H) {
+        const int64_t p = ((int64_t)z * vol.H + y) * vol.W + x;
+        const int64_t cb = (int64_t)chain * 3 * vol.V;
         const int64_t plane = (int64_t)vol.W * vol.H;
-        const int x = (int)(p % vol.W), y = (int)((p / vol.W) % vol.H), z = (int)(p / plane);
         const float sp[3] = {2.0f / (float)(vol.W - 1), 2.0f / (float)(vol.H - 1), 2.0f / (float)(vol.D - 1)};
         float n[3][3];  // n[a][comp]
 #pragma unroll
@@ -558,16 +554,16 @@ __global__ __launch_bounds__(kBlock) void log_det_kernel(const float* __restrict
         const float det = n[0][0] * n[1][1] * n[2][2] + n[0][1] * n[1][2] * n[2][0] + n[0][2] * n[1][0] * n[2][1] -
                           n[2][0] * n[1][1] * n[0][2] - n[2][1] * n[1][2] * n[0][0] - n[2][2] * n[1][0] * n[0][1];
         const float ld = logf(det);
-        if (log_det) log_det[(int64_t)blockIdx.y * vol.V + p] = ld;
+        if (log_det) log_det[(int64_t)chain * vol.V + p] = ld;
         bad = ld != ld;
     }
     const unsigned long long b = __ballot(bad);
-    if ((threadIdx.x & (kWave - 1)) == 0 && b) atomicAdd((unsigned long long*)(nan_count + blockIdx.y), (unsigned long long)__popcll(b));
+    if ((threadIdx.x & (kWave - 1)) == 0 && b) atomicAdd((unsigned long long*)(nan_count + chain), (unsigned long long)__popcll(b));
 }
 
 void launch_log_det_jacobian(const float* t, float* log_det, long long* nan_count, int C, Vol vol, hipStream_t st) {
     (void)hipMemsetAsync(nan_count, 0, sizeof(long long) * C, st);
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL(log_det_kernel, grid, dim3(kBlock), 0, st, t, log_det, nan_count, vol);
 }
 

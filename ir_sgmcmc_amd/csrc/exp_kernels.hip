@@ -35,6 +35,14 @@ __device__ __forceinline__ void atomic_max_nonneg(unsigned* addr, float v) {
     atomicMax(addr, __float_as_uint(v));
 }
 
+// The squaring-step kernels walk the tiles of all chains with a grid-stride loop over a capped grid: of the variants
+// launched per step only one does work (chosen on the device), and an idle variant should cost a few thousand empty
+// workgroups, not one per tile.
+struct TileGrid {
+    int ntx, nty, ntz, total;  // tiles per axis, total over all chains
+};
+constexpr int kExpGridCap = 4096;
+
 template <int H>
 struct ExpBox {
     static constexpr int SX = ETX + 2 * H, SY = ETY + 2 * H, SZ = ETZ + 2 * H, SN = SX * SY * SZ;
@@ -63,17 +71,24 @@ template <bool PRESCALE, int H>
 __global__ __launch_bounds__(kExpBlock) void exp_fwd_lds_kernel(const float* __restrict__ din, float* __restrict__ dout,
                                                                 Vol vol, Lin lin, Scale3L sc,
                                                                 const unsigned* __restrict__ dmax_in,
-                                                                unsigned* __restrict__ dmax_out, int tiles_z, int h_lo,
+                                                                unsigned* __restrict__ dmax_out, TileGrid tg, int h_lo,
                                                                 int h_hi) {
     using B = ExpBox<H>;
     __shared__ float lds[3 * B::SN];
-    const int chain = blockIdx.z / tiles_z;
+    __shared__ float red[3 * (kExpBlock / kWave)];
+  for (int tile = blockIdx.x; tile < tg.total; tile += gridDim.x) {
+    int t_ = tile;
+    const int ox = (t_ % tg.ntx) * ETX;
+    t_ /= tg.ntx;
+    const int oy = (t_ % tg.nty) * ETY;
+    t_ /= tg.nty;
+    const int oz = (t_ % tg.ntz) * ETZ;
+    const int chain = t_ / tg.ntz;
     if (dmax_in) {  // variant selection: this halo serves ceil(max|d_k|) in (h_lo, h_hi]
         const int need = max(max((int)ceilf(__uint_as_float(dmax_in[chain * 4 + 0])), (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 1]))),
                              (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 2])));
-        if (need <= h_lo || need > h_hi) return;
+        if (need <= h_lo || need > h_hi) continue;
     }
-    const int ox = blockIdx.x * ETX, oy = blockIdx.y * ETY, oz = (blockIdx.z % tiles_z) * ETZ;
     const int64_t V = vol.V;
     const float* c0 = din + (int64_t)chain * 3 * V;
     const float* c1 = c0 + V;
@@ -143,7 +158,6 @@ __global__ __launch_bounds__(kExpBlock) void exp_fwd_lds_kernel(const float* __r
         // max |d_k| in voxels per axis (normalised -> voxels: * (n - 1) / 2).  Reduced over the workgroup first, and the
         // atomic is skipped when the published bound already covers it (the bound only grows, so a stale read is safe):
         // thousands of same-address atomics per launch would serialise at the memory side.
-        __shared__ float red[3 * (kExpBlock / kWave)];
         m0 *= 0.5f * sc.nm1[0];
         m1 *= 0.5f * sc.nm1[1];
         m2 *= 0.5f * sc.nm1[2];
@@ -168,6 +182,8 @@ __global__ __launch_bounds__(kExpBlock) void exp_fwd_lds_kernel(const float* __r
             if (__float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_nonneg(slot, m);
         }
     }
+    __syncthreads();  // LDS is reused by the next tile
+  }
 }
 
 static Scale3L make_scale_l(Vol vol, int no_steps) {
@@ -179,9 +195,12 @@ static Scale3L make_scale_l(Vol vol, int no_steps) {
     return s;
 }
 
-static dim3 exp_grid(Vol vol, int C, int* tiles_z) {
-    *tiles_z = (vol.D + ETZ - 1) / ETZ;
-    return dim3((vol.W + ETX - 1) / ETX, (vol.H + ETY - 1) / ETY, (unsigned)(*tiles_z * C));
+static dim3 exp_grid(Vol vol, int C, TileGrid* tg) {
+    tg->ntx = (vol.W + ETX - 1) / ETX;
+    tg->nty = (vol.H + ETY - 1) / ETY;
+    tg->ntz = (vol.D + ETZ - 1) / ETZ;
+    tg->total = tg->ntx * tg->nty * tg->ntz * C;
+    return dim3((unsigned)(tg->total < kExpGridCap ? tg->total : kExpGridCap));
 }
 
 // dmax_in = published bound of the INPUT field (nullptr: unknown -> one launch with `halo`); dmax_out receives the bound
@@ -189,7 +208,7 @@ static dim3 exp_grid(Vol vol, int C, int* tiles_z) {
 // displacement stays below one voxel, halo 2 otherwise (taps beyond the staged box fall back to global memory).
 void launch_exp_step_fwd_lds(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
                              const unsigned* dmax_in, unsigned* dmax_out, int halo, hipStream_t st) {
-    int tz;
+    TileGrid tz;
     const dim3 grid = exp_grid(vol, C, &tz);
     const Scale3L sc = make_scale_l(vol, no_steps);
 #define IRS_FWD(P, HH, LO, HI) hipLaunchKernelGGL((exp_fwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, tz, LO, HI)
@@ -294,18 +313,24 @@ __device__ __forceinline__ void adjoint_source(const int x, const int y, const i
 template <bool PRESCALE, int H>
 __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __restrict__ G, const float* __restrict__ dk,
                                                                 float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
-                                                                const unsigned* __restrict__ dmax, int tiles_z,
+                                                                const unsigned* __restrict__ dmax, TileGrid tg,
                                                                 int gather_radius) {
     using B = ExpBox<H>;
     __shared__ float lds[3 * B::SN];
     __shared__ float acc[3 * ETN];
-    const int chain = blockIdx.z / tiles_z;
+  for (int tile = blockIdx.x; tile < tg.total; tile += gridDim.x) {
+    int t_ = tile;
+    const int ox = (t_ % tg.ntx) * ETX;
+    t_ /= tg.ntx;
+    const int oy = (t_ % tg.nty) * ETY;
+    t_ /= tg.nty;
+    const int oz = (t_ % tg.ntz) * ETZ;
+    const int chain = t_ / tg.ntz;
     {   // the gather kernel owns this launch when every source halo fits its radius
         const int h0 = (int)floorf(__uint_as_float(dmax[chain * 4 + 0])) + 1, h1 = (int)floorf(__uint_as_float(dmax[chain * 4 + 1])) + 1,
                   h2 = (int)floorf(__uint_as_float(dmax[chain * 4 + 2])) + 1;
-        if (h0 <= gather_radius && h1 <= gather_radius && h2 <= gather_radius) return;
+        if (h0 <= gather_radius && h1 <= gather_radius && h2 <= gather_radius) continue;
     }
-    const int ox = blockIdx.x * ETX, oy = blockIdx.y * ETY, oz = (blockIdx.z % tiles_z) * ETZ;
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
     const float* c0 = dk + cb;
@@ -365,11 +390,13 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
         o[g + V] = acc[ETN + i];
         o[g + 2 * V] = acc[2 * ETN + i];
     }
+    __syncthreads();
+  }
 }
 
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                              Lin lin, const unsigned* dmax, int halo, int gather_radius, hipStream_t st) {
-    int tz;
+    TileGrid tz;
     const dim3 grid = exp_grid(vol, C, &tz);
     const Scale3L sc = make_scale_l(vol, no_steps);
 #define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius)
@@ -400,16 +427,22 @@ template <bool PRESCALE, int R>
 __global__ __launch_bounds__(kExpBlock) void exp_bwd_gather_kernel(const float* __restrict__ G,
                                                                    const float* __restrict__ dk, float* __restrict__ gout,
                                                                    Vol vol, Lin lin, Scale3L sc,
-                                                                   const unsigned* __restrict__ dmax, int tiles_z, int r_lo) {
+                                                                   const unsigned* __restrict__ dmax, TileGrid tg, int r_lo) {
     using B = ExpBox<R>;
     __shared__ float rec[6 * B::SN];
-    const int chain = blockIdx.z / tiles_z;
+  for (int tile = blockIdx.x; tile < tg.total; tile += gridDim.x) {
+    int t_ = tile;
+    const int ox = (t_ % tg.ntx) * ETX;
+    t_ /= tg.ntx;
+    const int oy = (t_ % tg.nty) * ETY;
+    t_ /= tg.nty;
+    const int oz = (t_ % tg.ntz) * ETZ;
+    const int chain = t_ / tg.ntz;
     {   // this variant owns the launch iff the needed source halo hs = floor(max|d|) + 1 satisfies R_lo < hs <= R
         const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
                            (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
-        if (hs > R || hs <= r_lo) return;
+        if (hs > R || hs <= r_lo) continue;
     }
-    const int ox = blockIdx.x * ETX, oy = blockIdx.y * ETY, oz = (blockIdx.z % tiles_z) * ETZ;
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
     const float* c0 = dk + cb;
@@ -540,13 +573,15 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_gather_kernel(const float* 
         o[g + V] = own[j][1] + acc[j][1];
         o[g + 2 * V] = own[j][2] + acc[j][2];
     }
+    __syncthreads();
+  }
 }
 
 // launches the radius-1 and radius-2 variants back to back; on the device exactly one of {gather<1>, gather<2>, scatter}
 // does the work of a step, chosen from the displacement bound the forward pass published
 void launch_exp_step_bwd_gather(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                                 Lin lin, const unsigned* dmax, int max_radius, hipStream_t st) {
-    int tz;
+    TileGrid tz;
     const dim3 grid = exp_grid(vol, C, &tz);
     const Scale3L sc = make_scale_l(vol, no_steps);
 #define IRS_BWG(P, RR, LO) hipLaunchKernelGGL((exp_bwd_gather_kernel<P, RR>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, LO)
@@ -564,24 +599,35 @@ void launch_exp_step_bwd_gather(const float* G, const float* dk, float* gout, bo
 template <bool PRESCALE>
 __global__ __launch_bounds__(kBlock) void field_absmax_kernel(const float* __restrict__ d, unsigned* __restrict__ dmax,
                                                               Vol vol, Scale3L sc) {
+    __shared__ float red[3 * (kBlock / kWave)];
     const int chain = blockIdx.y;
     const float* c0 = d + (int64_t)chain * 3 * vol.V;
     float m[3] = {0.0f, 0.0f, 0.0f};
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < vol.V; v += (int64_t)gridDim.x * kBlock)
+    IRS_ROWS_BEGIN(vol, x, y, z, v)
+        (void)x; (void)y; (void)z;
 #pragma unroll
         for (int c = 0; c < 3; ++c) m[c] = fmaxf(m[c], fabsf(ldp<PRESCALE>(c0 + c * vol.V, v, sc.nm1[c], sc.inv_pow)));
+    IRS_ROWS_END
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         m[c] *= 0.5f * sc.nm1[c];
 #pragma unroll
         for (int off = kWave / 2; off > 0; off >>= 1) m[c] = fmaxf(m[c], __shfl_down(m[c], off, kWave));
-        if ((threadIdx.x & (kWave - 1)) == 0) atomic_max_nonneg(dmax + chain * 4 + c, m[c]);
+        if ((threadIdx.x & (kWave - 1)) == 0) red[c * (kBlock / kWave) + threadIdx.x / kWave] = m[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float mm = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) mm = fmaxf(mm, red[threadIdx.x * (kBlock / kWave) + w]);
+        unsigned* slot = dmax + chain * 4 + threadIdx.x;
+        if (__float_as_uint(mm) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_nonneg(slot, mm);
     }
 }
 
 void launch_field_absmax(const float* d, bool prescale_in, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st) {
-    const int64_t b = (vol.V + kBlock - 1) / kBlock;
-    dim3 grid((unsigned)(b < 1024 ? b : 1024), C);
+    const int rows = vol.H * vol.D;
+    dim3 grid((unsigned)(rows / 4 < 2048 ? (rows + 3) / 4 : 2048), C);
     const Scale3L sc = make_scale_l(vol, no_steps);
     if (prescale_in) hipLaunchKernelGGL(field_absmax_kernel<true>, grid, dim3(kBlock), 0, st, d, dmax, vol, sc);
     else hipLaunchKernelGGL(field_absmax_kernel<false>, grid, dim3(kBlock), 0, st, d, dmax, vol, sc);

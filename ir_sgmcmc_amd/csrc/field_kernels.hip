@@ -14,11 +14,10 @@ namespace irs {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void perturb_kernel(const float* __restrict__ v, const float* __restrict__ sigma,
                                                          const float* __restrict__ eps, float amp,
-                                                         float* __restrict__ out, int64_t V, uint64_t seed,
+                                                         float* __restrict__ out, Vol vol, uint64_t seed,
                                                          uint64_t iteration, const uint64_t* __restrict__ dev_iter) {
-    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (vox >= V) return;
-    const int chain = blockIdx.y;
+    IRS_VOXEL(vol, chain, x, y, z, vox);
+    const int64_t V = vol.V;
     const int64_t base = (int64_t)chain * 3 * V + vox;
     float n[3];
     if (eps) {
@@ -44,8 +43,7 @@ __global__ __launch_bounds__(kBlock) void perturb_kernel(const float* __restrict
 
 void launch_perturb(const float* v, const float* sigma, const float* eps, float amp, float* out, int C, Vol vol,
                     uint64_t seed, uint64_t iteration, const uint64_t* dev_iteration, hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
-    hipLaunchKernelGGL(perturb_kernel, grid, dim3(kBlock), 0, st, v, sigma, eps, amp, out, vol.V, seed, iteration,
+    hipLaunchKernelGGL(perturb_kernel, vox_grid(vol, C), dim3(kBlock), 0, st, v, sigma, eps, amp, out, vol, seed, iteration,
                        dev_iteration);
 }
 
@@ -56,10 +54,8 @@ void launch_perturb(const float* v, const float* sigma, const float* eps, float 
 template <int AXIS>
 __global__ __launch_bounds__(kBlock) void conv_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            Taps taps, Vol vol) {
-    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (vox >= vol.V) return;
-    const int64_t base = (int64_t)blockIdx.y * vol.V;
-    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
+    IRS_VOXEL(vol, plane, x, y, z, vox);
+    const int64_t base = (int64_t)plane * vol.V;
     const int pos = AXIS == 0 ? x : (AXIS == 1 ? y : z);
     const int n = AXIS == 0 ? vol.W : (AXIS == 1 ? vol.H : vol.D);
     const int64_t stride = AXIS == 0 ? 1 : (AXIS == 1 ? vol.W : (int64_t)vol.W * vol.H);
@@ -73,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void conv_axis_kernel(const float* __restri
 }
 
 void launch_conv_axis(const float* in, float* out, const Taps& taps, int axis, int CC, Vol vol, hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), CC);
+    const dim3 grid = vox_grid(vol, CC);
     if (axis == 0) hipLaunchKernelGGL(conv_axis_kernel<0>, grid, dim3(kBlock), 0, st, in, out, taps, vol);
     else if (axis == 1) hipLaunchKernelGGL(conv_axis_kernel<1>, grid, dim3(kBlock), 0, st, in, out, taps, vol);
     else hipLaunchKernelGGL(conv_axis_kernel<2>, grid, dim3(kBlock), 0, st, in, out, taps, vol);
@@ -99,13 +95,11 @@ __device__ __forceinline__ float ld(const float* p, int64_t i, float nm1, float 
 template <bool PRESCALE>
 __global__ __launch_bounds__(kBlock) void exp_step_fwd_kernel(const float* __restrict__ din, float* __restrict__ dout,
                                                               Vol vol, Lin lin, Scale3 sc) {
-    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (vox >= vol.V) return;
+    IRS_VOXEL(vol, chain, x, y, z, vox);
     const int64_t V = vol.V;
-    const float* c0 = din + (int64_t)blockIdx.y * 3 * V;
+    const float* c0 = din + (int64_t)chain * 3 * V;
     const float* c1 = c0 + V;
     const float* c2 = c1 + V;
-    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
 
     const float d0 = ld<PRESCALE>(c0, vox, sc.nm1[0], sc.inv_pow);
     const float d1 = ld<PRESCALE>(c1, vox, sc.nm1[1], sc.inv_pow);
@@ -131,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void exp_step_fwd_kernel(const float* __res
             }
         }
     }
-    float* o = dout + (int64_t)blockIdx.y * 3 * V;
+    float* o = dout + (int64_t)chain * 3 * V;
     o[vox] = __fadd_rn(d0, a0);
     o[vox + V] = __fadd_rn(d1, a1);
     o[vox + 2 * V] = __fadd_rn(d2, a2);
@@ -148,7 +142,7 @@ static Scale3 make_scale(Vol vol, int no_steps) {
 
 void launch_exp_step_fwd(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
                          hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const dim3 grid = vox_grid(vol, C);
     const Scale3 sc = make_scale(vol, no_steps);
     if (prescale_in) hipLaunchKernelGGL(exp_step_fwd_kernel<true>, grid, dim3(kBlock), 0, st, din, dout, vol, lin, sc);
     else hipLaunchKernelGGL(exp_step_fwd_kernel<false>, grid, dim3(kBlock), 0, st, din, dout, vol, lin, sc);
@@ -164,17 +158,15 @@ void launch_exp_step_fwd(const float* din, float* dout, bool prescale_in, int no
 template <bool PRESCALE>
 __global__ __launch_bounds__(kBlock) void exp_step_bwd_kernel(const float* __restrict__ G, const float* __restrict__ dk,
                                                               float* __restrict__ gout, Vol vol, Lin lin, Scale3 sc) {
-    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (vox >= vol.V) return;
+    IRS_VOXEL(vol, chain, x, y, z, vox);
     const int64_t V = vol.V;
-    const int64_t cb = (int64_t)blockIdx.y * 3 * V;
+    const int64_t cb = (int64_t)chain * 3 * V;
     const float* c0 = dk + cb;
     const float* c1 = c0 + V;
     const float* c2 = c1 + V;
     float* g0 = gout + cb;
     float* g1 = g0 + V;
     float* g2 = g1 + V;
-    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
 
     const float G0 = G[cb + vox], G1 = G[cb + V + vox], G2 = G[cb + 2 * V + vox];
     const float d0 = ld<PRESCALE>(c0, vox, sc.nm1[0], sc.inv_pow);
@@ -218,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void exp_step_bwd_kernel(const float* __res
 
 void launch_exp_step_bwd(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                          Lin lin, hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const dim3 grid = vox_grid(vol, C);
     const Scale3 sc = make_scale(vol, no_steps);
     if (prescale_in) hipLaunchKernelGGL(exp_step_bwd_kernel<true>, grid, dim3(kBlock), 0, st, G, dk, gout, vol, lin, sc);
     else hipLaunchKernelGGL(exp_step_bwd_kernel<false>, grid, dim3(kBlock), 0, st, G, dk, gout, vol, lin, sc);
@@ -229,10 +221,8 @@ void launch_exp_step_bwd(const float* G, const float* dk, float* gout, bool pres
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void svf_outputs_kernel(const float* __restrict__ d, float* __restrict__ transf,
                                                              float* __restrict__ disp, Vol vol, Lin lin, Scale3 sc) {
-    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (vox >= vol.V) return;
-    const int64_t cb = (int64_t)blockIdx.y * 3 * vol.V;
-    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
+    IRS_VOXEL(vol, chain, x, y, z, vox);
+    const int64_t cb = (int64_t)chain * 3 * vol.V;
     const float idv[3] = {lin.x[x], lin.y[y], lin.z[z]};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -244,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void svf_outputs_kernel(const float* __rest
 
 void launch_svf_outputs(const float* d, float* transformation, float* displacement, int C, Vol vol, Lin lin,
                         hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL(svf_outputs_kernel, grid, dim3(kBlock), 0, st, d, transformation, displacement, vol, lin,
                        make_scale(vol, 0));
 }
@@ -291,10 +281,7 @@ __device__ __forceinline__ void grid_point(const float* __restrict__ d, const fl
 __global__ __launch_bounds__(kBlock) void warp_fwd_kernel(const float* __restrict__ im, int64_t im_stride,
                                                           const float* __restrict__ d, const float* __restrict__ unif,
                                                           Jitter jt, float* __restrict__ out, Vol vol, Lin lin) {
-    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (vox >= vol.V) return;
-    const int chain = blockIdx.y;
-    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
+    IRS_VOXEL(vol, chain, x, y, z, vox);
     float g[3];
     grid_point(d, unif, jt, (int64_t)chain * 3 * vol.V, chain, vox, vol, lin, x, y, z, g);
     const AxisTap tx = axis_tap(g[0], vol.W), ty = axis_tap(g[1], vol.H), tz = axis_tap(g[2], vol.D);
@@ -329,7 +316,7 @@ static Jitter make_jitter(float alpha, Vol vol, uint64_t seed, uint64_t iteratio
 void launch_warp_fwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha, float* out,
                      int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration, const uint64_t* dev_iteration,
                      hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL(warp_fwd_kernel, grid, dim3(kBlock), 0, st, im, im_stride, d, unif,
                        make_jitter(alpha, vol, seed, iteration, dev_iteration), out, vol, lin);
 }
@@ -338,11 +325,8 @@ __global__ __launch_bounds__(kBlock) void warp_bwd_kernel(const float* __restric
                                                           const float* __restrict__ d, const float* __restrict__ unif,
                                                           Jitter jt, const float* __restrict__ gw,
                                                           float* __restrict__ gd, Vol vol, Lin lin) {
-    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (vox >= vol.V) return;
-    const int chain = blockIdx.y;
+    IRS_VOXEL(vol, chain, x, y, z, vox);
     const int64_t cb3 = (int64_t)chain * 3 * vol.V;
-    const int x = (int)(vox % vol.W), y = (int)((vox / vol.W) % vol.H), z = (int)(vox / ((int64_t)vol.W * vol.H));
     float g[3];
     grid_point(d, unif, jt, cb3, chain, vox, vol, lin, x, y, z, g);
     const AxisTap tx = axis_tap(g[0], vol.W), ty = axis_tap(g[1], vol.H), tz = axis_tap(g[2], vol.D);
@@ -371,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void warp_bwd_kernel(const float* __restric
 void launch_warp_bwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha,
                      const float* g_warped, float* g_d, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
                      const uint64_t* dev_iteration, hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL(warp_bwd_kernel, grid, dim3(kBlock), 0, st, im, im_stride, d, unif,
                        make_jitter(alpha, vol, seed, iteration, dev_iteration), g_warped, g_d, vol, lin);
 }
@@ -381,9 +365,8 @@ template <typename T, bool NEAREST>
 __global__ __launch_bounds__(kBlock) void warp_transformation_kernel(const T* __restrict__ im, int64_t im_stride,
                                                                      const float* __restrict__ t, T* __restrict__ out,
                                                                      Vol vol) {
-    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (vox >= vol.V) return;
-    const int chain = blockIdx.y;
+    IRS_VOXEL(vol, chain, x, y, z, vox);
+    (void)x; (void)y; (void)z;
     const int64_t cb3 = (int64_t)chain * 3 * vol.V;
     const T* src = im + (int64_t)chain * im_stride;
     const float gx = t[cb3 + vox], gy = t[cb3 + vol.V + vox], gz = t[cb3 + 2 * vol.V + vox];
@@ -417,17 +400,17 @@ __global__ __launch_bounds__(kBlock) void warp_transformation_kernel(const T* __
 
 void launch_warp_transformation(const float* im, int64_t im_stride, const float* t, float* out, int C, Vol vol,
                                 hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL((warp_transformation_kernel<float, false>), grid, dim3(kBlock), 0, st, im, im_stride, t, out, vol);
 }
 void launch_warp_nearest_u8(const uint8_t* im, int64_t im_stride, const float* t, uint8_t* out, int C, Vol vol,
                             hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL((warp_transformation_kernel<uint8_t, true>), grid, dim3(kBlock), 0, st, im, im_stride, t, out, vol);
 }
 void launch_warp_nearest_i16(const int16_t* im, int64_t im_stride, const float* t, int16_t* out, int C, Vol vol,
                              hipStream_t st) {
-    dim3 grid((unsigned)((vol.V + kBlock - 1) / kBlock), C);
+    const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL((warp_transformation_kernel<int16_t, true>), grid, dim3(kBlock), 0, st, im, im_stride, t, out, vol);
 }
 
@@ -475,18 +458,18 @@ void launch_ffd_axis(const float* in, float* out, const SplineTaps& taps, bool a
 
 // out[c] = in[c] * s_c  (chain rule of the prescale: d_0 = v * 2/(n_c-1) / 2^steps)
 __global__ __launch_bounds__(kBlock) void scale_channels_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                float s0, float s1, float s2, int64_t V) {
-    const int64_t vox = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (vox >= V) return;
-    const int64_t cb = (int64_t)blockIdx.y * 3 * V;
+                                                                float s0, float s1, float s2, Vol vol) {
+    IRS_VOXEL(vol, chain, x, y, z, vox);
+    (void)x; (void)y; (void)z;
+    const int64_t V = vol.V;
+    const int64_t cb = (int64_t)chain * 3 * V;
     out[cb + vox] = in[cb + vox] * s0;
     out[cb + V + vox] = in[cb + V + vox] * s1;
     out[cb + 2 * V + vox] = in[cb + 2 * V + vox] * s2;
 }
 
-void launch_scale_channels(const float* in, float* out, float s0, float s1, float s2, int C, int64_t V, hipStream_t st) {
-    dim3 grid((unsigned)((V + kBlock - 1) / kBlock), C);
-    hipLaunchKernelGGL(scale_channels_kernel, grid, dim3(kBlock), 0, st, in, out, s0, s1, s2, V);
+void launch_scale_channels(const float* in, float* out, float s0, float s1, float s2, int C, Vol vol, hipStream_t st) {
+    hipLaunchKernelGGL(scale_channels_kernel, vox_grid(vol, C), dim3(kBlock), 0, st, in, out, s0, s1, s2, vol);
 }
 
 // ------------------------------------------------------------------------------------------------

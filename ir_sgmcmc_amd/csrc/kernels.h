@@ -48,7 +48,7 @@ void launch_warp_nearest_i16(const int16_t* im, int64_t im_stride, const float* 
                              hipStream_t st);
 void launch_ffd_axis(const float* in, float* out, const SplineTaps& taps, bool adjoint, int64_t outer, int n_in,
                      int n_out, int64_t inner, hipStream_t st);
-void launch_scale_channels(const float* in, float* out, float s0, float s1, float s2, int C, int64_t V, hipStream_t st);
+void launch_scale_channels(const float* in, float* out, float s0, float s1, float s2, int C, Vol vol, hipStream_t st);
 
 // ---- exp_kernels.hip (LDS-tiled squaring step + owner-computes adjoint)
 void launch_exp_step_fwd_lds(const float* din, float* dout, bool prescale, int no_steps, int C, Vol vol, Lin lin,
