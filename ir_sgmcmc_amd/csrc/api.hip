@@ -133,6 +133,15 @@ int irs_perturb_smooth(const float* v, const float* sigma, const float* eps, flo
         launch_perturb(v, sigma, eps, (float)sqrt(2.0 * (double)tau), out, C, vol, seed, iteration, nullptr, st);
         src = out;
     }
+    if (env_int("IRS_SOBOLEV_FUSED", 1)) {
+        if (src == out) {  // the fused kernel cannot run in place
+            HIP_TRY(hipMemcpyAsync(tmp, out, bytes, hipMemcpyDeviceToDevice, st));
+            src = tmp;
+        }
+        launch_sobolev_fused(src, out, taps, C * 3, vol, nullptr, 12, st);
+        LAUNCH_CHECK();
+        return 0;
+    }
     launch_conv_axis(src, tmp, taps, 2, C * 3, vol, st);   // z
     launch_conv_axis(tmp, out, taps, 1, C * 3, vol, st);   // y
     // x pass needs a third buffer: out -> tmp would leave the result in tmp; run x into tmp then copy back
@@ -598,10 +607,18 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     float* first = cfg.sobolev_s > 0 ? c->tmpA : vs;
     if (with_noise) launch_perturb(v, io->sigma, io->eps, (float)sqrt(2.0 * (double)cfg.lr), first, C, c->volv, cfg.seed, 0, it, st);
     else HIP_TRY(hipMemcpyAsync(first, v, (size_t)C * 3 * c->volv.V * sizeof(float), hipMemcpyDeviceToDevice, st));
+    const bool lds = use_lds_exp();
+    if (lds) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (cfg.no_steps + 1), st));
+    bool have_dmax0 = false;
     if (cfg.sobolev_s > 0) {
-        launch_conv_axis(c->tmpA, c->tmpB, c->sob, 2, C * 3, c->volv, st);
-        launch_conv_axis(c->tmpB, c->tmpA, c->sob, 1, C * 3, c->volv, st);
-        launch_conv_axis(c->tmpA, vs, c->sob, 0, C * 3, c->volv, st);
+        if (env_int("IRS_SOBOLEV_FUSED", 1)) {
+            have_dmax0 = lds && !c->ffd;
+            launch_sobolev_fused(c->tmpA, vs, c->sob, C * 3, c->volv, have_dmax0 ? c->dmax : nullptr, cfg.no_steps, st);
+        } else {
+            launch_conv_axis(c->tmpA, c->tmpB, c->sob, 2, C * 3, c->volv, st);
+            launch_conv_axis(c->tmpB, c->tmpA, c->sob, 1, C * 3, c->volv, st);
+            launch_conv_axis(c->tmpA, vs, c->sob, 0, C * 3, c->volv, st);
+        }
     }
     // 2. dense velocity
     const float* dense = vs;
@@ -614,11 +631,7 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     if (timed) HIP_TRY(hipEventRecord(c->ev[1], st));
     const int64_t field = (int64_t)c->C * 3 * c->vol.V;
     const Lin lin = c->lin.lin();
-    const bool lds = use_lds_exp();
-    if (lds) {
-        HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (cfg.no_steps + 1), st));
-        launch_field_absmax(dense, true, cfg.no_steps, c->dmax, C, c->vol, st);  // bound of d_0
-    }
+    if (lds && !have_dmax0) launch_field_absmax(dense, true, cfg.no_steps, c->dmax, C, c->vol, st);  // bound of d_0
     for (int k = 0; k < cfg.no_steps; ++k) {
         const float* in = k == 0 ? dense : c->steps + (int64_t)(k - 1) * field;
         float* out = c->steps + (int64_t)k * field;
