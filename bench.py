@@ -81,11 +81,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # IRS_BENCH_DEVICE / IRS_BENCH_BACKEND exist only to rehearse the multi-rank path on a 1-GPU box (gloo, shared device)
+    dev_index = int(os.environ.get('IRS_BENCH_DEVICE', local_rank))
+    backend = os.environ.get('IRS_BENCH_BACKEND', 'nccl')
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == 'nccl' else torch.device('cpu')
 
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from ir_sgmcmc_amd.engine import EngineConfig, TransitionEngine
@@ -118,7 +125,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert bool(torch.isfinite(v).all()), 'chain diverged'

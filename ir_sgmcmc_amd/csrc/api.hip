@@ -188,7 +188,8 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
         if (lds) {
             launch_field_absmax(dk, k == 0, no_steps, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, C, vol, st);
             const int rad = env_int("IRS_EXP_GATHER", 2);
-            if (rad) launch_exp_step_bwd_gather(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, st);
+            if (rad && env_int("IRS_EXP_MARCH", 1)) launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, st);
+            else if (rad) launch_exp_step_bwd_gather(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, st);
             launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, rad, st);
         } else {
             HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
@@ -728,7 +729,8 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
             if (lds) {
                 const unsigned* dm = c->dmax + (int64_t)k * C * 4;
                 const int rad = env_int("IRS_EXP_GATHER", 2);  // largest gather radius to launch (0: scatter only)
-                if (rad) launch_exp_step_bwd_gather(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, st);
+                if (rad && env_int("IRS_EXP_MARCH", 1)) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, st);
+                else if (rad) launch_exp_step_bwd_gather(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, st);
                 launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, st);
             }
             else launch_exp_step_bwd(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, st);
