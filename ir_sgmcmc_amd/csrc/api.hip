@@ -636,8 +636,11 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     for (int k = 0; k < cfg.no_steps; ++k) {
         const float* in = k == 0 ? dense : c->steps + (int64_t)(k - 1) * field;
         float* out = c->steps + (int64_t)k * field;
-        if (lds) launch_exp_step_fwd_lds(in, out, k == 0, cfg.no_steps, C, c->vol, lin, c->dmax + (int64_t)k * c->C * 4,
-                                         c->dmax + (int64_t)(k + 1) * c->C * 4, 0, st);
+        if (lds && env_int("IRS_EXP_MARCH", 1))
+            launch_exp_step_fwd_march(in, out, k == 0, cfg.no_steps, C, c->vol, lin, c->dmax + (int64_t)k * c->C * 4,
+                                      c->dmax + (int64_t)(k + 1) * c->C * 4, st);
+        else if (lds) launch_exp_step_fwd_lds(in, out, k == 0, cfg.no_steps, C, c->vol, lin, c->dmax + (int64_t)k * c->C * 4,
+                                              c->dmax + (int64_t)(k + 1) * c->C * 4, 0, st);
         else launch_exp_step_fwd(in, out, k == 0, cfg.no_steps, C, c->vol, lin, st);
     }
     if (timed) HIP_TRY(hipEventRecord(c->ev[2], st));

@@ -823,6 +823,181 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
 #undef IRS_BWM
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward step, z-marching: same schedule as the adjoint above -- a 256-thread workgroup owns a 32x8 column over a
+// z-segment, keeps a ring of 2R+1 planes of d (3 floats per voxel: 12 KB for R = 1) in LDS, prefetches plane s+1 while
+// plane s-R is being interpolated, and reads its 24 taps from the ring (global memory only if a tap leaves the ring).
+// ------------------------------------------------------------------------------------------------
+template <bool PRESCALE, int R>
+__global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float* __restrict__ din, float* __restrict__ dout,
+                                                                    Vol vol, Lin lin, Scale3L sc,
+                                                                    const unsigned* __restrict__ dmax_in,
+                                                                    unsigned* __restrict__ dmax_out, int seg_len, int nseg,
+                                                                    int h_lo, int h_hi) {
+    using M = March<PRESCALE, R>;
+    constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
+    __shared__ float ring[NP * 3 * PN];
+    __shared__ float red[3 * (kMarchBlock / kWave)];
+    const int chain = blockIdx.z / nseg, seg = blockIdx.z % nseg;
+    if (dmax_in) {
+        const int need = max(max((int)ceilf(__uint_as_float(dmax_in[chain * 4 + 0])), (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 1]))),
+                             (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 2])));
+        if (need <= h_lo || need > h_hi) return;
+    }
+    const int ox = blockIdx.x * MTX, oy = blockIdx.y * MTY;
+    const int z0 = seg * seg_len, z1 = min(z0 + seg_len, vol.D);
+    const int64_t V = vol.V;
+    const int64_t cb = (int64_t)chain * 3 * V;
+    const float* __restrict__ dx_ = din + cb;
+    const float* __restrict__ dy_ = dx_ + V;
+    const float* __restrict__ dz_ = dy_ + V;
+    float* __restrict__ o = dout + cb;
+    const int lx = threadIdx.x % MTX, ly = threadIdx.x / MTX;
+    const int x = ox + lx, y = oy + ly;
+    const bool col_in = x < vol.W && y < vol.H;
+    const float linx = col_in ? lin.x[x] : 0.0f, liny = col_in ? lin.y[y] : 0.0f;
+
+    int sxy[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * kMarchBlock;
+        const int px = i % PX, py = i / PX;
+        const int cx = min(max(ox - R + px, 0), vol.W - 1), cy = min(max(oy - R + py, 0), vol.H - 1);
+        sxy[it] = i < PN ? cy * vol.W + cx : -1;
+    }
+    float pre[NIT][3];
+    auto prefetch = [&](int s) {
+        const int sc_ = min(max(s, 0), vol.D - 1);  // planes outside the volume replicate the border plane
+        const int64_t zo = (int64_t)sc_ * vol.H * vol.W;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (sxy[it] < 0) continue;
+            const int64_t g = zo + sxy[it];
+            pre[it][0] = dx_[g];
+            pre[it][1] = dy_[g];
+            pre[it][2] = dz_[g];
+        }
+    };
+    auto commit = [&](int slot) {
+        float* rs = ring + slot * 3 * PN;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (sxy[it] < 0) continue;
+            const int i = threadIdx.x + it * kMarchBlock;
+            rs[i] = PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.inv_pow) : pre[it][0];
+            rs[PN + i] = PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.inv_pow) : pre[it][1];
+            rs[2 * PN + i] = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.inv_pow) : pre[it][2];
+        }
+    };
+
+    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
+    const int sbase = z0 - R, slast = z1 - 1 + R;
+    prefetch(sbase);
+    for (int sb = sbase; sb <= slast; sb += NP) {
+#pragma unroll
+        for (int PH = 0; PH < NP; ++PH) {
+            const int s = sb + PH;
+            if (s > slast) break;
+            commit(PH);
+            if (s + 1 <= slast) prefetch(s + 1);
+            __syncthreads();
+            const int zo = s - R;
+            if (zo >= z0 && zo < z1 && col_in) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int a = (PH - R + NP) % NP;
+                const int ci = (ly + R) * PX + (lx + R);
+                const float* rc = ring + a * 3 * PN;
+                const float d0 = rc[ci], d1 = rc[PN + ci], d2 = rc[2 * PN + ci];
+                const AxisTap tx = axis_tap(__fadd_rn(linx, d0), vol.W);
+                const AxisTap ty = axis_tap(__fadd_rn(liny, d1), vol.H);
+                const AxisTap tz = axis_tap(__fadd_rn(lin.z[zo], d2), vol.D);
+                const int bx0 = tx.i0 - (ox - R), bx1 = tx.i1 - (ox - R), by0 = ty.i0 - (oy - R), by1 = ty.i1 - (oy - R);
+                const bool in_ring = bx0 >= 0 && bx1 < PX && by0 >= 0 && by1 < M::PY && tz.i0 >= zo - R && tz.i1 <= zo + R;
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+                if (in_ring) {
+#pragma unroll
+                    for (int cz = 0; cz < 2; ++cz) {
+                        const int zz = cz ? tz.i1 : tz.i0;
+                        // plane zz of the volume is ring slot (zz - sbase) mod NP; zz is already clamped to the volume and a
+                        // clamped border plane was staged under the index of the plane it replicates
+                        const float* rt = ring + (((zz - sbase) % NP + NP) % NP) * 3 * PN;
+#pragma unroll
+                        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                            for (int cx = 0; cx < 2; ++cx) {
+                                const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
+                                const int ti = (cy ? by1 : by0) * PX + (cx ? bx1 : bx0);
+                                a0 = __fadd_rn(a0, __fmul_rn(rt[ti], w));
+                                a1 = __fadd_rn(a1, __fmul_rn(rt[PN + ti], w));
+                                a2 = __fadd_rn(a2, __fmul_rn(rt[2 * PN + ti], w));
+                            }
+                    }
+                } else {
+#pragma unroll
+                    for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+                        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                            for (int cx = 0; cx < 2; ++cx) {
+                                const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
+                                const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
+                                a0 = __fadd_rn(a0, __fmul_rn(ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.inv_pow), w));
+                                a1 = __fadd_rn(a1, __fmul_rn(ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.inv_pow), w));
+                                a2 = __fadd_rn(a2, __fmul_rn(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.inv_pow), w));
+                            }
+                }
+                const int64_t g = ((int64_t)zo * vol.H + y) * vol.W + x;
+                const float r0 = __fadd_rn(d0, a0), r1 = __fadd_rn(d1, a1), r2 = __fadd_rn(d2, a2);
+                o[g] = r0;
+                o[g + V] = r1;
+                o[g + 2 * V] = r2;
+                m0 = fmaxf(m0, fabsf(r0));
+                m1 = fmaxf(m1, fabsf(r1));
+                m2 = fmaxf(m2, fabsf(r2));
+            }
+            __syncthreads();
+        }
+    }
+    if (dmax_out) {
+        m0 *= 0.5f * sc.nm1[0];
+        m1 *= 0.5f * sc.nm1[1];
+        m2 *= 0.5f * sc.nm1[2];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            m0 = fmaxf(m0, __shfl_down(m0, off, kWave));
+            m1 = fmaxf(m1, __shfl_down(m1, off, kWave));
+            m2 = fmaxf(m2, __shfl_down(m2, off, kWave));
+        }
+        const int wid = threadIdx.x / kWave;
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            red[wid] = m0;
+            red[(kMarchBlock / kWave) + wid] = m1;
+            red[2 * (kMarchBlock / kWave) + wid] = m2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float m = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kMarchBlock / kWave; ++w) m = fmaxf(m, red[threadIdx.x * (kMarchBlock / kWave) + w]);
+            unsigned* slot = dmax_out + chain * 4 + threadIdx.x;
+            if (__float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_nonneg(slot, m);
+        }
+    }
+}
+
+void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
+                               const unsigned* dmax_in, unsigned* dmax_out, hipStream_t st) {
+    const int seg_len = 32;
+    const int nseg = (vol.D + seg_len - 1) / seg_len;
+    const dim3 grid((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
+    const Scale3L sc = make_scale_l(vol, no_steps);
+#define IRS_FWM(P, RR, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), grid, dim3(kMarchBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI)
+    if (prescale_in) { IRS_FWM(true, 1, -1, 1); IRS_FWM(true, 2, 1, 1 << 30); }
+    else { IRS_FWM(false, 1, -1, 1); IRS_FWM(false, 2, 1, 1 << 30); }
+#undef IRS_FWM
+}
+
 // per-chain max |d| (voxels, per axis) of a field -- used by the stateless adjoint, which has no forward by-product
 template <bool PRESCALE>
 __global__ __launch_bounds__(kBlock) void field_absmax_kernel(const float* __restrict__ d, unsigned* __restrict__ dmax,

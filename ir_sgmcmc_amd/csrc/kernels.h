@@ -57,6 +57,8 @@ void launch_exp_step_fwd_lds(const float* din, float* dout, bool prescale, int n
 // and the (LDS-atomic) scatter kernel, which skips launches the gather kernel owns, does it; decided on the device
 void launch_exp_step_bwd_gather(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
                                 Lin lin, const unsigned* dmax, int radius, hipStream_t st);
+void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale, int no_steps, int C, Vol vol, Lin lin,
+                               const unsigned* dmax_in, unsigned* dmax_out, hipStream_t st);
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, hipStream_t st);
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
