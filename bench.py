@@ -68,6 +68,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', type=int, default=256, help='volume edge N (N^3 voxels)')
     ap.add_argument('--loss', choices=['gmm', 'ssd'], default='gmm')
+    ap.add_argument('--init', choices=['identity', 'smooth'], default='identity',
+                    help="chain start: identity (MCMC_init 'identity', sub-voxel displacements) or a smooth random velocity "
+                         "field of --init-amp voxels (exercises the large-displacement kernel variants)")
+    ap.add_argument('--init-amp', type=float, default=3.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-size', type=int, default=64)
     ap.add_argument('--cpu-reps', type=int, default=5)
@@ -109,6 +113,13 @@ def main():
     fixed, moving = eng.prepare(fixed, moving)
     eng.gmm_init(fixed, moving)
     v = torch.zeros(1, 3, *dims, device=dev)  # MCMC_init: identity (trainer.py:596-598)
+    if args.init == 'smooth':
+        from ir_sgmcmc_amd.ops import perturb_smooth, sobolev_kernel_1d
+        g = torch.Generator(device='cpu').manual_seed(7)
+        lo = torch.randn(1, 3, N // 8, N // 8, N // 8, generator=g)
+        v = torch.nn.functional.interpolate(lo, size=dims, mode='trilinear', align_corners=True).to(dev).contiguous()
+        v = perturb_smooth(v, sobolev_kernel_1d(3, 0.5)) * (args.init_amp / float(v.abs().max()))
+        v = v.contiguous()
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -153,7 +164,8 @@ def main():
             'config': {'workload': f'{N}^3 synthetic pair, SVF_3D 12 steps, '
                                    + ('GMM(K=4)/LCC(s=1) + virtual decimation' if args.loss == 'gmm' else 'SSD')
                                    + ', RegLoss_L2 w=1.4, Sobolev s=3, uniform noise 0.1, SGLD lr 0.4, Philox noise',
-                       'volume': [N, N, N], 'chains_per_gpu': 1, 'parallelism': f'{world} independent chain(s)'},
+                       'volume': [N, N, N], 'init': args.init + (f' amp {args.init_amp}' if args.init == 'smooth' else ''),
+                       'chains_per_gpu': 1, 'parallelism': f'{world} independent chain(s)'},
             'roofline': {'bound': 'hbm', 'kernel': 'exp_step_bwd_kernel (adjoint of one squaring step)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': None, 'algorithmic_bytes_per_launch': BWD_STEP_BYTES_PER_VOXEL * V,

@@ -620,7 +620,10 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_ker
     const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo) {
     using M = March<PRESCALE, R>;
     constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
-    __shared__ float ring[NP * 9 * PN];  // [slot][field: d0 d1 d2 p0 p1 p2 G0 G1 G2][PN]
+    // ring slot layout (9 floats per source, 8-byte fields so that the gather needs three ds_read_b64 per candidate):
+    //   q_xy = (px, py)   q_zg = (pz, G2)   q_g = (G0, G1)   q_d = (d0, d1)   q_dz = d2
+    __shared__ float2 q_xy[NP * PN], q_zg[NP * PN], q_g[NP * PN], q_d[NP * PN];
+    __shared__ float q_dz[NP * PN];
     const int chain = blockIdx.z / nseg, seg = blockIdx.z % nseg;
     {
         const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
@@ -643,11 +646,11 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_ker
     const int x = ox + lx, y = oy + ly;
     const bool col_in = x < vol.W && y < vol.H;
     const float fx = (float)x, fy = (float)y;
+    const float linx = col_in ? lin.x[x] : 0.0f, liny = col_in ? lin.y[y] : 0.0f;
     const float nxm = (float)(vol.W - 1), nym = (float)(vol.H - 1), nzm = (float)(vol.D - 1);
 
-    // in-plane coordinates of the records this thread stages
-    int sxy[NIT];     // clamped (y * W + x) offset, or -1 when the slot index is past the plane
-    bool sin_[NIT];   // the (x, y) of the record lies inside the volume
+    int sxy[NIT];
+    bool sin_[NIT];
     float slx[NIT], sly[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -677,13 +680,12 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_ker
         }
     };
     auto commit = [&](int s, int slot) {  // registers -> ring slot (with the clipped sampling position)
-        float* rs = ring + slot * 9 * PN;
         const bool zin = s >= 0 && s < vol.D;
         const float lz_ = zin ? lin.z[s] : 0.0f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
-            const int i = threadIdx.x + it * kMarchBlock;
+            const int i = slot * PN + threadIdx.x + it * kMarchBlock;
             float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, p0 = -1.0e9f, p1 = -1.0e9f, p2 = -1.0e9f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
             if (zin) {
                 d0 = PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.inv_pow) : pre[it][0];
@@ -701,21 +703,21 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_ker
                     g2 = pre[it][5];
                 }
             }
-            rs[0 * PN + i] = d0;
-            rs[1 * PN + i] = d1;
-            rs[2 * PN + i] = d2;
-            rs[3 * PN + i] = p0;
-            rs[4 * PN + i] = p1;
-            rs[5 * PN + i] = p2;
-            rs[6 * PN + i] = g0;
-            rs[7 * PN + i] = g1;
-            rs[8 * PN + i] = g2;
+            q_xy[i] = make_float2(p0, p1);
+            q_zg[i] = make_float2(p2, g2);
+            q_g[i] = make_float2(g0, g1);
+            q_d[i] = make_float2(d0, d1);
+            q_dz[i] = d2;
         }
     };
 
-    float acc[NP][3];
+    float2 acc01[NP];  // channels 0, 1 of the NP output planes in flight (packed FMA)
+    float acc2[NP];
 #pragma unroll
-    for (int a = 0; a < NP; ++a) acc[a][0] = acc[a][1] = acc[a][2] = 0.0f;
+    for (int a = 0; a < NP; ++a) {
+        acc01[a] = make_float2(0.0f, 0.0f);
+        acc2[a] = 0.0f;
+    }
 
     const int sbase = z0 - R;            // ring slot of plane s is (s - sbase) % NP
     const int slast = z1 - 1 + R;
@@ -730,38 +732,36 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_ker
             __syncthreads();
             // ---- contributions of source plane s to output planes s-R .. s+R
             if (s >= 0 && s < vol.D && col_in) {
-                const float* rs = ring + PH * 9 * PN;
+                const float fs = (float)s;
 #pragma unroll
                 for (int dy = 0; dy <= 2 * R; ++dy)
 #pragma unroll
                     for (int dx = 0; dx <= 2 * R; ++dx) {
-                        const int ri = (ly + dy) * PX + (lx + dx);
-                        const float px = rs[3 * PN + ri], py = rs[4 * PN + ri], pz = rs[5 * PN + ri];
-                        const float g0 = rs[6 * PN + ri], g1 = rs[7 * PN + ri], g2 = rs[8 * PN + ri];
-                        const float hxy = __saturatef(1.0f - fabsf(px - fx)) * __saturatef(1.0f - fabsf(py - fy));
+                        const int ri = PH * PN + (ly + dy) * PX + (lx + dx);
+                        const float2 pxy = q_xy[ri], pzg = q_zg[ri], g01 = q_g[ri];
+                        const float hxy = __saturatef(1.0f - fabsf(pxy.x - fx)) * __saturatef(1.0f - fabsf(pxy.y - fy));
+                        const float t = pzg.x - fs;  // offset of the sampling position from the source plane
 #pragma unroll
                         for (int oo = -R; oo <= R; ++oo) {
                             const int a = (PH + oo + NP) % NP;  // accumulator of output plane s + oo (static index)
-                            const float w = hxy * __saturatef(1.0f - fabsf(pz - (float)(s + oo)));
-                            acc[a][0] = fmaf(w, g0, acc[a][0]);
-                            acc[a][1] = fmaf(w, g1, acc[a][1]);
-                            acc[a][2] = fmaf(w, g2, acc[a][2]);
+                            const float w = hxy * __saturatef(1.0f - fabsf(t - (float)oo));
+                            acc01[a].x = fmaf(w, g01.x, acc01[a].x);
+                            acc01[a].y = fmaf(w, g01.y, acc01[a].y);
+                            acc2[a] = fmaf(w, pzg.y, acc2[a]);
                         }
                     }
             }
             // ---- output plane zo = s - R is complete
             {
-                constexpr int dummy = 0;
-                (void)dummy;
                 const int zo = s - R;
                 const int a = (PH - R + NP) % NP;
                 if (zo >= z0 && zo < z1 && col_in) {
-                    const int ci = (ly + R) * PX + (lx + R);
-                    const float* rc = ring + a * 9 * PN;  // plane zo sits in slot (zo - sbase) % NP == a
-                    const float d0 = rc[ci], d1 = rc[PN + ci], d2 = rc[2 * PN + ci];
-                    const float G0 = rc[6 * PN + ci], G1 = rc[7 * PN + ci], G2 = rc[8 * PN + ci];
-                    const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
-                    const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
+                    const int ci = a * PN + (ly + R) * PX + (lx + R);  // plane zo sits in slot (zo - sbase) % NP == a
+                    const float2 d01 = q_d[ci], Gc01 = q_g[ci];
+                    const float d2 = q_dz[ci], G2 = q_zg[ci].y;
+                    const float G0 = Gc01.x, G1 = Gc01.y;
+                    const AxisTap tx = axis_tap(__fadd_rn(linx, d01.x), vol.W);
+                    const AxisTap ty = axis_tap(__fadd_rn(liny, d01.y), vol.H);
                     const AxisTap tz = axis_tap(__fadd_rn(lin.z[zo], d2), vol.D);
                     const int bx0 = tx.i0 - (ox - R), bx1 = tx.i1 - (ox - R), by0 = ty.i0 - (oy - R), by1 = ty.i1 - (oy - R);
                     const bool in_ring = bx0 >= 0 && bx1 < PX && by0 >= 0 && by1 < M::PY && tz.i0 >= zo - R && tz.i1 <= zo + R &&
@@ -770,17 +770,18 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_ker
 #pragma unroll
                     for (int cz = 0; cz < 2; ++cz) {
                         const int zz = cz ? tz.i1 : tz.i0;
-                        const float* rt = ring + (((zz - sbase) % NP + NP) % NP) * 9 * PN;
+                        const int sl = (((zz - sbase) % NP + NP) % NP) * PN;
 #pragma unroll
                         for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
                             for (int cx = 0; cx < 2; ++cx) {
                                 float v0, v1, v2;
                                 if (in_ring) {
-                                    const int ti = (cy ? by1 : by0) * PX + (cx ? bx1 : bx0);
-                                    v0 = rt[ti];
-                                    v1 = rt[PN + ti];
-                                    v2 = rt[2 * PN + ti];
+                                    const int ti = sl + (cy ? by1 : by0) * PX + (cx ? bx1 : bx0);
+                                    const float2 v01 = q_d[ti];
+                                    v0 = v01.x;
+                                    v1 = v01.y;
+                                    v2 = q_dz[ti];
                                 } else {  // cannot happen while max|d| < R
                                     const int64_t idx = ((int64_t)zz * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
                                     v0 = ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.inv_pow);
@@ -795,11 +796,12 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_ker
                             }
                     }
                     const int64_t g = ((int64_t)zo * vol.H + y) * vol.W + x;
-                    o[g] = (G0 + tx.gmul * gix) + acc[a][0];
-                    o[g + V] = (G1 + ty.gmul * giy) + acc[a][1];
-                    o[g + 2 * V] = (G2 + tz.gmul * giz) + acc[a][2];
+                    o[g] = (G0 + tx.gmul * gix) + acc01[a].x;
+                    o[g + V] = (G1 + ty.gmul * giy) + acc01[a].y;
+                    o[g + 2 * V] = (G2 + tz.gmul * giz) + acc2[a];
                 }
-                acc[a][0] = acc[a][1] = acc[a][2] = 0.0f;
+                acc01[a] = make_float2(0.0f, 0.0f);
+                acc2[a] = 0.0f;
             }
             __syncthreads();  // the next commit overwrites the oldest ring slot
         }
