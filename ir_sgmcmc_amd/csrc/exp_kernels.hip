@@ -667,16 +667,22 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_ker
     auto prefetch = [&](int s) {
         if (s < 0 || s >= vol.D) return;
         const int64_t zo = (int64_t)s * vol.H * vol.W;
+        const float* __restrict__ p0_ = dx_ + zo;  // uniform plane bases + 32-bit lane offsets
+        const float* __restrict__ p1_ = dy_ + zo;
+        const float* __restrict__ p2_ = dz_ + zo;
+        const float* __restrict__ p3_ = Gx_ + zo;
+        const float* __restrict__ p4_ = Gy_ + zo;
+        const float* __restrict__ p5_ = Gz_ + zo;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
-            const int64_t g = zo + sxy[it];
-            pre[it][0] = dx_[g];
-            pre[it][1] = dy_[g];
-            pre[it][2] = dz_[g];
-            pre[it][3] = Gx_[g];
-            pre[it][4] = Gy_[g];
-            pre[it][5] = Gz_[g];
+            const unsigned g = (unsigned)sxy[it];
+            pre[it][0] = p0_[g];
+            pre[it][1] = p1_[g];
+            pre[it][2] = p2_[g];
+            pre[it][3] = p3_[g];
+            pre[it][4] = p4_[g];
+            pre[it][5] = p5_[g];
         }
     };
     auto commit = [&](int s, int slot) {  // registers -> ring slot (with the clipped sampling position)
@@ -770,7 +776,11 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_ker
 #pragma unroll
                     for (int cz = 0; cz < 2; ++cz) {
                         const int zz = cz ? tz.i1 : tz.i0;
-                        const int sl = (((zz - sbase) % NP + NP) % NP) * PN;
+                        const int rel = zz - zo;  // in [-R, R] whenever in_ring
+                        int sl = a * PN;
+#pragma unroll
+                        for (int q = -R; q <= R; ++q)
+                            if (q != 0) sl = rel == q ? ((a + q + NP) % NP) * PN : sl;
 #pragma unroll
                         for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
@@ -795,10 +805,11 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_ker
                                 giz += (cz ? dot : -dot) * (wx * wy);
                             }
                     }
-                    const int64_t g = ((int64_t)zo * vol.H + y) * vol.W + x;
-                    o[g] = (G0 + tx.gmul * gix) + acc01[a].x;
-                    o[g + V] = (G1 + ty.gmul * giy) + acc01[a].y;
-                    o[g + 2 * V] = (G2 + tz.gmul * giz) + acc2[a];
+                    const int64_t pl = (int64_t)zo * vol.H * vol.W;
+                    const unsigned g = (unsigned)(y * vol.W + x);
+                    (o + pl)[g] = (G0 + tx.gmul * gix) + acc01[a].x;
+                    (o + V + pl)[g] = (G1 + ty.gmul * giy) + acc01[a].y;
+                    (o + 2 * V + pl)[g] = (G2 + tz.gmul * giz) + acc2[a];
                 }
                 acc01[a] = make_float2(0.0f, 0.0f);
                 acc2[a] = 0.0f;
@@ -810,7 +821,8 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_ker
 
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, hipStream_t st) {
-    const int seg_len = 32;
+    static const int seg_env = getenv("IRS_MARCH_SEG") ? atoi(getenv("IRS_MARCH_SEG")) : 32;
+    const int seg_len = seg_env;
     const int nseg = (vol.D + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
     const Scale3L sc = make_scale_l(vol, no_steps);
@@ -838,7 +850,8 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
                                                                     int h_lo, int h_hi) {
     using M = March<PRESCALE, R>;
     constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
-    __shared__ float ring[NP * 3 * PN];
+    __shared__ float2 r_xy[NP * PN];  // (d0, d1): one ds_read_b64 per tap
+    __shared__ float r_z[NP * PN];    // d2
     __shared__ float red[3 * (kMarchBlock / kWave)];
     const int chain = blockIdx.z / nseg, seg = blockIdx.z % nseg;
     if (dmax_in) {
@@ -871,24 +884,26 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
     auto prefetch = [&](int s) {
         const int sc_ = min(max(s, 0), vol.D - 1);  // planes outside the volume replicate the border plane
         const int64_t zo = (int64_t)sc_ * vol.H * vol.W;
+        const float* __restrict__ px_ = dx_ + zo;  // uniform plane bases + 32-bit lane offsets
+        const float* __restrict__ py_ = dy_ + zo;
+        const float* __restrict__ pz_ = dz_ + zo;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
-            const int64_t g = zo + sxy[it];
-            pre[it][0] = dx_[g];
-            pre[it][1] = dy_[g];
-            pre[it][2] = dz_[g];
+            const unsigned g = (unsigned)sxy[it];
+            pre[it][0] = px_[g];
+            pre[it][1] = py_[g];
+            pre[it][2] = pz_[g];
         }
     };
     auto commit = [&](int slot) {
-        float* rs = ring + slot * 3 * PN;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
-            const int i = threadIdx.x + it * kMarchBlock;
-            rs[i] = PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.inv_pow) : pre[it][0];
-            rs[PN + i] = PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.inv_pow) : pre[it][1];
-            rs[2 * PN + i] = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.inv_pow) : pre[it][2];
+            const int i = slot * PN + threadIdx.x + it * kMarchBlock;
+            r_xy[i] = make_float2(PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.inv_pow) : pre[it][0],
+                                  PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.inv_pow) : pre[it][1]);
+            r_z[i] = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.inv_pow) : pre[it][2];
         }
     };
 
@@ -908,9 +923,9 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
                 constexpr int dummy = 0;
                 (void)dummy;
                 const int a = (PH - R + NP) % NP;
-                const int ci = (ly + R) * PX + (lx + R);
-                const float* rc = ring + a * 3 * PN;
-                const float d0 = rc[ci], d1 = rc[PN + ci], d2 = rc[2 * PN + ci];
+                const int ci = a * PN + (ly + R) * PX + (lx + R);
+                const float2 dxy = r_xy[ci];
+                const float d0 = dxy.x, d1 = dxy.y, d2 = r_z[ci];
                 const AxisTap tx = axis_tap(__fadd_rn(linx, d0), vol.W);
                 const AxisTap ty = axis_tap(__fadd_rn(liny, d1), vol.H);
                 const AxisTap tz = axis_tap(__fadd_rn(lin.z[zo], d2), vol.D);
@@ -918,21 +933,29 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
                 const bool in_ring = bx0 >= 0 && bx1 < PX && by0 >= 0 && by1 < M::PY && tz.i0 >= zo - R && tz.i1 <= zo + R;
                 float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
                 if (in_ring) {
+                    // (wx * wy) is shared by the two z corners: same products, same rounding as ((wx * wy) * wz)
+                    const float wxy[2][2] = {{__fmul_rn(tx.w0, ty.w0), __fmul_rn(tx.w1, ty.w0)},
+                                             {__fmul_rn(tx.w0, ty.w1), __fmul_rn(tx.w1, ty.w1)}};
 #pragma unroll
                     for (int cz = 0; cz < 2; ++cz) {
                         const int zz = cz ? tz.i1 : tz.i0;
-                        // plane zz of the volume is ring slot (zz - sbase) mod NP; zz is already clamped to the volume and a
-                        // clamped border plane was staged under the index of the plane it replicates
-                        const float* rt = ring + (((zz - sbase) % NP + NP) % NP) * 3 * PN;
+                        // plane zz of the volume sits in ring slot (a + (zz - zo)) mod NP; with a compile-time `a` the slot
+                        // of each of the 2R+1 candidate planes is a constant, picked by comparing zz - zo
+                        const int rel = zz - zo;
+                        int sl = a * PN;
+#pragma unroll
+                        for (int q = -R; q <= R; ++q)
+                            if (q != 0) sl = rel == q ? ((a + q + NP) % NP) * PN : sl;
 #pragma unroll
                         for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
                             for (int cx = 0; cx < 2; ++cx) {
-                                const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
-                                const int ti = (cy ? by1 : by0) * PX + (cx ? bx1 : bx0);
-                                a0 = __fadd_rn(a0, __fmul_rn(rt[ti], w));
-                                a1 = __fadd_rn(a1, __fmul_rn(rt[PN + ti], w));
-                                a2 = __fadd_rn(a2, __fmul_rn(rt[2 * PN + ti], w));
+                                const float w = __fmul_rn(wxy[cy][cx], cz ? tz.w1 : tz.w0);
+                                const int ti = sl + (cy ? by1 : by0) * PX + (cx ? bx1 : bx0);
+                                const float2 txy = r_xy[ti];
+                                a0 = __fadd_rn(a0, __fmul_rn(txy.x, w));
+                                a1 = __fadd_rn(a1, __fmul_rn(txy.y, w));
+                                a2 = __fadd_rn(a2, __fmul_rn(r_z[ti], w));
                             }
                     }
                 } else {
@@ -949,11 +972,12 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
                                 a2 = __fadd_rn(a2, __fmul_rn(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.inv_pow), w));
                             }
                 }
-                const int64_t g = ((int64_t)zo * vol.H + y) * vol.W + x;
+                const int64_t pl = (int64_t)zo * vol.H * vol.W;
+                const unsigned g = (unsigned)(y * vol.W + x);
                 const float r0 = __fadd_rn(d0, a0), r1 = __fadd_rn(d1, a1), r2 = __fadd_rn(d2, a2);
-                o[g] = r0;
-                o[g + V] = r1;
-                o[g + 2 * V] = r2;
+                (o + pl)[g] = r0;
+                (o + V + pl)[g] = r1;
+                (o + 2 * V + pl)[g] = r2;
                 m0 = fmaxf(m0, fabsf(r0));
                 m1 = fmaxf(m1, fabsf(r1));
                 m2 = fmaxf(m2, fabsf(r2));
@@ -990,7 +1014,8 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
 
 void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
                                const unsigned* dmax_in, unsigned* dmax_out, hipStream_t st) {
-    const int seg_len = 32;
+    static const int seg_env = getenv("IRS_MARCH_SEG_FWD") ? atoi(getenv("IRS_MARCH_SEG_FWD")) : 32;
+    const int seg_len = seg_env;
     const int nseg = (vol.D + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
     const Scale3L sc = make_scale_l(vol, no_steps);
