@@ -30,6 +30,22 @@ BWD_STEP_BYTES_PER_VOXEL = 36.0
 FWD_STEP_BYTES_PER_VOXEL = 24.0
 
 
+def pmc_traffic_bytes(n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
+    WRITE_SIZE runs of this same command at 256^3; profiles/r01_v3_march_256_pmc_traffic.json).  Corrections as the
+    MI355X guide prescribes: counters are KiB; FETCH_SIZE reads exactly 1/2 of the bytes of this kernel's dword-per-lane
+    loads (calibrated in the same run on perturb_kernel, whose read volume is known); WRITE_SIZE is exact.
+    None for sizes that were not profiled."""
+    path = os.path.join(ROOT, 'profiles', 'r01_v3_march_256_pmc_traffic.json')
+    if n != 256 or not os.path.isfile(path):
+        return None
+    t = json.load(open(path))
+    for k, v in t.items():
+        if 'exp_bwd_march_kernel<false, 1>' in k:
+            return (2.0 * v['FETCH_SIZE_KiB_raw'] + v['WRITE_SIZE_KiB_raw']) * 1024.0
+    return None
+
+
 def cpu_baseline(n_small, reps, loss):
     """the CPU oracle (op-for-op the reference's ATen sequence) on a bounded sample, all host cores"""
     import torch
@@ -166,9 +182,9 @@ def main():
                                    + ', RegLoss_L2 w=1.4, Sobolev s=3, uniform noise 0.1, SGLD lr 0.4, Philox noise',
                        'volume': [N, N, N], 'init': args.init + (f' amp {args.init_amp}' if args.init == 'smooth' else ''),
                        'chains_per_gpu': 1, 'parallelism': f'{world} independent chain(s)'},
-            'roofline': {'bound': 'hbm', 'kernel': 'exp_step_bwd_kernel (adjoint of one squaring step)',
+            'roofline': {'bound': 'hbm', 'kernel': 'exp_bwd_march_kernel<false,1> (adjoint of one squaring step)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'algorithmic_bytes_per_launch': BWD_STEP_BYTES_PER_VOXEL * V,
+                         'traffic': pmc_traffic_bytes(N), 'algorithmic_bytes_per_launch': BWD_STEP_BYTES_PER_VOXEL * V,
                          'avg_launch_ms': bwd_kernel_ms},
             'transition_roofline': {'algorithmic_bytes': BYTES_PER_VOXEL[args.loss] * V,
                                     'achieved_GBps': BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9,

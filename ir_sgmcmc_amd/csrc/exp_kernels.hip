@@ -41,7 +41,7 @@ __device__ __forceinline__ void atomic_max_nonneg(unsigned* addr, float v) {
 struct TileGrid {
     int ntx, nty, ntz, total;  // tiles per axis, total over all chains
 };
-constexpr int kExpGridCap = 4096;
+constexpr int kExpGridCap = 1024;  // also bounds the cost of a variant that is launched but not selected
 
 template <int H>
 struct ExpBox {
@@ -607,6 +607,9 @@ void launch_exp_step_bwd_gather(const float* G, const float* dk, float* gout, bo
 // Halo redundancy is (32+2R)(8+2R)/(32*8) in-plane only (1.33x for R=1, vs 1.66x for the 3-D tile).
 // ------------------------------------------------------------------------------------------------
 constexpr int MTX = 32, MTY = 8, kMarchBlock = MTX * MTY;
+#ifndef IRS_MARCH_WAVES
+#define IRS_MARCH_WAVES 3
+#endif
 
 template <bool PRESCALE, int R>
 struct March {
@@ -615,22 +618,25 @@ struct March {
 };
 
 template <bool PRESCALE, int R>
-__global__ __launch_bounds__(kMarchBlock, R == 1 ? 4 : 2) void exp_bwd_march_kernel(
+__global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp_bwd_march_kernel(
     const float* __restrict__ G, const float* __restrict__ dk, float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
-    const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo) {
+    const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int swz_run) {
     using M = March<PRESCALE, R>;
     constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
     // ring slot layout (9 floats per source, 8-byte fields so that the gather needs three ds_read_b64 per candidate):
     //   q_xy = (px, py)   q_zg = (pz, G2)   q_g = (G0, G1)   q_d = (d0, d1)   q_dz = d2
     __shared__ float2 q_xy[NP * PN], q_zg[NP * PN], q_g[NP * PN], q_d[NP * PN];
     __shared__ float q_dz[NP * PN];
-    const int chain = blockIdx.z / nseg, seg = blockIdx.z % nseg;
+    // XCD-aware tile assignment: consecutive tiles (x fastest, then y, then z-segment, then chain) stay on one L2
+    const int tile_ = xcd_swizzle_runs(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z, swz_run);
+    const int tbx = tile_ % gridDim.x, tby = (tile_ / gridDim.x) % gridDim.y, tbz = tile_ / (gridDim.x * gridDim.y);
+    const int chain = tbz / nseg, seg = tbz % nseg;
     {
         const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
                            (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
         if (hs > R || hs <= r_lo) return;
     }
-    const int ox = blockIdx.x * MTX, oy = blockIdx.y * MTY;
+    const int ox = tbx * MTX, oy = tby * MTY;
     const int z0 = seg * seg_len, z1 = min(z0 + seg_len, vol.D);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
@@ -826,7 +832,9 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
     const int nseg = (vol.D + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
     const Scale3L sc = make_scale_l(vol, no_steps);
-#define IRS_BWM(P, RR, LO) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), grid, dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO)
+    static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
+    const int swz_run = swz_env >= 0 ? swz_env : (int)grid.x;  // 0/1: no remap; default: one x-row of tiles per XCD run
+#define IRS_BWM(P, RR, LO) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), grid, dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, swz_run)
     if (prescale_in) {
         IRS_BWM(true, 1, 0);
         if (max_radius >= 2) IRS_BWM(true, 2, 1);
@@ -847,19 +855,21 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
                                                                     Vol vol, Lin lin, Scale3L sc,
                                                                     const unsigned* __restrict__ dmax_in,
                                                                     unsigned* __restrict__ dmax_out, int seg_len, int nseg,
-                                                                    int h_lo, int h_hi) {
+                                                                    int h_lo, int h_hi, int swz_run) {
     using M = March<PRESCALE, R>;
     constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
     __shared__ float2 r_xy[NP * PN];  // (d0, d1): one ds_read_b64 per tap
     __shared__ float r_z[NP * PN];    // d2
     __shared__ float red[3 * (kMarchBlock / kWave)];
-    const int chain = blockIdx.z / nseg, seg = blockIdx.z % nseg;
+    const int tile_ = xcd_swizzle_runs(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z, swz_run);
+    const int tbx = tile_ % gridDim.x, tby = (tile_ / gridDim.x) % gridDim.y, tbz = tile_ / (gridDim.x * gridDim.y);
+    const int chain = tbz / nseg, seg = tbz % nseg;
     if (dmax_in) {
         const int need = max(max((int)ceilf(__uint_as_float(dmax_in[chain * 4 + 0])), (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 1]))),
                              (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 2])));
         if (need <= h_lo || need > h_hi) return;
     }
-    const int ox = blockIdx.x * MTX, oy = blockIdx.y * MTY;
+    const int ox = tbx * MTX, oy = tby * MTY;
     const int z0 = seg * seg_len, z1 = min(z0 + seg_len, vol.D);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
@@ -1019,7 +1029,9 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     const int nseg = (vol.D + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
     const Scale3L sc = make_scale_l(vol, no_steps);
-#define IRS_FWM(P, RR, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), grid, dim3(kMarchBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI)
+    static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
+    const int swz_run = swz_env >= 0 ? swz_env : (int)grid.x;
+#define IRS_FWM(P, RR, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), grid, dim3(kMarchBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run)
     if (prescale_in) { IRS_FWM(true, 1, -1, 1); IRS_FWM(true, 2, 1, 1 << 30); }
     else { IRS_FWM(false, 1, -1, 1); IRS_FWM(false, 2, 1, 1 << 30); }
 #undef IRS_FWM
