@@ -11,15 +11,27 @@ constexpr int kBlock = 256;        // 4 wavefronts
 constexpr int kWave = 64;
 constexpr int kMaxPartialBlocks = 2048;  // cap for per-block partial sums (reduced in fixed order)
 
+// A volume plus the z-window [z0, z0 + nz) of OUTPUT planes a launch covers.  Indexing is always global (arrays are
+// full size, clamping uses D); the window only restricts which planes a kernel writes.  A single GPU uses the full
+// window; the z-slab decomposition (SlabEngine) launches every stage on its own slab (+ the ghost planes it recomputes).
 struct Vol {
     int D, H, W;
     int64_t V;  // D*H*W
+    int z0, nz;
 };
 
-__host__ __device__ inline Vol make_vol(int D, int H, int W) { return Vol{D, H, W, (int64_t)D * H * W}; }
+__host__ __device__ inline Vol make_vol(int D, int H, int W) { return Vol{D, H, W, (int64_t)D * H * W, 0, D}; }
+
+__host__ __device__ inline Vol window(Vol v, int zlo, int zhi) {
+    zlo = zlo < 0 ? 0 : zlo;
+    zhi = zhi > v.D ? v.D : zhi;
+    v.z0 = zlo;
+    v.nz = zhi > zlo ? zhi - zlo : 0;
+    return v;
+}
 
 inline dim3 vox_grid(const Vol& vol, int planes) {
-    return dim3((unsigned)((vol.W + 63) / 64), (unsigned)((vol.H + 3) / 4), (unsigned)(vol.D * planes));
+    return dim3((unsigned)((vol.W + 63) / 64), (unsigned)((vol.H + 3) / 4), (unsigned)(vol.nz * planes));
 }
 
 // Division-free voxel mapping for the pointwise kernels: 256-thread blocks laid out 64 (x) x 4 (y),
@@ -28,17 +40,17 @@ inline dim3 vox_grid(const Vol& vol, int planes) {
 #define IRS_VOXEL(vol, PLANE, X, Y, Z, VOX)                                   \
     const int X = blockIdx.x * 64 + (threadIdx.x & 63);                        \
     const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);                         \
-    const int PLANE = blockIdx.z / (vol).D;                                    \
-    const int Z = blockIdx.z - PLANE * (vol).D;                                \
+    const int PLANE = blockIdx.z / (vol).nz;                                   \
+    const int Z = (vol).z0 + blockIdx.z - PLANE * (vol).nz;                    \
     if (X >= (vol).W || Y >= (vol).H) return;                                  \
     const int64_t VOX = ((int64_t)Z * (vol).H + Y) * (vol).W + X
 
 // Grid-stride loop over the rows of a volume for the reduction kernels: each wavefront of a 256-thread block walks
 // rows (y, z) and its lanes stride along x, so the only division is one 32-bit one per row.
 #define IRS_ROWS_BEGIN(vol, X, Y, Z, VOX)                                                                             \
-    for (int row_ = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); row_ < (vol).H * (vol).D;                     \
+    for (int row_ = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); row_ < (vol).H * (vol).nz;                    \
          row_ += gridDim.x * (kBlock / kWave)) {                                                                       \
-        const int Z = row_ / (vol).H, Y = row_ - Z * (vol).H;                                                          \
+        const int zr_ = row_ / (vol).H, Y = row_ - zr_ * (vol).H, Z = (vol).z0 + zr_;                                  \
         for (int X = threadIdx.x & 63; X < (vol).W; X += kWave) {                                                      \
             const int64_t VOX = ((int64_t)Z * (vol).H + Y) * (vol).W + X;
 #define IRS_ROWS_END \

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(kLdsBlock) void sobolev_fused_kernel(const float* _
     __shared__ float bufB[AX * AY * STZ];
     __shared__ float red[kLdsBlock / kWave];
     const int plane = blockIdx.z / tiles_z;
-    const int ox = blockIdx.x * STX, oy = blockIdx.y * STY, oz = (blockIdx.z % tiles_z) * STZ;
+    const int ox = blockIdx.x * STX, oy = blockIdx.y * STY, oz = vol.z0 + (blockIdx.z % tiles_z) * STZ;
+    const int zend = vol.z0 + vol.nz;
     const float* src = in + (int64_t)plane * vol.V;
     const Box RA{ox - S, oy - S, oz - S, AX, AY, AZ};
     for (int i = threadIdx.x; i < AX * AY * AZ; i += kLdsBlock) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kLdsBlock) void sobolev_fused_kernel(const float* _
     for (int i = threadIdx.x; i < STX * STY * STZ; i += kLdsBlock) {
         const int lx = i % STX, ly = (i / STX) % STY, lz = i / (STX * STY);
         const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
-        if (gx >= vol.W || gy >= vol.H || gz >= vol.D) continue;
+        if (gx >= vol.W || gy >= vol.H || gz >= zend) continue;
         float acc = 0.0f;
         const int row = (lz * Bzy.ey + ly) * Bzy.ex;
         for (int t = 0; t <= 2 * S; ++t) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kLdsBlock) void sobolev_fused_kernel(const float* _
 
 void launch_sobolev_fused(const float* in, float* out, const Taps& taps, int planes, Vol vol, unsigned* dmax0, int no_steps,
                           hipStream_t st) {
-    const int tz = (vol.D + STZ - 1) / STZ;
+    const int tz = (vol.nz + STZ - 1) / STZ;
     const dim3 grid((vol.W + STX - 1) / STX, (vol.H + STY - 1) / STY, (unsigned)(tz * planes));
     const float inv_pow = 1.0f / (float)(1 << no_steps);
 #define IRS_SOB(SS) hipLaunchKernelGGL((sobolev_fused_kernel<SS>), grid, dim3(kLdsBlock), 0, st, in, out, taps, vol, dmax0, inv_pow, tz)
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(kLdsBlock) void lcc_fwd_kernel(const float* __restr
     float* bufQ = bufP + Z::P1;
 
     const int chain = blockIdx.z / tiles_z;
-    const int ox = blockIdx.x * TX, oy = blockIdx.y * TY, oz = (blockIdx.z % tiles_z) * TZ;
+    const int ox = blockIdx.x * TX, oy = blockIdx.y * TY, oz = vol.z0 + (blockIdx.z % tiles_z) * TZ;
+    const int zend = vol.z0 + vol.nz;
     const float* src = im + (int64_t)chain * vol.V;
     const Box R2{ox - 2 * S, oy - 2 * S, oz - 2 * S, TX + 4 * S, TY + 4 * S, TZ + 4 * S};
     const float inv_n_dummy = 0.0f;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(kLdsBlock) void lcc_fwd_kernel(const float* __restr
     for (int i = threadIdx.x; i < TX * TY * TZ; i += kLdsBlock) {
         const int lx = i % TX, ly = (i / TX) % TY, lz = i / (TX * TY);
         const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
-        if (gx >= vol.W || gy >= vol.H || gz >= vol.D) continue;
+        if (gx >= vol.W || gy >= vol.H || gz >= zend) continue;
         float acc = 0.0f;
         for (int o = -S; o <= S; ++o) {
             const int q = min(max(gz + o, 0), vol.D - 1);
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(kLdsBlock) void lcc_fwd_kernel(const float* __restr
 }
 
 static dim3 tile_grid(Vol vol, int C, int* tiles_z) {
-    *tiles_z = (vol.D + TZ - 1) / TZ;
+    *tiles_z = (vol.nz + TZ - 1) / TZ;
     return dim3((vol.W + TX - 1) / TX, (vol.H + TY - 1) / TY, (unsigned)(*tiles_z * C));
 }
 
@@ -286,7 +288,8 @@ __global__ __launch_bounds__(kLdsBlock) void lcc_data_bwd_kernel(const float* __
     float* bufW = bufQ + Z::P2;   // g_w / sigma over R1
     float* bufA = bufW + Z::R1;   // 2 a / n over R1
 
-    const int ox = blockIdx.x * TX, oy = blockIdx.y * TY, oz = blockIdx.z * TZ;
+    const int ox = blockIdx.x * TX, oy = blockIdx.y * TY, oz = vol.z0 + blockIdx.z * TZ;
+    const int zend = vol.z0 + vol.nz;
     const Box R2{ox - 2 * S, oy - 2 * S, oz - 2 * S, TX + 4 * S, TY + 4 * S, TZ + 4 * S};
     const Box Bx = shrink(R2, 0, S), Bxy = shrink(Bx, 1, S), R1 = shrink(Bxy, 2, S);
     const float n = (float)((2 * S + 1) * (2 * S + 1) * (2 * S + 1));
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(kLdsBlock) void lcc_data_bwd_kernel(const float* __
                 if (mask[g]) {
                     const MixEval e = mix_eval<false>(zz, state, nullptr, nullptr);
                     gzv = alpha * e.gz;
-                    if (lx >= 2 * S && lx < 2 * S + TX && ly >= 2 * S && ly < 2 * S + TY && lz >= 2 * S && lz < 2 * S + TZ)
+                    if (lx >= 2 * S && lx < 2 * S + TX && ly >= 2 * S && ly < 2 * S + TY && lz >= 2 * S && lz < 2 * S + TZ && gz < zend)
                         nll += (double)e.nll;
                 }
             }
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(kLdsBlock) void lcc_data_bwd_kernel(const float* __
     for (int i = threadIdx.x; i < TX * TY * TZ; i += kLdsBlock) {
         const int lx = i % TX, ly = (i / TX) % TY, lz = i / (TX * TY);
         const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
-        if (gx >= vol.W || gy >= vol.H || gz >= vol.D) continue;
+        if (gx >= vol.W || gy >= vol.H || gz >= zend) continue;
         float acc = 0.0f;
         const int col = ly * Cxy.ex + lx;
         for (int o = -S; o <= S; ++o) {
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(const float* __restrict
 
 int data_bwd_blocks(int mode, Vol vol) {
     if (mode == IRS_DATA_SSD) return stats_blocks(vol);
-    return ((vol.W + TX - 1) / TX) * ((vol.H + TY - 1) / TY) * ((vol.D + TZ - 1) / TZ);
+    return ((vol.W + TX - 1) / TX) * ((vol.H + TY - 1) / TY) * ((vol.nz + TZ - 1) / TZ);
 }
 
 void launch_data_bwd(int mode, const float* fhat_or_fixed, int64_t f_stride, const float* z, const float* sigma_m,
@@ -635,7 +638,7 @@ void launch_gradient_operator(const float* v, float* nabla, int transformation, 
 __global__ __launch_bounds__(kBlock) void log_det_kernel(const float* __restrict__ t, float* __restrict__ log_det,
                                                          long long* __restrict__ nan_count, Vol vol) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int chain = blockIdx.z / vol.D, z = blockIdx.z - chain * vol.D;
+    const int chain = blockIdx.z / vol.nz, z = vol.z0 + blockIdx.z - chain * vol.nz;
     int bad = 0;
     if (x < vol.W && y < vol.H) {
         const int64_t p = ((int64_t)z * vol.H + y) * vol.W + x;

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_fwd_lds_kernel(const float* __r
     t_ /= tg.ntx;
     const int oy = (t_ % tg.nty) * ETY;
     t_ /= tg.nty;
-    const int oz = (t_ % tg.ntz) * ETZ;
+    const int oz = vol.z0 + (t_ % tg.ntz) * ETZ;
     const int chain = t_ / tg.ntz;
     if (dmax_in) {  // variant selection: this halo serves ceil(max|d_k|) in (h_lo, h_hi]
         const int need = max(max((int)ceilf(__uint_as_float(dmax_in[chain * 4 + 0])), (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 1]))),
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_fwd_lds_kernel(const float* __r
     for (int i = threadIdx.x; i < ETN; i += kExpBlock) {
         const int lx = i % ETX, ly = (i / ETX) % ETY, lz = i / (ETX * ETY);
         const int x = ox + lx, y = oy + ly, z = oz + lz;
-        if (x >= vol.W || y >= vol.H || z >= vol.D) continue;
+        if (x >= vol.W || y >= vol.H || z >= vol.z0 + vol.nz) continue;
         const int ctr = ((lz + H) * B::SY + (ly + H)) * B::SX + (lx + H);
         const float d0 = lds[ctr], d1 = lds[B::SN + ctr], d2 = lds[2 * B::SN + ctr];
         const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
@@ -198,7 +198,7 @@ static Scale3L make_scale_l(Vol vol, int no_steps) {
 static dim3 exp_grid(Vol vol, int C, TileGrid* tg) {
     tg->ntx = (vol.W + ETX - 1) / ETX;
     tg->nty = (vol.H + ETY - 1) / ETY;
-    tg->ntz = (vol.D + ETZ - 1) / ETZ;
+    tg->ntz = (vol.nz + ETZ - 1) / ETZ;
     tg->total = tg->ntx * tg->nty * tg->ntz * C;
     return dim3((unsigned)(tg->total < kExpGridCap ? tg->total : kExpGridCap));
 }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
     t_ /= tg.ntx;
     const int oy = (t_ % tg.nty) * ETY;
     t_ /= tg.nty;
-    const int oz = (t_ % tg.ntz) * ETZ;
+    const int oz = vol.z0 + (t_ % tg.ntz) * ETZ;
     const int chain = t_ / tg.ntz;
     {   // the gather kernel owns this launch when every source halo fits its radius
         const int h0 = (int)floorf(__uint_as_float(dmax[chain * 4 + 0])) + 1, h1 = (int)floorf(__uint_as_float(dmax[chain * 4 + 1])) + 1,
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
     for (int i = threadIdx.x; i < ETN; i += kExpBlock) {
         const int lx = i % ETX, ly = (i / ETX) % ETY, lz = i / (ETX * ETY);
         const int x = ox + lx, y = oy + ly, z = oz + lz;
-        if (x >= vol.W || y >= vol.H || z >= vol.D) continue;
+        if (x >= vol.W || y >= vol.H || z >= vol.z0 + vol.nz) continue;
         const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
         o[g] = acc[i];
         o[g + V] = acc[ETN + i];
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_gather_kernel(const float* 
     t_ /= tg.ntx;
     const int oy = (t_ % tg.nty) * ETY;
     t_ /= tg.nty;
-    const int oz = (t_ % tg.ntz) * ETZ;
+    const int oz = vol.z0 + (t_ % tg.ntz) * ETZ;
     const int chain = t_ / tg.ntz;
     {   // this variant owns the launch iff the needed source halo hs = floor(max|d|) + 1 satisfies R_lo < hs <= R
         const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_gather_kernel(const float* 
         __builtin_amdgcn_sched_barrier(0);
         own[j][0] = own[j][1] = own[j][2] = 0.0f;
         const int z = oz + lz0 + j;
-        if (!col_in || z >= vol.D) continue;
+        if (!col_in || z >= vol.z0 + vol.nz) continue;
         const float* rc = rec + 6 * (((lz0 + j + R) * B::SY + (ly + R)) * B::SX + (lx + R));
         const float d0 = rc[0], d1 = rc[1], d2 = rc[2], G0 = rc[3], G1 = rc[4], G2 = rc[5];
         const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_gather_kernel(const float* 
 #pragma unroll
     for (int j = 0; j < kColZ; ++j) {
         const int z = oz + lz0 + j;
-        if (!col_in || z >= vol.D) continue;
+        if (!col_in || z >= vol.z0 + vol.nz) continue;
         const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
         o[g] = own[j][0] + acc[j][0];
         o[g + V] = own[j][1] + acc[j][1];
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
         if (hs > R || hs <= r_lo) return;
     }
     const int ox = tbx * MTX, oy = tby * MTY;
-    const int z0 = seg * seg_len, z1 = min(z0 + seg_len, vol.D);
+    const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
     const float* __restrict__ dx_ = dk + cb;
@@ -829,7 +829,7 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
                                Lin lin, const unsigned* dmax, int max_radius, hipStream_t st) {
     static const int seg_env = getenv("IRS_MARCH_SEG") ? atoi(getenv("IRS_MARCH_SEG")) : 32;
     const int seg_len = seg_env;
-    const int nseg = (vol.D + seg_len - 1) / seg_len;
+    const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
     const Scale3L sc = make_scale_l(vol, no_steps);
     static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
         if (need <= h_lo || need > h_hi) return;
     }
     const int ox = tbx * MTX, oy = tby * MTY;
-    const int z0 = seg * seg_len, z1 = min(z0 + seg_len, vol.D);
+    const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
     const float* __restrict__ dx_ = din + cb;
@@ -1026,7 +1026,7 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
                                const unsigned* dmax_in, unsigned* dmax_out, hipStream_t st) {
     static const int seg_env = getenv("IRS_MARCH_SEG_FWD") ? atoi(getenv("IRS_MARCH_SEG_FWD")) : 32;
     const int seg_len = seg_env;
-    const int nseg = (vol.D + seg_len - 1) / seg_len;
+    const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
     const Scale3L sc = make_scale_l(vol, no_steps);
     static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(kBlock) void field_absmax_kernel(const float* __res
 }
 
 void launch_field_absmax(const float* d, bool prescale_in, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st) {
-    const int rows = vol.H * vol.D;
+    const int rows = vol.H * vol.nz;
     dim3 grid((unsigned)(rows / 4 < 2048 ? (rows + 3) / 4 : 2048), C);
     const Scale3L sc = make_scale_l(vol, no_steps);
     if (prescale_in) hipLaunchKernelGGL(field_absmax_kernel<true>, grid, dim3(kBlock), 0, st, d, dmax, vol, sc);
