@@ -88,6 +88,9 @@ def main():
                     help="chain start: identity (MCMC_init 'identity', sub-voxel displacements) or a smooth random velocity "
                          "field of --init-amp voxels (exercises the large-displacement kernel variants)")
     ap.add_argument('--init-amp', type=float, default=3.0)
+    ap.add_argument('--decomp', choices=['chains', 'slab'], default='chains',
+                    help='N > 1: independent chains per rank (weak scaling, default) or ONE chain split into z-slabs with '
+                         'ghost-plane exchange (strong scaling, ir_sgmcmc_amd/slab.py)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-size', type=int, default=64)
     ap.add_argument('--cpu-reps', type=int, default=5)
@@ -122,7 +125,13 @@ def main():
     V = N ** 3
     cfg = EngineConfig(dims=dims, no_chains=1, data_loss='GMM' if args.loss == 'gmm' else 'SSD',
                        virtual_decimation=(args.loss == 'gmm'), reg_loss='RegLoss_L2', w_reg=1.4, seed=1234 + rank)
-    eng = TransitionEngine(cfg, dev)
+    slab = args.decomp == 'slab' and world > 1
+    if slab:
+        from ir_sgmcmc_amd.slab import SlabEngine
+        cfg.seed = 1234  # one chain: every rank must draw the same Philox noise
+        eng = SlabEngine(cfg, dev)
+    else:
+        eng = TransitionEngine(cfg, dev)
     f1, m1 = synthetic_pair(dims, seed=0)
     fixed = {k: v.unsqueeze(0).to(dev) for k, v in f1.items() if k != 'seg'}
     moving = {k: v.unsqueeze(0).to(dev) for k, v in m1.items() if k != 'seg'}
@@ -160,8 +169,14 @@ def main():
     # per-stage HIP-event timings (outside the timed region), averaged over a few transitions
     reps = max(3, min(10, args.steps))
     acc = None
+    timing_eng = eng
+    if slab:  # per-stage events come from the fused path: time them on a plain engine (same kernels, full window)
+        timing_eng = TransitionEngine(cfg, dev)
+        timing_eng.prepare(fixed, moving)
+        timing_eng.gmm_init(fixed, moving)
+        v = torch.zeros(1, 3, *dims, device=dev)
     for _ in range(reps):
-        tm = eng.transition(fixed, moving, v, timed=True)
+        tm = timing_eng.transition(fixed, moving, v, timed=True)
         acc = tm if acc is None else {k: acc[k] + tm[k] for k in tm}
     tm = {k: x / reps for k, x in acc.items()}
     steps = cfg.no_steps
@@ -170,18 +185,19 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * args.steps / elapsed
+        value = (1 if slab else world) * args.steps / elapsed
         achieved = BWD_STEP_BYTES_PER_VOXEL * V / (bwd_kernel_ms * 1e-3) / 1e9
         out = {
             'metric': 'SG-MCMC transitions/sec (full _SGLD_transition, 1 chain per GPU)', 'value': value,
             'unit': 'transitions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if slab else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{N}^3 synthetic pair, SVF_3D 12 steps, '
                                    + ('GMM(K=4)/LCC(s=1) + virtual decimation' if args.loss == 'gmm' else 'SSD')
                                    + ', RegLoss_L2 w=1.4, Sobolev s=3, uniform noise 0.1, SGLD lr 0.4, Philox noise',
                        'volume': [N, N, N], 'init': args.init + (f' amp {args.init_amp}' if args.init == 'smooth' else ''),
-                       'chains_per_gpu': 1, 'parallelism': f'{world} independent chain(s)'},
+                       'chains_per_gpu': 1,
+                       'parallelism': (f'1 chain in {world} z-slabs, ghost-plane exchange' if slab else f'{world} independent chain(s)')},
             'roofline': {'bound': 'hbm', 'kernel': 'exp_bwd_march_kernel<false,1> (adjoint of one squaring step)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic_bytes(N), 'algorithmic_bytes_per_launch': BWD_STEP_BYTES_PER_VOXEL * V,

@@ -555,6 +555,19 @@ __global__ __launch_bounds__(kBlock) void reduce_rows_kernel(const double* __res
     if (threadIdx.x == 0) out[blockIdx.x] = acc[0];
 }
 
+__global__ __launch_bounds__(kBlock) void reduce_cols_kernel(const double* __restrict__ partials, int nblocks, int ncols,
+                                                             double* __restrict__ out) {
+    __shared__ double smem[kBlock / kWave];
+    double acc[1] = {0.0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) acc[0] += partials[(int64_t)b * ncols + blockIdx.x];
+    block_sum<1>(acc, smem);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc[0];
+}
+
+void launch_reduce_cols(const double* partials, int nblocks, int ncols, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(ncols), dim3(kBlock), 0, st, partials, nblocks, ncols, out);
+}
+
 void launch_reduce_partials(const double* partials, int nblocks, int nvals, double* out, hipStream_t st) {
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(nvals), dim3(kBlock), 0, st, partials, nblocks, out);
 }

@@ -83,6 +83,8 @@ int data_bwd_blocks(int mode, Vol vol);
 void launch_masked_moments(const float* z, const uint8_t* mask, double* partials, Vol vol, hipStream_t st);
 void launch_reg_energy(const float* v, double* partials, int C, Vol vol, hipStream_t st);
 void launch_reduce_partials(const double* partials, int nblocks, int nvals, double* out, hipStream_t st);
+// out[j] = sum_b partials[b * ncols + j]
+void launch_reduce_cols(const double* partials, int nblocks, int ncols, double* out, hipStream_t st);
 void launch_sgld_update(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
                         float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st);
 void launch_gradient_operator(const float* v, float* nabla, int transformation, int C, Vol vol, hipStream_t st);
