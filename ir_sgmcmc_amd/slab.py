@@ -151,17 +151,7 @@ class SlabEngine(TransitionEngine):
         self._allreduce(self.energy_sum, dist.ReduceOp.SUM)
         self._stage(io, ST_REG_SCALAR)
 
-        halo = [0] * n  # ghost planes of d_k each rank holds (also what the adjoint of step k needs)
-        for k in range(n):
-            h = int(math.floor(self._bound_z(k))) + 1  # taps and gather sources of a voxel lie within floor(max|d|) + 1 planes
-            halo[k] = h
-            if k == 0:
-                if h > 1:
-                    raise L.IrsError('|d_0| >= 1 voxel: velocity field too large for 12 squaring steps')
-            else:
-                self._halo(self.steps[k - 1], h)
-            self._stage(io, ST_EXP_FWD, k)
-            self._allreduce(self.dmax[k + 1], dist.ReduceOp.MAX)
+        halo = self._forward_steps(io, n)
         self._stage(io, ST_OUTPUTS)
         self._stage(io, ST_WARP)
         if gmm:
@@ -185,6 +175,45 @@ class SlabEngine(TransitionEngine):
         self._stage(io, ST_UPDATE)
         self._stage(io, ST_FINALIZE)
         return None
+
+    def _forward_steps(self, io, n):
+        """the n squaring steps with ghost-plane exchange; returns the ghost width held for every d_k.
+
+        First transition (or after a misprediction): exact mode -- the bound of d_k is MAX-all-reduced and read back
+        before step k (one host sync per step).  Afterwards: predicted mode -- widths come from the previous transition's
+        bounds plus one spare plane, nothing is read back during the loop; the bounds of all steps are all-reduced in ONE
+        operation afterwards (the adjoint's variant selection needs the global bound anyway) and checked; a misprediction
+        re-runs the loop in exact mode."""
+        dmax_all = self._view(BUF_DMAX, 0, (n + 1, self.cfg.no_chains, 4), '<f4')
+        pred = getattr(self, '_halo_pred', None)
+        if pred is not None and self.world > 1:
+            used = [1] + [min(p + 1, self.min_slab) for p in pred[1:]]
+            for k in range(n):
+                if k > 0:
+                    self._halo(self.steps[k - 1], used[k])
+                self._stage(io, ST_EXP_FWD, k)
+            self._allreduce(dmax_all, dist.ReduceOp.MAX)
+            need = [int(math.floor(x)) + 1 for x in dmax_all[:n, :, 2].max(dim=1).values.tolist()]
+            if all(nd <= u for nd, u in zip(need, used)):
+                self._halo_pred = need
+                self.mispredictions = getattr(self, 'mispredictions', 0)
+                return used
+            self.mispredictions = getattr(self, 'mispredictions', 0) + 1
+            # fall through: redo with exact widths (the bounds of steps 1.. must be rebuilt from a clean slate)
+            dmax_all[1:].zero_()
+        halo = [0] * n
+        for k in range(n):
+            h = int(math.floor(self._bound_z(k))) + 1  # taps and gather sources of a voxel lie within floor(max|d|) + 1 planes
+            halo[k] = h
+            if k == 0:
+                if h > 1:
+                    raise L.IrsError('|d_0| >= 1 voxel: velocity field too large for 12 squaring steps')
+            else:
+                self._halo(self.steps[k - 1], h)
+            self._stage(io, ST_EXP_FWD, k)
+            self._allreduce(self.dmax[k + 1], dist.ReduceOp.MAX)
+        self._halo_pred = halo
+        return halo
 
     def _own(self, key, shape):
         t = self._keep.get(('own', key))

@@ -77,6 +77,7 @@ def _worker(rank, world, port, q, data_loss, C, N):
         cfg, fixed, moving, v0, noise = _setup(N, C, data_loss)
         eng, v, d, s = _run(SlabEngine, cfg, fixed, moving, v0, noise)
         assert (eng.a, eng.b) == ((rank * N) // world, ((rank + 1) * N) // world) and eng.exchanged_planes > 0
+        assert getattr(eng, "mispredictions", 0) == 0  # second transition ran in predicted-width mode
         v_full = eng.gather_slabs(v)
         d_full = eng.gather_slabs(d)
         if rank == 0:
