@@ -62,15 +62,6 @@ int env_int(const char* name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 
-// LDS halo of the staged displacement box per squaring step: |d_k| ~ |d_n| / 2^(n-k), so all but the last few steps
-// move less than a voxel and a 1-voxel halo keeps every tap in LDS; the last steps get 2.  Taps that still fall
-// outside are fetched from global memory, so this is a speed knob only.  IRS_EXP_HALO=1|2 overrides it.
-int exp_halo(int k, int no_steps) {
-    const int forced = env_int("IRS_EXP_HALO", 0);
-    if (forced) return forced;
-    return k >= no_steps - 3 ? 2 : 1;
-}
-
 bool use_lds_exp() { return env_int("IRS_EXP_LDS", 1) != 0; }
 
 int control_points(int n, int cps) { return (int)ceil((double)(n - 1) / (double)cps) + 1 + 2; }  // utils/util.py:61-69
@@ -162,8 +153,7 @@ int irs_svf_exp_fwd(const float* v, float* steps, float* transformation, float* 
     const int64_t field = (int64_t)C * 3 * vol.V;
     for (int k = 0; k < no_steps; ++k) {
         const float* in = k == 0 ? v : steps + (int64_t)(k - 1) * field;
-        if (use_lds_exp()) launch_exp_step_fwd_lds(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, nullptr, nullptr,
-                                                   exp_halo(k, no_steps), st);
+        if (use_lds_exp()) launch_exp_step_fwd_march(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, nullptr, nullptr, st);
         else launch_exp_step_fwd(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, st);
     }
     if (transformation || displacement)
@@ -189,8 +179,7 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
         if (lds) {
             launch_field_absmax(dk, k == 0, no_steps, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, C, vol, st);
             const int rad = env_int("IRS_EXP_GATHER", 2);
-            if (rad && env_int("IRS_EXP_MARCH", 1)) launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, st);
-            else if (rad) launch_exp_step_bwd_gather(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, st);
+            if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, st);
             launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, rad, st);
         } else {
             HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
@@ -641,11 +630,9 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     for (int k = 0; k < cfg.no_steps; ++k) {
         const float* in = k == 0 ? dense : c->steps + (int64_t)(k - 1) * field;
         float* out = c->steps + (int64_t)k * field;
-        if (lds && env_int("IRS_EXP_MARCH", 1))
+        if (lds)
             launch_exp_step_fwd_march(in, out, k == 0, cfg.no_steps, C, c->vol, lin, c->dmax + (int64_t)k * c->C * 4,
                                       c->dmax + (int64_t)(k + 1) * c->C * 4, st);
-        else if (lds) launch_exp_step_fwd_lds(in, out, k == 0, cfg.no_steps, C, c->vol, lin, c->dmax + (int64_t)k * c->C * 4,
-                                              c->dmax + (int64_t)(k + 1) * c->C * 4, 0, st);
         else launch_exp_step_fwd(in, out, k == 0, cfg.no_steps, C, c->vol, lin, st);
     }
     if (timed) HIP_TRY(hipEventRecord(c->ev[2], st));
@@ -737,8 +724,7 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
             if (lds) {
                 const unsigned* dm = c->dmax + (int64_t)k * C * 4;
                 const int rad = env_int("IRS_EXP_GATHER", 2);  // largest gather radius to launch (0: scatter only)
-                if (rad && env_int("IRS_EXP_MARCH", 1)) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, st);
-                else if (rad) launch_exp_step_bwd_gather(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, st);
+                if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, st);
                 launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, st);
             }
             else launch_exp_step_bwd(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, st);

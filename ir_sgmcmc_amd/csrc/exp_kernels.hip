@@ -1,17 +1,18 @@
-// LDS-tiled scaling-and-squaring step and its adjoint for gfx950 (the dominant kernels: 720 of the 878 algorithmic
-// bytes per voxel of a transition).  Reference semantics: utils/transformation.py:70-73 and autograd through it.
+// Scaling-and-squaring step and its adjoint for gfx950 -- the dominant kernels of a transition (720 of its 878
+// algorithmic bytes per voxel).  Reference semantics: utils/transformation.py:70-73 and autograd through it.
 //
-// Forward  d_out = d + sample(d, id + d):  a 32x8x8 output tile per 512-thread workgroup; d (3 channels) over the tile
-//   plus a halo of HF voxels is staged in LDS with coalesced row loads, the 8 trilinear taps come from LDS whenever the
-//   sampling position stays inside the staged box and from global memory otherwise (any displacement is handled;
-//   only speed depends on the halo).  As a by-product the per-chain max |d| (voxels, per axis) is reduced with one
-//   atomicMax per wavefront -- the adjoint needs it to size its source region.
+// Both directions use a z-MARCHING schedule: a 256-thread workgroup owns a 32x8 column of output voxels over a segment of
+// 32 planes, keeps a ring of the last 2R+1 source planes in LDS, has the next plane's global loads in flight while it
+// works on the current one, and is placed so that x-adjacent tiles (which share halo cache lines) sit on one XCD.
 //
-// Adjoint  g = G + (grid-gradient) + (trilinear scatter of G):  "owner computes".  Each workgroup owns the OUTPUT tile
-//   and keeps its three accumulator planes in LDS; it walks every source voxel that can reach the tile (tile +/-
-//   (ceil(max|d|) + 1), known from the forward pass), recomputes that voxel's trilinear weights and adds the corner
-//   contributions that land inside the tile with LDS atomics (ds_add_f32).  No global atomics, no zero-fill of the
-//   output, plain coalesced stores; results are deterministic up to the order of LDS adds.
+//   forward   d_out = d + sample(d, id + d): taps from the ring (global memory only if a tap leaves it: any displacement
+//             is handled, the ring radius R in {1, 2} is a speed knob picked on the device from the published bound
+//             max|d_k|); publishes max|d_{k+1}| per chain with one guarded atomicMax per workgroup.
+//   adjoint   g = G + grid-gradient + trilinear scatter of G, computed as an owner-computes GATHER: every output voxel
+//             sums G(x) * prod_a hat(p_a(x) - y_a) over its (2R+1)^3 candidate sources.  No atomics (LDS float atomics
+//             retire one lane per clock on gfx950, global ones cost 7.5 ms per step at 256^3), fixed summation order,
+//             plain coalesced stores, no zero-fill.  For max|d_k| >= 2 voxels the LDS-atomic scatter kernel takes over
+//             (correct for any displacement).  Which kernel does the work of a step is decided on the device.
 #include "kernels.h"
 
 namespace irs {
@@ -64,128 +65,6 @@ __device__ __forceinline__ void stage_field(const float* __restrict__ c0, float*
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// forward step
-// ------------------------------------------------------------------------------------------------
-template <bool PRESCALE, int H>
-__global__ __launch_bounds__(kExpBlock) void exp_fwd_lds_kernel(const float* __restrict__ din, float* __restrict__ dout,
-                                                                Vol vol, Lin lin, Scale3L sc,
-                                                                const unsigned* __restrict__ dmax_in,
-                                                                unsigned* __restrict__ dmax_out, TileGrid tg, int h_lo,
-                                                                int h_hi) {
-    using B = ExpBox<H>;
-    __shared__ float lds[3 * B::SN];
-    __shared__ float red[3 * (kExpBlock / kWave)];
-  for (int tile = blockIdx.x; tile < tg.total; tile += gridDim.x) {
-    int t_ = tile;
-    const int ox = (t_ % tg.ntx) * ETX;
-    t_ /= tg.ntx;
-    const int oy = (t_ % tg.nty) * ETY;
-    t_ /= tg.nty;
-    const int oz = vol.z0 + (t_ % tg.ntz) * ETZ;
-    const int chain = t_ / tg.ntz;
-    if (dmax_in) {  // variant selection: this halo serves ceil(max|d_k|) in (h_lo, h_hi]
-        const int need = max(max((int)ceilf(__uint_as_float(dmax_in[chain * 4 + 0])), (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 1]))),
-                             (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 2])));
-        if (need <= h_lo || need > h_hi) continue;
-    }
-    const int64_t V = vol.V;
-    const float* c0 = din + (int64_t)chain * 3 * V;
-    const float* c1 = c0 + V;
-    const float* c2 = c1 + V;
-    float* o = dout + (int64_t)chain * 3 * V;
-
-    stage_field<PRESCALE, H>(c0, lds, ox, oy, oz, vol, sc);
-    __syncthreads();
-
-    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
-    for (int i = threadIdx.x; i < ETN; i += kExpBlock) {
-        const int lx = i % ETX, ly = (i / ETX) % ETY, lz = i / (ETX * ETY);
-        const int x = ox + lx, y = oy + ly, z = oz + lz;
-        if (x >= vol.W || y >= vol.H || z >= vol.z0 + vol.nz) continue;
-        const int ctr = ((lz + H) * B::SY + (ly + H)) * B::SX + (lx + H);
-        const float d0 = lds[ctr], d1 = lds[B::SN + ctr], d2 = lds[2 * B::SN + ctr];
-        const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
-        const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
-        const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
-        // local coordinates of the corner taps inside the staged box
-        const int bx0 = tx.i0 - (ox - H), bx1 = tx.i1 - (ox - H);
-        const int by0 = ty.i0 - (oy - H), by1 = ty.i1 - (oy - H);
-        const int bz0 = tz.i0 - (oz - H), bz1 = tz.i1 - (oz - H);
-        const bool in_lds = bx0 >= 0 && bx1 < B::SX && by0 >= 0 && by1 < B::SY && bz0 >= 0 && bz1 < B::SZ;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-        if (in_lds) {
-#pragma unroll
-            for (int cz = 0; cz < 2; ++cz)
-#pragma unroll
-                for (int cy = 0; cy < 2; ++cy) {
-                    const int row = ((cz ? bz1 : bz0) * B::SY + (cy ? by1 : by0)) * B::SX;
-#pragma unroll
-                    for (int cx = 0; cx < 2; ++cx) {
-                        const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
-                        const int idx = row + (cx ? bx1 : bx0);
-                        a0 = __fadd_rn(a0, __fmul_rn(lds[idx], w));
-                        a1 = __fadd_rn(a1, __fmul_rn(lds[B::SN + idx], w));
-                        a2 = __fadd_rn(a2, __fmul_rn(lds[2 * B::SN + idx], w));
-                    }
-                }
-        } else {
-#pragma unroll
-            for (int cz = 0; cz < 2; ++cz)
-#pragma unroll
-                for (int cy = 0; cy < 2; ++cy) {
-                    const int64_t rowoff = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W;
-#pragma unroll
-                    for (int cx = 0; cx < 2; ++cx) {
-                        const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
-                        const int64_t idx = rowoff + (cx ? tx.i1 : tx.i0);
-                        a0 = __fadd_rn(a0, __fmul_rn(ldp<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow), w));
-                        a1 = __fadd_rn(a1, __fmul_rn(ldp<PRESCALE>(c1, idx, sc.nm1[1], sc.inv_pow), w));
-                        a2 = __fadd_rn(a2, __fmul_rn(ldp<PRESCALE>(c2, idx, sc.nm1[2], sc.inv_pow), w));
-                    }
-                }
-        }
-        const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-        const float r0 = __fadd_rn(d0, a0), r1 = __fadd_rn(d1, a1), r2 = __fadd_rn(d2, a2);
-        o[g] = r0;
-        o[g + V] = r1;
-        o[g + 2 * V] = r2;
-        m0 = fmaxf(m0, fabsf(r0));
-        m1 = fmaxf(m1, fabsf(r1));
-        m2 = fmaxf(m2, fabsf(r2));
-    }
-    if (dmax_out) {
-        // max |d_k| in voxels per axis (normalised -> voxels: * (n - 1) / 2).  Reduced over the workgroup first, and the
-        // atomic is skipped when the published bound already covers it (the bound only grows, so a stale read is safe):
-        // thousands of same-address atomics per launch would serialise at the memory side.
-        m0 *= 0.5f * sc.nm1[0];
-        m1 *= 0.5f * sc.nm1[1];
-        m2 *= 0.5f * sc.nm1[2];
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) {
-            m0 = fmaxf(m0, __shfl_down(m0, off, kWave));
-            m1 = fmaxf(m1, __shfl_down(m1, off, kWave));
-            m2 = fmaxf(m2, __shfl_down(m2, off, kWave));
-        }
-        const int wid = threadIdx.x / kWave;
-        if ((threadIdx.x & (kWave - 1)) == 0) {
-            red[wid] = m0;
-            red[(kExpBlock / kWave) + wid] = m1;
-            red[2 * (kExpBlock / kWave) + wid] = m2;
-        }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            float m = 0.0f;
-#pragma unroll
-            for (int w = 0; w < kExpBlock / kWave; ++w) m = fmaxf(m, red[threadIdx.x * (kExpBlock / kWave) + w]);
-            unsigned* slot = dmax_out + chain * 4 + threadIdx.x;
-            if (__float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_nonneg(slot, m);
-        }
-    }
-    __syncthreads();  // LDS is reused by the next tile
-  }
-}
-
 static Scale3L make_scale_l(Vol vol, int no_steps) {
     Scale3L s;
     s.nm1[0] = (float)(vol.W - 1);
@@ -201,26 +80,6 @@ static dim3 exp_grid(Vol vol, int C, TileGrid* tg) {
     tg->ntz = (vol.nz + ETZ - 1) / ETZ;
     tg->total = tg->ntx * tg->nty * tg->ntz * C;
     return dim3((unsigned)(tg->total < kExpGridCap ? tg->total : kExpGridCap));
-}
-
-// dmax_in = published bound of the INPUT field (nullptr: unknown -> one launch with `halo`); dmax_out receives the bound
-// of the output field.  With dmax_in both halo variants are launched and the device picks one: halo 1 when the
-// displacement stays below one voxel, halo 2 otherwise (taps beyond the staged box fall back to global memory).
-void launch_exp_step_fwd_lds(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
-                             const unsigned* dmax_in, unsigned* dmax_out, int halo, hipStream_t st) {
-    TileGrid tz;
-    const dim3 grid = exp_grid(vol, C, &tz);
-    const Scale3L sc = make_scale_l(vol, no_steps);
-#define IRS_FWD(P, HH, LO, HI) hipLaunchKernelGGL((exp_fwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, tz, LO, HI)
-    if (dmax_in) {
-        if (prescale_in) { IRS_FWD(true, 1, -1, 1); IRS_FWD(true, 2, 1, 1 << 30); }
-        else { IRS_FWD(false, 1, -1, 1); IRS_FWD(false, 2, 1, 1 << 30); }
-    } else if (prescale_in) {
-        if (halo <= 1) IRS_FWD(true, 1, 0, 0); else IRS_FWD(true, 2, 0, 0);
-    } else {
-        if (halo <= 1) IRS_FWD(false, 1, 0, 0); else IRS_FWD(false, 2, 0, 0);
-    }
-#undef IRS_FWD
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -406,193 +265,6 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
         if (halo <= 1) IRS_BWD(false, 1); else IRS_BWD(false, 2);
     }
 #undef IRS_BWD
-}
-
-// ------------------------------------------------------------------------------------------------
-// adjoint step, gather form (the common case max|d_k| < R voxels, R = 1 or 2): LDS float atomics retire one lane per
-// clock on gfx950 (measured: ~62 LDS cycles per ds_add_f32 wave-instruction), so instead of scattering, every OUTPUT
-// voxel y sums over its (2R+1)^3 candidate sources x:   sum_x G(x) * prod_a hat(p_a(x) - y_a),  hat(t) = max(0, 1 - |t|),
-// with p(x) the clipped sampling position of x.  hat() reproduces ATen's corner weights exactly ((i0 + 1) - p and p - i0
-// are exact differences) and is zero for every non-corner cell.  No atomics, fixed summation order => bitwise
-// reproducible.  LDS holds one 6-float record per source over tile +/- R: (d or p, G).
-//   phase A  own voxels: identity path + grid-gradient from the staged d        (registers)
-//   phase B  records: d -> clipped sampling position p (sentinel outside the volume)
-//   phase C  gather; each thread owns a column of 4 outputs in z so that a source record is read once for up to
-//            2R+1 outputs and the x/y hat factors are shared.
-// Workgroups whose published bound max|d_k| >= R leave immediately: the scatter kernel below handles those launches.
-// ------------------------------------------------------------------------------------------------
-constexpr int kColZ = ETZ / (kExpBlock / (ETX * ETY));  // outputs per thread along z (4)
-
-template <bool PRESCALE, int R>
-__global__ __launch_bounds__(kExpBlock) void exp_bwd_gather_kernel(const float* __restrict__ G,
-                                                                   const float* __restrict__ dk, float* __restrict__ gout,
-                                                                   Vol vol, Lin lin, Scale3L sc,
-                                                                   const unsigned* __restrict__ dmax, TileGrid tg, int r_lo) {
-    using B = ExpBox<R>;
-    __shared__ float rec[6 * B::SN];
-  for (int tile = blockIdx.x; tile < tg.total; tile += gridDim.x) {
-    int t_ = tile;
-    const int ox = (t_ % tg.ntx) * ETX;
-    t_ /= tg.ntx;
-    const int oy = (t_ % tg.nty) * ETY;
-    t_ /= tg.nty;
-    const int oz = vol.z0 + (t_ % tg.ntz) * ETZ;
-    const int chain = t_ / tg.ntz;
-    {   // this variant owns the launch iff the needed source halo hs = floor(max|d|) + 1 satisfies R_lo < hs <= R
-        const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
-                           (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
-        if (hs > R || hs <= r_lo) continue;
-    }
-    const int64_t V = vol.V;
-    const int64_t cb = (int64_t)chain * 3 * V;
-    const float* c0 = dk + cb;
-    const float* Gc = G + cb;
-
-    for (int i = threadIdx.x; i < B::SN; i += kExpBlock) {
-        const int lx = i % B::SX, ly = (i / B::SX) % B::SY, lz = i / (B::SX * B::SY);
-        const int ux = ox - R + lx, uy = oy - R + ly, uz = oz - R + lz;
-        const bool inside = (unsigned)ux < (unsigned)vol.W && (unsigned)uy < (unsigned)vol.H && (unsigned)uz < (unsigned)vol.D;
-        const int gx = min(max(ux, 0), vol.W - 1), gy = min(max(uy, 0), vol.H - 1), gz = min(max(uz, 0), vol.D - 1);
-        const int64_t g = ((int64_t)gz * vol.H + gy) * vol.W + gx;
-        float* r = rec + 6 * i;
-        r[0] = ldp<PRESCALE>(c0, g, sc.nm1[0], sc.inv_pow);
-        r[1] = ldp<PRESCALE>(c0 + V, g, sc.nm1[1], sc.inv_pow);
-        r[2] = ldp<PRESCALE>(c0 + 2 * V, g, sc.nm1[2], sc.inv_pow);
-        r[3] = inside ? Gc[g] : 0.0f;
-        r[4] = inside ? Gc[V + g] : 0.0f;
-        r[5] = inside ? Gc[2 * V + g] : 0.0f;
-    }
-    __syncthreads();
-
-    const int col = threadIdx.x & (ETX * ETY - 1);
-    const int lx = col % ETX, ly = col / ETX, lz0 = (threadIdx.x / (ETX * ETY)) * kColZ;
-    const int x = ox + lx, y = oy + ly;
-    const bool col_in = x < vol.W && y < vol.H;
-
-    // ---- phase A (results stay in registers; the scheduling barrier keeps the four iterations from being interleaved,
-    // which would otherwise cost > 256 VGPRs)
-    float own[kColZ][3];
-#pragma unroll
-    for (int j = 0; j < kColZ; ++j) {
-        __builtin_amdgcn_sched_barrier(0);
-        own[j][0] = own[j][1] = own[j][2] = 0.0f;
-        const int z = oz + lz0 + j;
-        if (!col_in || z >= vol.z0 + vol.nz) continue;
-        const float* rc = rec + 6 * (((lz0 + j + R) * B::SY + (ly + R)) * B::SX + (lx + R));
-        const float d0 = rc[0], d1 = rc[1], d2 = rc[2], G0 = rc[3], G1 = rc[4], G2 = rc[5];
-        const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
-        const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
-        const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
-        const int bx0 = tx.i0 - (ox - R), bx1 = tx.i1 - (ox - R);
-        const int by0 = ty.i0 - (oy - R), by1 = ty.i1 - (oy - R);
-        const int bz0 = tz.i0 - (oz - R), bz1 = tz.i1 - (oz - R);
-        const bool in_box = bx0 >= 0 && bx1 < B::SX && by0 >= 0 && by1 < B::SY && bz0 >= 0 && bz1 < B::SZ;
-        float gix = 0.0f, giy = 0.0f, giz = 0.0f;
-#pragma unroll
-        for (int cz = 0; cz < 2; ++cz)
-#pragma unroll
-            for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-                for (int cx = 0; cx < 2; ++cx) {
-                    float v0, v1, v2;
-                    if (in_box) {
-                        const float* t = rec + 6 * (((cz ? bz1 : bz0) * B::SY + (cy ? by1 : by0)) * B::SX + (cx ? bx1 : bx0));
-                        v0 = t[0];
-                        v1 = t[1];
-                        v2 = t[2];
-                    } else {  // cannot happen while max|d| < R, kept for safety
-                        const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
-                        v0 = ldp<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow);
-                        v1 = ldp<PRESCALE>(c0 + V, idx, sc.nm1[1], sc.inv_pow);
-                        v2 = ldp<PRESCALE>(c0 + 2 * V, idx, sc.nm1[2], sc.inv_pow);
-                    }
-                    const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
-                    const float dot = v0 * G0 + v1 * G1 + v2 * G2;
-                    gix += (cx ? dot : -dot) * (wy * wz);
-                    giy += (cy ? dot : -dot) * (wx * wz);
-                    giz += (cz ? dot : -dot) * (wx * wy);
-                }
-        own[j][0] = G0 + tx.gmul * gix;
-        own[j][1] = G1 + ty.gmul * giy;
-        own[j][2] = G2 + tz.gmul * giz;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-
-    // ---- phase B: displacement -> clipped sampling position in voxel coordinates (same arithmetic as axis_tap)
-    for (int i = threadIdx.x; i < B::SN; i += kExpBlock) {
-        const int bx = i % B::SX, by = (i / B::SX) % B::SY, bz = i / (B::SX * B::SY);
-        const int ux = ox - R + bx, uy = oy - R + by, uz = oz - R + bz;
-        float* r = rec + 6 * i;
-        if ((unsigned)ux < (unsigned)vol.W && (unsigned)uy < (unsigned)vol.H && (unsigned)uz < (unsigned)vol.D) {
-            const float nx = (float)(vol.W - 1), ny = (float)(vol.H - 1), nz = (float)(vol.D - 1);
-            const float px = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.x[ux], r[0]), 1.0f), 0.5f), nx);
-            const float py = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.y[uy], r[1]), 1.0f), 0.5f), ny);
-            const float pz = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.z[uz], r[2]), 1.0f), 0.5f), nz);
-            r[0] = px <= 0.0f ? 0.0f : (px >= nx ? nx : px);
-            r[1] = py <= 0.0f ? 0.0f : (py >= ny ? ny : py);
-            r[2] = pz <= 0.0f ? 0.0f : (pz >= nz ? nz : pz);
-        } else {
-            r[0] = r[1] = r[2] = -1.0e9f;  // replicated halo cell outside the volume: not a source
-        }
-    }
-    __syncthreads();
-
-    // ---- phase C
-    float acc[kColZ][3];
-#pragma unroll
-    for (int j = 0; j < kColZ; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 0.0f;
-    const float fx = (float)x, fy = (float)y, fz0 = (float)(oz + lz0);
-#pragma unroll
-    for (int sz = 0; sz < kColZ + 2 * R; ++sz) {       // source plane: z = oz + lz0 - R + sz
-#pragma unroll 1
-        for (int dy = 0; dy <= 2 * R; ++dy) {
-#pragma unroll
-            for (int dx = 0; dx <= 2 * R; ++dx) {
-                const float* t = rec + 6 * (((lz0 + sz) * B::SY + (ly + dy)) * B::SX + (lx + dx));
-                const float px = t[0], py = t[1], pz = t[2], g0 = t[3], g1 = t[4], g2 = t[5];
-                const float hxy = __saturatef(1.0f - fabsf(px - fx)) * __saturatef(1.0f - fabsf(py - fy));
-#pragma unroll
-                for (int j = 0; j < kColZ; ++j) {
-                    if (sz - R - j > R || j - (sz - R) > R) continue;  // |source plane - output plane| <= R (compile time)
-                    const float w = hxy * __saturatef(1.0f - fabsf(pz - (fz0 + (float)j)));
-                    acc[j][0] = fmaf(w, g0, acc[j][0]);
-                    acc[j][1] = fmaf(w, g1, acc[j][1]);
-                    acc[j][2] = fmaf(w, g2, acc[j][2]);
-                }
-            }
-        }
-    }
-    float* o = gout + cb;
-#pragma unroll
-    for (int j = 0; j < kColZ; ++j) {
-        const int z = oz + lz0 + j;
-        if (!col_in || z >= vol.z0 + vol.nz) continue;
-        const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-        o[g] = own[j][0] + acc[j][0];
-        o[g + V] = own[j][1] + acc[j][1];
-        o[g + 2 * V] = own[j][2] + acc[j][2];
-    }
-    __syncthreads();
-  }
-}
-
-// launches the radius-1 and radius-2 variants back to back; on the device exactly one of {gather<1>, gather<2>, scatter}
-// does the work of a step, chosen from the displacement bound the forward pass published
-void launch_exp_step_bwd_gather(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
-                                Lin lin, const unsigned* dmax, int max_radius, hipStream_t st) {
-    TileGrid tz;
-    const dim3 grid = exp_grid(vol, C, &tz);
-    const Scale3L sc = make_scale_l(vol, no_steps);
-#define IRS_BWG(P, RR, LO) hipLaunchKernelGGL((exp_bwd_gather_kernel<P, RR>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, LO)
-    if (prescale_in) {
-        IRS_BWG(true, 1, 0);
-        if (max_radius >= 2) IRS_BWG(true, 2, 1);
-    } else {
-        IRS_BWG(false, 1, 0);
-        if (max_radius >= 2) IRS_BWG(false, 2, 1);
-    }
-#undef IRS_BWG
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1032,7 +704,9 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
     const int swz_run = swz_env >= 0 ? swz_env : (int)grid.x;
 #define IRS_FWM(P, RR, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), grid, dim3(kMarchBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run)
-    if (prescale_in) { IRS_FWM(true, 1, -1, 1); IRS_FWM(true, 2, 1, 1 << 30); }
+    if (!dmax_in) {  // no published bound: the radius-1 ring is correct for any displacement (far taps go to global memory)
+        if (prescale_in) IRS_FWM(true, 1, -1, 1 << 30); else IRS_FWM(false, 1, -1, 1 << 30);
+    } else if (prescale_in) { IRS_FWM(true, 1, -1, 1); IRS_FWM(true, 2, 1, 1 << 30); }
     else { IRS_FWM(false, 1, -1, 1); IRS_FWM(false, 2, 1, 1 << 30); }
 #undef IRS_FWM
 }

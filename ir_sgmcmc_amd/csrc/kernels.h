@@ -50,15 +50,12 @@ void launch_ffd_axis(const float* in, float* out, const SplineTaps& taps, bool a
                      int n_out, int64_t inner, hipStream_t st);
 void launch_scale_channels(const float* in, float* out, float s0, float s1, float s2, int C, Vol vol, hipStream_t st);
 
-// ---- exp_kernels.hip (LDS-tiled squaring step + owner-computes adjoint)
-void launch_exp_step_fwd_lds(const float* din, float* dout, bool prescale, int no_steps, int C, Vol vol, Lin lin,
-                             const unsigned* dmax_in, unsigned* dmax_out, int halo, hipStream_t st);
-// the adjoint is launched as a pair: the gather kernel does the work when max|d_k| < radius, otherwise it exits at once
-// and the (LDS-atomic) scatter kernel, which skips launches the gather kernel owns, does it; decided on the device
-void launch_exp_step_bwd_gather(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
-                                Lin lin, const unsigned* dmax, int radius, hipStream_t st);
+// ---- exp_kernels.hip (z-marching squaring step + owner-computes gather adjoint, LDS-scatter fallback)
+// dmax_in: published bound of the input field (nullptr = unknown), dmax_out: receives the bound of the output field
 void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale, int no_steps, int C, Vol vol, Lin lin,
                                const unsigned* dmax_in, unsigned* dmax_out, hipStream_t st);
+// the adjoint is launched as a set: gather radius 1, gather radius 2 and the scatter fallback; exactly one of them does
+// the work, chosen on the device from the bound max|d_k|
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, hipStream_t st);
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
