@@ -280,13 +280,21 @@ __global__ __launch_bounds__(kLdsBlock) void lcc_data_bwd_kernel(const float* __
                                                                  float* __restrict__ g_m, double* __restrict__ nll_out,
                                                                  Vol vol) {
     using Z = LccSizes<S>;
-    __shared__ float lds[Z::R2 + Z::P1 + Z::P2 + 2 * Z::R1];
+    // LDS regions, aliased along the lifetime of the buffers (S = 1: 67.5 KB -> two workgroups per CU):
+    //   region G : g_var over R2  -> y-pass temporary of the first adjoint box -> g_a over R1
+    //   region P : x-pass / z-pass temporaries (both adjoint boxes)
+    //   region W : g_w / sigma over R1 -> y-pass temporary of the second adjoint box
+    //   region A : 2 a / n over R1
+    static_assert(Z::P2 <= Z::R2 && Z::R1 <= Z::R2 && TX * (TY + 2 * S) * (TZ + 2 * S) <= Z::P1 && TX * TY * (TZ + 2 * S) <= Z::R1,
+                  "LDS aliasing assumptions");
+    __shared__ float lds[Z::R2 + Z::P1 + 2 * Z::R1];
     __shared__ double red[kLdsBlock / kWave];
-    float* bufG = lds;            // g_var over R2, later g_a over R1
+    float* bufG = lds;
     float* bufP = bufG + Z::R2;
-    float* bufQ = bufP + Z::P1;
-    float* bufW = bufQ + Z::P2;   // g_w / sigma over R1
-    float* bufA = bufW + Z::R1;   // 2 a / n over R1
+    float* bufW = bufP + Z::P1;
+    float* bufA = bufW + Z::R1;
+    float* bufQ = bufG;   // first box: written by the y pass, when g_var (x-pass input) is dead
+    float* bufQ2 = bufW;  // second box: written by the y pass, when g_w / sigma has been folded into g_a
 
     const int ox = blockIdx.x * TX, oy = blockIdx.y * TY, oz = vol.z0 + blockIdx.z * TZ;
     const int zend = vol.z0 + vol.nz;
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(kLdsBlock) void lcc_data_bwd_kernel(const float* __
     const Box Cx = shrink(R1, 0, S), Cxy = shrink(Cx, 1, S);
     lds_pass<0, true>(bufG, R1, bufP, Cx, S, vol);
     __syncthreads();
-    lds_pass<1, true>(bufP, Cx, bufQ, Cxy, S, vol);
+    lds_pass<1, true>(bufP, Cx, bufQ2, Cxy, S, vol);
     __syncthreads();
     for (int i = threadIdx.x; i < TX * TY * TZ; i += kLdsBlock) {
         const int lx = i % TX, ly = (i / TX) % TY, lz = i / (TX * TY);
@@ -351,13 +359,13 @@ __global__ __launch_bounds__(kLdsBlock) void lcc_data_bwd_kernel(const float* __
         const int col = ly * Cxy.ex + lx;
         for (int o = -S; o <= S; ++o) {
             const int q = gz + o;
-            if (q >= 0 && q < vol.D) acc += bufQ[(q - Cxy.oz) * Cxy.ey * Cxy.ex + col];
+            if (q >= 0 && q < vol.D) acc += bufQ2[(q - Cxy.oz) * Cxy.ey * Cxy.ex + col];
         }
         if (gz == 0)
-            for (int q = 0; q < S; ++q) acc += (float)(S - q) * bufQ[(q - Cxy.oz) * Cxy.ey * Cxy.ex + col];
+            for (int q = 0; q < S; ++q) acc += (float)(S - q) * bufQ2[(q - Cxy.oz) * Cxy.ey * Cxy.ex + col];
         if (gz == vol.D - 1)
             for (int q = vol.D - S; q < vol.D; ++q)
-                acc += (float)(S - (vol.D - 1 - q)) * bufQ[(q - Cxy.oz) * Cxy.ey * Cxy.ex + col];
+                acc += (float)(S - (vol.D - 1 - q)) * bufQ2[(q - Cxy.oz) * Cxy.ey * Cxy.ex + col];
         const float ga = bufG[((lz + S) * R1.ey + (ly + S)) * R1.ex + (lx + S)];
         g_m[((int64_t)gz * vol.H + gy) * vol.W + gx] = ga - acc / n;
     }
