@@ -283,6 +283,11 @@ constexpr int MTX = 32, MTY = 8, kMarchBlock = MTX * MTY;
 #define IRS_MARCH_WAVES 3
 #endif
 
+// hat function max(0, 1 - |t|).  v_med3_f32 folds into the clamp output modifier of the subtraction (one VALU op);
+// HIP's __saturatef compiles to two compares and two selects.
+__device__ __forceinline__ float clamp01(float t) { return __builtin_amdgcn_fmed3f(t, 0.0f, 1.0f); }
+__device__ __forceinline__ float hat01(float t) { return clamp01(1.0f - fabsf(t)); }
+
 template <bool PRESCALE, int R>
 struct March {
     static constexpr int NP = 2 * R + 1, PX = MTX + 2 * R, PY = MTY + 2 * R, PN = PX * PY;
@@ -423,12 +428,15 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
                     for (int dx = 0; dx <= 2 * R; ++dx) {
                         const int ri = PH * PN + (ly + dy) * PX + (lx + dx);
                         const float2 pxy = q_xy[ri], pzg = q_zg[ri], g01 = q_g[ri];
-                        const float hxy = __saturatef(1.0f - fabsf(pxy.x - fx)) * __saturatef(1.0f - fabsf(pxy.y - fy));
+                        const float hxy = hat01(pxy.x - fx) * hat01(pxy.y - fy);
                         const float t = pzg.x - fs;  // offset of the sampling position from the source plane
 #pragma unroll
                         for (int oo = -R; oo <= R; ++oo) {
                             const int a = (PH + oo + NP) % NP;  // accumulator of output plane s + oo (static index)
-                            const float w = hxy * __saturatef(1.0f - fabsf(t - (float)oo));
+                            // R == 1 guarantees |t| < 1 (variant selection by the displacement bound), where
+                            // hat(t + 1) = max(0, -t) and hat(t - 1) = max(0, t): one clamped op each, no offset add
+                            const float hz = R == 1 && oo != 0 ? clamp01(oo < 0 ? -t : t) : hat01(t - (float)oo);
+                            const float w = hxy * hz;
                             acc01[a].x = fmaf(w, g01.x, acc01[a].x);
                             acc01[a].y = fmaf(w, g01.y, acc01[a].y);
                             acc2[a] = fmaf(w, pzg.y, acc2[a]);
@@ -451,37 +459,47 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
                     const bool in_ring = bx0 >= 0 && bx1 < PX && by0 >= 0 && by1 < M::PY && tz.i0 >= zo - R && tz.i1 <= zo + R &&
                                          tz.i0 >= sbase;
                     float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+                    auto corners = [&](auto fetch) {  // grid gradient of the sample taken at this voxel
 #pragma unroll
-                    for (int cz = 0; cz < 2; ++cz) {
-                        const int zz = cz ? tz.i1 : tz.i0;
-                        const int rel = zz - zo;  // in [-R, R] whenever in_ring
-                        int sl = a * PN;
+                        for (int cz = 0; cz < 2; ++cz)
 #pragma unroll
-                        for (int q = -R; q <= R; ++q)
-                            if (q != 0) sl = rel == q ? ((a + q + NP) % NP) * PN : sl;
+                            for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-                        for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-                            for (int cx = 0; cx < 2; ++cx) {
-                                float v0, v1, v2;
-                                if (in_ring) {
-                                    const int ti = sl + (cy ? by1 : by0) * PX + (cx ? bx1 : bx0);
-                                    const float2 v01 = q_d[ti];
-                                    v0 = v01.x;
-                                    v1 = v01.y;
-                                    v2 = q_dz[ti];
-                                } else {  // cannot happen while max|d| < R
-                                    const int64_t idx = ((int64_t)zz * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
-                                    v0 = ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.inv_pow);
-                                    v1 = ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.inv_pow);
-                                    v2 = ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.inv_pow);
+                                for (int cx = 0; cx < 2; ++cx) {
+                                    float v0, v1, v2;
+                                    fetch(cx, cy, cz, v0, v1, v2);
+                                    const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
+                                    const float dot = v0 * G0 + v1 * G1 + v2 * G2;
+                                    gix += (cx ? dot : -dot) * (wy * wz);
+                                    giy += (cy ? dot : -dot) * (wx * wz);
+                                    giz += (cz ? dot : -dot) * (wx * wy);
                                 }
-                                const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
-                                const float dot = v0 * G0 + v1 * G1 + v2 * G2;
-                                gix += (cx ? dot : -dot) * (wy * wz);
-                                giy += (cy ? dot : -dot) * (wx * wz);
-                                giz += (cz ? dot : -dot) * (wx * wy);
-                            }
+                    };
+                    if (in_ring) {
+                        int slz[2];
+#pragma unroll
+                        for (int cz = 0; cz < 2; ++cz) {
+                            const int rel = (cz ? tz.i1 : tz.i0) - zo;  // in [-R, R]
+                            int sl = a * PN;
+#pragma unroll
+                            for (int q = -R; q <= R; ++q)
+                                if (q != 0) sl = rel == q ? ((a + q + NP) % NP) * PN : sl;
+                            slz[cz] = sl;
+                        }
+                        corners([&](int cx, int cy, int cz, float& v0, float& v1, float& v2) {
+                            const int ti = slz[cz] + (cy ? by1 : by0) * PX + (cx ? bx1 : bx0);
+                            const float2 v01 = q_d[ti];
+                            v0 = v01.x;
+                            v1 = v01.y;
+                            v2 = q_dz[ti];
+                        });
+                    } else {  // cannot happen while max|d| < R
+                        corners([&](int cx, int cy, int cz, float& v0, float& v1, float& v2) {
+                            const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
+                            v0 = ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.inv_pow);
+                            v1 = ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.inv_pow);
+                            v2 = ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.inv_pow);
+                        });
                     }
                     const int64_t pl = (int64_t)zo * vol.H * vol.W;
                     const unsigned g = (unsigned)(y * vol.W + x);
