@@ -100,15 +100,11 @@ struct AxisTap {
 __device__ __forceinline__ AxisTap axis_tap(float g, int n) {
     AxisTap t;
     const float nm1 = (float)(n - 1);
-    float i = __fmul_rn(__fmul_rn(__fadd_rn(g, 1.0f), 0.5f), nm1);
-    t.gmul = nm1 * 0.5f;
-    if (i <= 0.0f) {
-        i = 0.0f;
-        t.gmul = 0.0f;
-    } else if (i >= nm1) {
-        i = nm1;
-        t.gmul = 0.0f;
-    }
+    const float raw = __fmul_rn(__fmul_rn(__fadd_rn(g, 1.0f), 0.5f), nm1);
+    // branch-free clip (selects, not divergent branches: this runs three times per voxel in every sampling kernel)
+    const bool interior = raw > 0.0f && raw < nm1;
+    const float i = raw <= 0.0f ? 0.0f : (raw >= nm1 ? nm1 : raw);
+    t.gmul = interior ? nm1 * 0.5f : 0.0f;
     const float f = floorf(i);
     t.i0 = (int)f;
     t.i1 = min(t.i0 + 1, n - 1);

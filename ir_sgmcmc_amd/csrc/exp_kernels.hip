@@ -285,6 +285,14 @@ constexpr int MTX = 32, MTY = 8, kMarchBlock = MTX * MTY;
 
 // hat function max(0, 1 - |t|).  v_med3_f32 folds into the clamp output modifier of the subtraction (one VALU op);
 // HIP's __saturatef compiles to two compares and two selects.
+// load p[byte_off / 4] with the address formed as (uniform 64-bit base) + (32-bit lane byte offset): the global_load
+// saddr form, no 64-bit VALU address arithmetic per load.  Planes are < 4 GiB, so a 32-bit byte offset always suffices.
+__device__ __forceinline__ float ld_off(const float* __restrict__ base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st_off(float* __restrict__ base, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
 __device__ __forceinline__ float clamp01(float t) { return __builtin_amdgcn_fmed3f(t, 0.0f, 1.0f); }
 __device__ __forceinline__ float hat01(float t) { return clamp01(1.0f - fabsf(t)); }
 
@@ -359,13 +367,13 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
-            const unsigned g = (unsigned)sxy[it];
-            pre[it][0] = p0_[g];
-            pre[it][1] = p1_[g];
-            pre[it][2] = p2_[g];
-            pre[it][3] = p3_[g];
-            pre[it][4] = p4_[g];
-            pre[it][5] = p5_[g];
+            const unsigned g = (unsigned)sxy[it] * 4u;
+            pre[it][0] = ld_off(p0_, g);
+            pre[it][1] = ld_off(p1_, g);
+            pre[it][2] = ld_off(p2_, g);
+            pre[it][3] = ld_off(p3_, g);
+            pre[it][4] = ld_off(p4_, g);
+            pre[it][5] = ld_off(p5_, g);
         }
     };
     auto commit = [&](int s, int slot) {  // registers -> ring slot (with the clipped sampling position)
@@ -502,10 +510,10 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
                         });
                     }
                     const int64_t pl = (int64_t)zo * vol.H * vol.W;
-                    const unsigned g = (unsigned)(y * vol.W + x);
-                    (o + pl)[g] = (G0 + tx.gmul * gix) + acc01[a].x;
-                    (o + V + pl)[g] = (G1 + ty.gmul * giy) + acc01[a].y;
-                    (o + 2 * V + pl)[g] = (G2 + tz.gmul * giz) + acc2[a];
+                    const unsigned g = (unsigned)(y * vol.W + x) * 4u;
+                    st_off(o + pl, g, (G0 + tx.gmul * gix) + acc01[a].x);
+                    st_off(o + V + pl, g, (G1 + ty.gmul * giy) + acc01[a].y);
+                    st_off(o + 2 * V + pl, g, (G2 + tz.gmul * giz) + acc2[a]);
                 }
                 acc01[a] = make_float2(0.0f, 0.0f);
                 acc2[a] = 0.0f;
@@ -547,9 +555,12 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
                                                                     unsigned* __restrict__ dmax_out, int seg_len, int nseg,
                                                                     int h_lo, int h_hi, int swz_run) {
     using M = March<PRESCALE, R>;
-    constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
-    __shared__ float2 r_xy[NP * PN];  // (d0, d1): one ds_read_b64 per tap
-    __shared__ float r_z[NP * PN];    // d2
+    constexpr int PX = M::PX, PN = M::PN, NIT = M::NIT;
+    // ring of 2R+2 slots: one more than a sample can reach, so that the commit of the next source plane never overwrites
+    // a plane another wavefront is still sampling -> ONE barrier per plane instead of two
+    constexpr int NS = M::NP + 1;
+    __shared__ float2 r_xy[NS * PN];  // (d0, d1): one ds_read_b64 per tap
+    __shared__ float r_z[NS * PN];    // d2
     __shared__ float red[3 * (kMarchBlock / kWave)];
     const int tile_ = xcd_swizzle_runs(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z, swz_run);
     const int tbx = tile_ % gridDim.x, tby = (tile_ / gridDim.x) % gridDim.y, tbz = tile_ / (gridDim.x * gridDim.y);
@@ -590,10 +601,10 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
-            const unsigned g = (unsigned)sxy[it];
-            pre[it][0] = px_[g];
-            pre[it][1] = py_[g];
-            pre[it][2] = pz_[g];
+            const unsigned g = (unsigned)sxy[it] * 4u;
+            pre[it][0] = ld_off(px_, g);
+            pre[it][1] = ld_off(py_, g);
+            pre[it][2] = ld_off(pz_, g);
         }
     };
     auto commit = [&](int slot) {
@@ -610,9 +621,9 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
     float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
     const int sbase = z0 - R, slast = z1 - 1 + R;
     prefetch(sbase);
-    for (int sb = sbase; sb <= slast; sb += NP) {
+    for (int sb = sbase; sb <= slast; sb += NS) {
 #pragma unroll
-        for (int PH = 0; PH < NP; ++PH) {
+        for (int PH = 0; PH < NS; ++PH) {
             const int s = sb + PH;
             if (s > slast) break;
             commit(PH);
@@ -620,9 +631,7 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
             __syncthreads();
             const int zo = s - R;
             if (zo >= z0 && zo < z1 && col_in) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int a = (PH - R + NP) % NP;
+                const int a = (PH - R + NS) % NS;  // slot of plane zo (compile-time)
                 const int ci = a * PN + (ly + R) * PX + (lx + R);
                 const float2 dxy = r_xy[ci];
                 const float d0 = dxy.x, d1 = dxy.y, d2 = r_z[ci];
@@ -639,13 +648,13 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
 #pragma unroll
                     for (int cz = 0; cz < 2; ++cz) {
                         const int zz = cz ? tz.i1 : tz.i0;
-                        // plane zz of the volume sits in ring slot (a + (zz - zo)) mod NP; with a compile-time `a` the slot
+                        // plane zz of the volume sits in ring slot (a + (zz - zo)) mod NS; with a compile-time `a` the slot
                         // of each of the 2R+1 candidate planes is a constant, picked by comparing zz - zo
                         const int rel = zz - zo;
                         int sl = a * PN;
 #pragma unroll
                         for (int q = -R; q <= R; ++q)
-                            if (q != 0) sl = rel == q ? ((a + q + NP) % NP) * PN : sl;
+                            if (q != 0) sl = rel == q ? ((a + q + NS) % NS) * PN : sl;
 #pragma unroll
                         for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
@@ -673,16 +682,15 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
                             }
                 }
                 const int64_t pl = (int64_t)zo * vol.H * vol.W;
-                const unsigned g = (unsigned)(y * vol.W + x);
+                const unsigned g = (unsigned)(y * vol.W + x) * 4u;
                 const float r0 = __fadd_rn(d0, a0), r1 = __fadd_rn(d1, a1), r2 = __fadd_rn(d2, a2);
-                (o + pl)[g] = r0;
-                (o + V + pl)[g] = r1;
-                (o + 2 * V + pl)[g] = r2;
+                st_off(o + pl, g, r0);
+                st_off(o + V + pl, g, r1);
+                st_off(o + 2 * V + pl, g, r2);
                 m0 = fmaxf(m0, fabsf(r0));
                 m1 = fmaxf(m1, fabsf(r1));
                 m2 = fmaxf(m2, fabsf(r2));
             }
-            __syncthreads();
         }
     }
     if (dmax_out) {
