@@ -130,7 +130,7 @@ int irs_perturb_smooth(const float* v, const float* sigma, const float* eps, flo
             HIP_TRY(hipMemcpyAsync(tmp, out, bytes, hipMemcpyDeviceToDevice, st));
             src = tmp;
         }
-        launch_sobolev_fused(src, out, taps, C * 3, vol, nullptr, 12, st);
+        launch_sobolev_march(src, out, taps, C * 3, vol, nullptr, 12, st);
         LAUNCH_CHECK();
         return 0;
     }
@@ -608,7 +608,7 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     if (cfg.sobolev_s > 0) {
         if (env_int("IRS_SOBOLEV_FUSED", 1)) {
             have_dmax0 = lds && !c->ffd;
-            launch_sobolev_fused(c->tmpA, vs, c->sob, C * 3, c->volv, have_dmax0 ? c->dmax : nullptr, cfg.no_steps, st);
+            launch_sobolev_march(c->tmpA, vs, c->sob, C * 3, c->volv, have_dmax0 ? c->dmax : nullptr, cfg.no_steps, st);
         } else {
             launch_conv_axis(c->tmpA, c->tmpB, c->sob, 2, C * 3, c->volv, st);
             launch_conv_axis(c->tmpB, c->tmpA, c->sob, 1, C * 3, c->volv, st);
@@ -817,7 +817,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
                            cfg.seed, 0, it, st);
             break;
         case IRS_ST_SMOOTH:
-            if (cfg.sobolev_s > 0) launch_sobolev_fused(c->tmpA, vs, c->sob, C * 3, w, c->dmax, cfg.no_steps, st);
+            if (cfg.sobolev_s > 0) launch_sobolev_march(c->tmpA, vs, c->sob, C * 3, w, c->dmax, cfg.no_steps, st);
             else launch_field_absmax(vs, true, cfg.no_steps, c->dmax, C, w, st);
             break;
         case IRS_ST_ENERGY:

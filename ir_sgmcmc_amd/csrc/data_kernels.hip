@@ -64,107 +64,6 @@ __device__ __forceinline__ Box shrink(Box b, int axis, int s) {
     return b;
 }
 
-// ------------------------------------------------------------------------------------------------
-// SobolevGrad.forward fused: the three replicate-padded 1-D passes (z, y, x -- the reference's order,
-// utils/util.py:400-404) over an LDS tile.  The separate-pass version moved every element through L1 with 7 dword
-// taps per pass and sat at the ~4.7 TB/s L1/TA ceiling (0.9 ms at 256^3); here each input element is staged once
-// (tile 32x16x8 + halo S: 2.9x read amplification, served by L2) and the taps come from LDS.
-// Optionally publishes max|v_s| / 2^steps per channel = the displacement bound of d_0 in voxels (exp_kernels.hip).
-// ------------------------------------------------------------------------------------------------
-constexpr int STX = 32, STY = 16, STZ = 8;
-
-template <int AXIS>
-__device__ __forceinline__ void lds_conv_pass(const float* __restrict__ src, const Box sb, float* __restrict__ dst,
-                                              const Box db, const Taps& taps, const Vol vol) {
-    const int n = db.ex * db.ey * db.ez;
-    const int s = taps.s;
-    const int nA = AXIS == 0 ? vol.W : (AXIS == 1 ? vol.H : vol.D);
-    const int so = AXIS == 0 ? sb.ox : (AXIS == 1 ? sb.oy : sb.oz);
-    const int stride = AXIS == 0 ? 1 : (AXIS == 1 ? sb.ex : sb.ex * sb.ey);
-    for (int i = threadIdx.x; i < n; i += kLdsBlock) {
-        const int lx = i % db.ex, ly = (i / db.ex) % db.ey, lz = i / (db.ex * db.ey);
-        const int gx = db.ox + lx, gy = db.oy + ly, gz = db.oz + lz;
-        const int g = AXIS == 0 ? gx : (AXIS == 1 ? gy : gz);
-        const int base = ((gz - sb.oz) * sb.ey + (gy - sb.oy)) * sb.ex + (gx - sb.ox) - (g - so) * stride;
-        float acc = 0.0f;
-        for (int t = 0; t <= 2 * s; ++t) {
-            const int q = min(max(g + t - s, 0), nA - 1);
-            acc = fmaf(taps.k[t], src[base + (q - so) * stride], acc);
-        }
-        dst[i] = acc;
-    }
-}
-
-template <int S>
-__global__ __launch_bounds__(kLdsBlock) void sobolev_fused_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                  Taps taps, Vol vol, unsigned* __restrict__ dmax0,
-                                                                  float inv_pow, int tiles_z) {
-    constexpr int AX = STX + 2 * S, AY = STY + 2 * S, AZ = STZ + 2 * S;
-    __shared__ float bufA[AX * AY * AZ];
-    __shared__ float bufB[AX * AY * STZ];
-    __shared__ float red[kLdsBlock / kWave];
-    const int plane = blockIdx.z / tiles_z;
-    const int ox = blockIdx.x * STX, oy = blockIdx.y * STY, oz = vol.z0 + (blockIdx.z % tiles_z) * STZ;
-    const int zend = vol.z0 + vol.nz;
-    const float* src = in + (int64_t)plane * vol.V;
-    const Box RA{ox - S, oy - S, oz - S, AX, AY, AZ};
-    for (int i = threadIdx.x; i < AX * AY * AZ; i += kLdsBlock) {
-        const int lx = i % AX, ly = (i / AX) % AY, lz = i / (AX * AY);
-        const int gx = min(max(RA.ox + lx, 0), vol.W - 1), gy = min(max(RA.oy + ly, 0), vol.H - 1),
-                  gz = min(max(RA.oz + lz, 0), vol.D - 1);
-        bufA[i] = src[(unsigned)((gz * vol.H + gy) * vol.W + gx)];
-    }
-    __syncthreads();
-    const Box Bz = shrink(RA, 2, S), Bzy = shrink(Bz, 1, S);
-    lds_conv_pass<2>(bufA, RA, bufB, Bz, taps, vol);
-    __syncthreads();
-    lds_conv_pass<1>(bufB, Bz, bufA, Bzy, taps, vol);
-    __syncthreads();
-    float m = 0.0f;
-    float* dst = out + (int64_t)plane * vol.V;
-    for (int i = threadIdx.x; i < STX * STY * STZ; i += kLdsBlock) {
-        const int lx = i % STX, ly = (i / STX) % STY, lz = i / (STX * STY);
-        const int gx = ox + lx, gy = oy + ly, gz = oz + lz;
-        if (gx >= vol.W || gy >= vol.H || gz >= zend) continue;
-        float acc = 0.0f;
-        const int row = (lz * Bzy.ey + ly) * Bzy.ex;
-        for (int t = 0; t <= 2 * S; ++t) {
-            const int q = min(max(gx + t - S, 0), vol.W - 1);
-            acc = fmaf(taps.k[t], bufA[row + (q - Bzy.ox)], acc);
-        }
-        dst[((int64_t)gz * vol.H + gy) * vol.W + gx] = acc;
-        m = fmaxf(m, fabsf(acc));
-    }
-    if (dmax0) {
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, kWave));
-        if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float mm = 0.0f;
-            for (int w = 0; w < kLdsBlock / kWave; ++w) mm = fmaxf(mm, red[w]);
-            mm *= inv_pow;  // |d_0| in voxels = |v_s| * (2/(n-1)/2^steps) * ((n-1)/2)
-            unsigned* slot = dmax0 + (plane / 3) * 4 + (plane % 3);
-            if (__float_as_uint(mm) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(mm));
-        }
-    }
-}
-
-void launch_sobolev_fused(const float* in, float* out, const Taps& taps, int planes, Vol vol, unsigned* dmax0, int no_steps,
-                          hipStream_t st) {
-    const int tz = (vol.nz + STZ - 1) / STZ;
-    const dim3 grid((vol.W + STX - 1) / STX, (vol.H + STY - 1) / STY, (unsigned)(tz * planes));
-    const float inv_pow = 1.0f / (float)(1 << no_steps);
-#define IRS_SOB(SS) hipLaunchKernelGGL((sobolev_fused_kernel<SS>), grid, dim3(kLdsBlock), 0, st, in, out, taps, vol, dmax0, inv_pow, tz)
-    switch (taps.s) {
-        case 1: IRS_SOB(1); break;
-        case 2: IRS_SOB(2); break;
-        case 3: IRS_SOB(3); break;
-        default: IRS_SOB(4); break;
-    }
-#undef IRS_SOB
-}
-
 template <int S>
 struct LccSizes {
     static constexpr int R2 = (TX + 4 * S) * (TY + 4 * S) * (TZ + 4 * S);

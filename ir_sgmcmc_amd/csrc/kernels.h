@@ -63,8 +63,8 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
 void launch_field_absmax(const float* d, bool prescale, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st);
 
 // ---- data_kernels.hip
-void launch_sobolev_fused(const float* in, float* out, const Taps& taps, int planes, Vol vol, unsigned* dmax0, int no_steps,
-                          hipStream_t st);
+void launch_sobolev_march(const float* in, float* out, const Taps& taps, int planes, Vol vol, unsigned* dmax0, int no_steps,
+                          hipStream_t st);  // z-marching version (stencil_kernels.hip)
 void launch_lcc_fwd(const float* fhat, int64_t fhat_stride, const float* im, float* z, float* sigma_out, int s, int C,
                     Vol vol, hipStream_t st);
 struct GmmDev;  // device-side mixture parameters (scalar_kernels.hip)
