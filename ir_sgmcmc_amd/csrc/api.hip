@@ -324,7 +324,7 @@ static bool lcc_ok(int s, int D, int H, int W) { return (s == 1 || s == 2) && D 
 int irs_lcc_normalise(const float* im, float* out, float* sigma_out, int s, int C, int D, int H, int W, void* stream) {
     if (!im || !out || !dims_ok(C, D, H, W)) return fail("irs_lcc_normalise: bad arguments");
     if (!lcc_ok(s, D, H, W)) return fail("irs_lcc_normalise: LCC half width must be 1 or 2 and smaller than half the volume");
-    launch_lcc_fwd(nullptr, 0, im, out, sigma_out, s, C, make_vol(D, H, W), (hipStream_t)stream);
+    launch_lcc_fwd_march(nullptr, 0, im, out, sigma_out, s, C, make_vol(D, H, W), (hipStream_t)stream);
     LAUNCH_CHECK();
     return 0;
 }
@@ -335,7 +335,7 @@ int irs_lcc_map_fwd(const float* fhat, int Cf, const float* warped, float* z, fl
         return fail("irs_lcc_map_fwd: bad arguments");
     if (!lcc_ok(s, D, H, W)) return fail("irs_lcc_map_fwd: LCC half width must be 1 or 2 and smaller than half the volume");
     const Vol vol = make_vol(D, H, W);
-    launch_lcc_fwd(fhat, Cf == 1 ? 0 : vol.V, warped, z, sigma_m, s, C, vol, (hipStream_t)stream);
+    launch_lcc_fwd_march(fhat, Cf == 1 ? 0 : vol.V, warped, z, sigma_m, s, C, vol, (hipStream_t)stream);
     LAUNCH_CHECK();
     return 0;
 }
@@ -547,7 +547,7 @@ int irs_velocity_dims(const irs_ctx* c, int32_t out[3]) {
 int irs_set_fixed(irs_ctx* c, const float* fixed_im, int fixed_chains, void* stream) {
     if (!c || !fixed_im || (fixed_chains != 1 && fixed_chains != c->C)) return fail("irs_set_fixed: bad arguments");
     if (c->cfg.data_loss == IRS_DATA_GMM_LCC) {
-        launch_lcc_fwd(nullptr, 0, fixed_im, c->fhat, nullptr, c->cfg.lcc_s, fixed_chains, c->vol, (hipStream_t)stream);
+        launch_lcc_fwd_march(nullptr, 0, fixed_im, c->fhat, nullptr, c->cfg.lcc_s, fixed_chains, c->vol, (hipStream_t)stream);
         LAUNCH_CHECK();
     }
     c->fhat_chains = fixed_chains;
@@ -642,7 +642,7 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     launch_warp_fwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif, alpha, warped, C, c->vol, lin,
                     cfg.seed, 0, it, st);
     if (cfg.data_loss == IRS_DATA_GMM_LCC)
-        launch_lcc_fwd(c->fhat, c->fhat_chains == 1 ? 0 : c->vol.V, warped, z, c->sigM, cfg.lcc_s, C, c->vol, st);
+        launch_lcc_fwd_march(c->fhat, c->fhat_chains == 1 ? 0 : c->vol.V, warped, z, c->sigM, cfg.lcc_s, C, c->vol, st);
     else
         launch_residual_ssd(io->fixed_im, io->fixed_chains == 1 ? 0 : c->vol.V, warped, z, C, c->vol, st);
     LAUNCH_CHECK();
@@ -842,7 +842,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
             break;
         case IRS_ST_RESIDUAL:
             if (cfg.data_loss == IRS_DATA_GMM_LCC)
-                launch_lcc_fwd(c->fhat, c->fhat_chains == 1 ? 0 : c->vol.V, warped, z, c->sigM, cfg.lcc_s, C, w, st);
+                launch_lcc_fwd_march(c->fhat, c->fhat_chains == 1 ? 0 : c->vol.V, warped, z, c->sigM, cfg.lcc_s, C, w, st);
             else
                 launch_residual_ssd(io->fixed_im, io->fixed_chains == 1 ? 0 : c->vol.V, warped, z, C, w, st);
             break;

@@ -65,8 +65,8 @@ void launch_field_absmax(const float* d, bool prescale, int no_steps, unsigned* 
 // ---- data_kernels.hip
 void launch_sobolev_march(const float* in, float* out, const Taps& taps, int planes, Vol vol, unsigned* dmax0, int no_steps,
                           hipStream_t st);  // z-marching version (stencil_kernels.hip)
-void launch_lcc_fwd(const float* fhat, int64_t fhat_stride, const float* im, float* z, float* sigma_out, int s, int C,
-                    Vol vol, hipStream_t st);
+void launch_lcc_fwd_march(const float* fhat, int64_t fhat_stride, const float* im, float* z, float* sigma_out, int s, int C,
+                    Vol vol, hipStream_t st);  // z-marching version (stencil_kernels.hip)
 struct GmmDev;  // device-side mixture parameters (scalar_kernels.hip)
 // data term + its gradient w.r.t. the warped image (LCC adjoint fused); mode: IRS_DATA_*
 void launch_data_bwd(int mode, const float* fhat_or_fixed, int64_t f_stride, const float* z, const float* sigma_m,
@@ -76,6 +76,11 @@ void launch_stats(int want_vd, const float* z, const uint8_t* mask, const void* 
                   hipStream_t st);
 void launch_residual_ssd(const float* fixed, int64_t f_stride, const float* warped, float* z, int C, Vol vol,
                          hipStream_t st);
+// z-marching fused data-term backward (stencil_kernels.hip)
+int lcc_data_bwd_march_blocks(Vol vol);
+void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* sigma_m, const uint8_t* mask,
+                               const float* g_z_override, const void* dev_state, int chain, float* g_warped,
+                               double* nll_partials, int s, Vol vol, hipStream_t st);
 int data_bwd_blocks(int mode, Vol vol);
 void launch_masked_moments(const float* z, const uint8_t* mask, double* partials, Vol vol, hipStream_t st);
 void launch_reg_energy(const float* v, double* partials, int C, Vol vol, hipStream_t st);

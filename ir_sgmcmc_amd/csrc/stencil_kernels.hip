@@ -173,4 +173,438 @@ void launch_sobolev_march(const float* in, float* out, const Taps& taps, int pla
 #undef IRS_SOB
 }
 
+// ------------------------------------------------------------------------------------------------
+// LCC map (model/loss.py:53-59,102-111):  u = box(I)/n,  w = I - u,  var = box(w^2)/n,  sigma = sqrt(var + 1e-10),
+// out = w / sigma  (MAP: fhat - w / sigma, the fixed side being pre-normalised once).  box = (2S+1)^3 all-ones filter
+// with REPLICATE padding -- of I for the first box, of w^2 for the second (so the second box indexes clamped
+// COORDINATES: a w computed from replicated I outside the volume would be a different number).
+//
+// One pipeline iteration per staged input plane `pin` (segment [z0, z1) -> pin = z0 - 2S .. z1 - 1 + 2S):
+//   A  I(clamp(pin)) over the tile + 2S halo, clamped loads -> LDS plane LA
+//   B  per element of the tile + S region: in-plane (2S+1)^2 sum of LA -> register ring over 2S+1 planes -> u, w at
+//      plane pu = pin - S -> LDS ring LW (S+2 planes)
+//   C  per output: in-plane (2S+1)^2 sum of w^2 (clamped coordinates) -> register ring (replicated at the volume ends)
+//      -> var, sigma, output at plane pv = pin - 2S.
+// Two barriers per plane.  Tile 32 x 16, two outputs per thread.
+// ------------------------------------------------------------------------------------------------
+constexpr int LMX = 32, LMY = 16;
+
+template <int S, bool MAP>
+__global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __restrict__ fhat, int64_t fhat_stride,
+                                                                 const float* __restrict__ im, float* __restrict__ out,
+                                                                 float* __restrict__ sigma_out, Vol vol, int seg_len, int nseg) {
+    constexpr int NT = 2 * S + 1, NS = S + 2;
+    constexpr int AX = LMX + 4 * S, AY = LMY + 4 * S, AN = AX * AY, NITA = (AN + kStBlock - 1) / kStBlock;
+    constexpr int BX = LMX + 2 * S, BY = LMY + 2 * S, BN = BX * BY, NITB = (BN + kStBlock - 1) / kStBlock;
+    __shared__ float LA[AN];
+    __shared__ float LW[NS * BN];
+
+    const int chain = blockIdx.z / nseg, seg = blockIdx.z % nseg;
+    const int ox = blockIdx.x * LMX, oy = blockIdx.y * LMY;
+    const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
+    const int64_t HW = (int64_t)vol.H * vol.W;
+    const float* __restrict__ src = im + (int64_t)chain * vol.V;
+    const float n = (float)(NT * NT * NT);
+
+    unsigned aoff[NITA];
+    bool aval[NITA];
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) {
+        const int i = threadIdx.x + it * kStBlock;
+        const int px = i % AX, py = i / AX;
+        const int cx = min(max(ox - 2 * S + px, 0), vol.W - 1), cy = min(max(oy - 2 * S + py, 0), vol.H - 1);
+        aval[it] = i < AN;
+        aoff[it] = (unsigned)(cy * vol.W + cx) * 4u;
+    }
+    int bwin[NITB];  // LA index of the top-left tap of the element's window; -1: no element
+#pragma unroll
+    for (int it = 0; it < NITB; ++it) {
+        const int e = threadIdx.x + it * kStBlock;
+        bwin[it] = e < BN ? (e / BX) * AX + (e % BX) : -1;
+    }
+    const int lx = threadIdx.x % LMX, ly = threadIdx.x / LMX;
+    const int gx = ox + lx;
+    int xo[NT], yo[2][NT];
+    bool oval[2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) xo[i] = min(max(gx + i - S, 0), vol.W - 1) - (ox - S);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int gy = oy + ly + o * (LMY / 2);
+        oval[o] = gx < vol.W && gy < vol.H;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) yo[o][j] = (min(max(gy + j - S, 0), vol.H - 1) - (oy - S)) * BX;
+    }
+
+    float ring1[NITB][NT], iring[NITB][S + 1], ring2[2][NT];
+#pragma unroll
+    for (int it = 0; it < NITB; ++it) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ring1[it][t] = 0.0f;
+#pragma unroll
+        for (int t = 0; t <= S; ++t) iring[it][t] = 0.0f;
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ring2[o][t] = 0.0f;
+
+    float pre[NITA];
+    auto load_plane = [&](int p) {
+        const float* __restrict__ base = src + (int64_t)min(max(p, 0), vol.D - 1) * HW;
+#pragma unroll
+        for (int it = 0; it < NITA; ++it)
+            if (aval[it]) pre[it] = ldg_off(base, aoff[it]);
+    };
+    const int pfirst = z0 - 2 * S, plast = z1 - 1 + 2 * S;
+    load_plane(pfirst);
+    for (int pin = pfirst; pin <= plast; ++pin) {
+        // ---- A
+#pragma unroll
+        for (int it = 0; it < NITA; ++it)
+            if (aval[it]) LA[threadIdx.x + it * kStBlock] = pre[it];
+        if (pin < plast) load_plane(pin + 1);
+        __syncthreads();
+        // ---- B
+        const int pu = pin - S;
+        const bool pu_real = pu >= 0 && pu < vol.D;
+        const int slot_u = ((pu % NS) + NS) % NS;
+#pragma unroll
+        for (int it = 0; it < NITB; ++it) {
+            if (bwin[it] < 0) continue;
+            float sxy = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) sxy += LA[bwin[it] + j * AX + i];
+#pragma unroll
+            for (int t = 0; t < NT - 1; ++t) ring1[it][t] = ring1[it][t + 1];
+            ring1[it][NT - 1] = sxy;
+#pragma unroll
+            for (int t = 0; t < S; ++t) iring[it][t] = iring[it][t + 1];
+            iring[it][S] = LA[bwin[it] + S * AX + S];
+            if (pu_real && pin >= z0) {  // ring1 holds planes pin - 2S .. pin = pu - S .. pu + S
+                float sum = 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) sum += ring1[it][t];
+                LW[slot_u * BN + threadIdx.x + it * kStBlock] = iring[it][0] - sum / n;
+            }
+        }
+        __syncthreads();
+        // ---- C
+        const int pv = pin - 2 * S;
+        const int slot_v = ((pv % NS) + NS) % NS;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            if (!oval[o]) continue;
+            if (pu_real && pin >= z0) {
+                float q = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        const float w = LW[slot_u * BN + yo[o][j] + xo[i]];
+                        q = fmaf(w, w, q);
+                    }
+                if (pu == 0) {  // volume start: planes -S .. -1 replicate plane 0
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) ring2[o][t] = q;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT - 1; ++t) ring2[o][t] = ring2[o][t + 1];
+                    ring2[o][NT - 1] = q;
+                }
+            } else if (pu >= vol.D) {  // volume end: replicate plane D - 1
+#pragma unroll
+                for (int t = 0; t < NT - 1; ++t) ring2[o][t] = ring2[o][t + 1];
+            }
+            if (pv >= z0 && pv < z1) {
+                float var = 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) var += ring2[o][t];
+                const float sigma = sqrtf(var / n + 1e-10f);
+                const int yy = ly + o * (LMY / 2);
+                const float wc = LW[slot_v * BN + (yy + S) * BX + lx + S];
+                const float r = wc / sigma;
+                const int64_t g = (int64_t)pv * HW + (unsigned)((oy + yy) * vol.W + gx);
+                out[(int64_t)chain * vol.V + g] = MAP ? fhat[(int64_t)chain * fhat_stride + g] - r : r;
+                if (sigma_out) sigma_out[(int64_t)chain * vol.V + g] = sigma;
+            }
+        }
+    }
+}
+
+void launch_lcc_fwd_march(const float* fhat, int64_t fhat_stride, const float* im, float* z, float* sigma_out, int s, int C,
+                          Vol vol, hipStream_t st) {
+    static const int seg_env = getenv("IRS_LCC_SEG") ? atoi(getenv("IRS_LCC_SEG")) : 32;
+    const int seg_len = seg_env;
+    const int nseg = (vol.nz + seg_len - 1) / seg_len;
+    const dim3 grid((vol.W + LMX - 1) / LMX, (vol.H + LMY - 1) / LMY, (unsigned)(nseg * C));
+    const bool map = fhat != nullptr;
+#define IRS_LCC_FWD(SS)                                                                                                    \
+    if (map) hipLaunchKernelGGL((lcc_fwd_march_kernel<SS, true>), grid, dim3(kStBlock), 0, st, fhat, fhat_stride, im, z,  \
+                                sigma_out, vol, seg_len, nseg);                                                           \
+    else hipLaunchKernelGGL((lcc_fwd_march_kernel<SS, false>), grid, dim3(kStBlock), 0, st, fhat, fhat_stride, im, z,     \
+                            sigma_out, vol, seg_len, nseg);
+    if (s == 1) { IRS_LCC_FWD(1) } else { IRS_LCC_FWD(2) }
+#undef IRS_LCC_FWD
+}
+
+// ------------------------------------------------------------------------------------------------
+// Data term backward, fused: GMM d(-log p)/dz (with the UPDATED mixture, trainer.py:316-330), the NLL partial sums, and
+// the adjoint of the LCC map down to g_M = dL/d(warped image).
+//   w' = fhat - z (= w / sigma),  gw = -gz,  gvar = -gw w' / (2 sigma^2),  pw = gw / sigma,  a2 = 2 w' sigma / n
+//   T1 = box^T(gvar),  ga = pw + a2 T1,  T2 = box^T(ga),  g_M = ga - T2 / n
+// box^T is the adjoint of the replicate-padded box filter: a plain (2S+1)-sum over the voxels that exist (nothing is
+// replicated, out-of-volume terms are zero) plus, on the first / last index of an axis, the extra weights of the padding
+// that folded onto it:  index 0 gets (S - x) more of x = 0..S-1,  index n-1 gets (S - (n-1-x)) more of x = n-S..n-1.
+//
+// Pipeline per staged plane `pin` (segment [z0, z1) -> pin = z0 - 2S .. z1 - 1 + 2S), tile 32 x 16:
+//   A  per element of the tile + 2S halo: mixture evaluation -> gvar (LDS plane), pw / a2 (LDS rings, tile + S region)
+//   B  per element of the tile + S region: weighted in-plane sum of gvar -> register ring -> T1, ga at plane q = pin - S
+//   C  per output: weighted in-plane sum of ga -> register ring -> T2, g_M at plane r = pin - 2S.
+// ------------------------------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ void adjoint_weights(int g, int n, float (&w)[2 * S + 1]) {
+#pragma unroll
+    for (int i = 0; i <= 2 * S; ++i) {
+        float v = 1.0f;
+        if (g == 0 && i >= S && i < 2 * S) v += (float)(2 * S - i);
+        if (g == n - 1 && i >= 1 && i <= S) v += (float)i;
+        w[i] = v;
+    }
+}
+
+// sum of a register ring over planes c-S .. c+S with the z border weights of box^T for centre plane c
+template <int S>
+__device__ __forceinline__ float adjoint_ring_sum(const float (&ring)[2 * S + 1], int c, int D) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t <= 2 * S; ++t) acc += ring[t];
+    if (c == 0) {
+#pragma unroll
+        for (int x = 0; x < S; ++x) acc += (float)(S - x) * ring[x + S];
+    }
+    if (c == D - 1) {
+#pragma unroll
+        for (int t = 1; t <= S; ++t) acc += (float)t * ring[t];
+    }
+    return acc;
+}
+
+template <int S, bool EXPLICIT_GZ>
+__global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const float* __restrict__ fhat,
+                                                                      const float* __restrict__ z,
+                                                                      const float* __restrict__ sigma_m,
+                                                                      const uint8_t* __restrict__ mask,
+                                                                      const float* __restrict__ gz_in,
+                                                                      const DevState* __restrict__ state, int chain,
+                                                                      float* __restrict__ g_m, double* __restrict__ nll_out,
+                                                                      Vol vol, int seg_len, int nseg) {
+    constexpr int NT = 2 * S + 1, NS1 = S + 1, NS2 = S + 2;
+    constexpr int AX = LMX + 4 * S, AY = LMY + 4 * S, AN = AX * AY, NITA = (AN + kStBlock - 1) / kStBlock;
+    constexpr int BX = LMX + 2 * S, BY = LMY + 2 * S, BN = BX * BY, NITB = (BN + kStBlock - 1) / kStBlock;
+    __shared__ float LGV[AN];
+    __shared__ float LPW[NS1 * BN], LA2[NS1 * BN];
+    __shared__ float LG[NS2 * BN];
+    __shared__ double red[kStBlock / kWave];
+
+    const int seg = blockIdx.z;
+    const int ox = blockIdx.x * LMX, oy = blockIdx.y * LMY;
+    const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
+    const int64_t HW = (int64_t)vol.H * vol.W;
+    const float n = (float)(NT * NT * NT);
+    const float alpha = EXPLICIT_GZ ? 1.0f : (float)state->sc.alpha[chain];
+
+    // stage A elements
+    unsigned aoff[NITA];
+    int abidx[NITA];  // index in the tile + S region, -1 if the element is halo-only
+    bool aexist[NITA], ainside[NITA], acentre[NITA];
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) {
+        const int i = threadIdx.x + it * kStBlock;
+        const int px = i % AX, py = i / AX;
+        const int gx = ox - 2 * S + px, gy = oy - 2 * S + py;
+        aexist[it] = i < AN;
+        ainside[it] = aexist[it] && gx >= 0 && gx < vol.W && gy >= 0 && gy < vol.H;
+        aoff[it] = ainside[it] ? (unsigned)(gy * vol.W + gx) : 0u;
+        const bool inb = aexist[it] && px >= S && px < AX - S && py >= S && py < AY - S;
+        abidx[it] = inb ? (py - S) * BX + (px - S) : -1;
+        acentre[it] = ainside[it] && px >= 2 * S && px < AX - 2 * S && py >= 2 * S && py < AY - 2 * S;
+    }
+    // stage B elements
+    int bwin[NITB];
+    float bwx[NITB][NT], bwy[NITB][NT];
+#pragma unroll
+    for (int it = 0; it < NITB; ++it) {
+        const int e = threadIdx.x + it * kStBlock;
+        const int bx = e % BX, by = e / BX;
+        bwin[it] = e < BN ? by * AX + bx : -1;
+        adjoint_weights<S>(ox - S + bx, vol.W, bwx[it]);
+        adjoint_weights<S>(oy - S + by, vol.H, bwy[it]);
+    }
+    // stage C outputs
+    const int lx = threadIdx.x % LMX, ly = threadIdx.x / LMX;
+    const int gxo = ox + lx;
+    float cwx[NT], cwy[2][NT];
+    bool oval[2];
+    adjoint_weights<S>(gxo, vol.W, cwx);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int gy = oy + ly + o * (LMY / 2);
+        oval[o] = gxo < vol.W && gy < vol.H;
+        adjoint_weights<S>(gy, vol.H, cwy[o]);
+    }
+
+    float ring1[NITB][NT], ring2[2][NT];
+#pragma unroll
+    for (int it = 0; it < NITB; ++it)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ring1[it][t] = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ring2[o][t] = 0.0f;
+
+    double nll = 0.0;
+    float pz[NITA], ps[NITA], pf[NITA], pg[NITA];
+    uint8_t pm[NITA];
+    auto load_plane = [&](int p) {
+        if (p < 0 || p >= vol.D) return;
+        const int64_t zo = (int64_t)p * HW;
+#pragma unroll
+        for (int it = 0; it < NITA; ++it) {
+            if (!ainside[it]) continue;
+            const unsigned g = aoff[it];
+            pz[it] = (z + zo)[g];
+            ps[it] = (sigma_m + zo)[g];
+            pf[it] = (fhat + zo)[g];
+            if (EXPLICIT_GZ) pg[it] = (gz_in + zo)[g];
+            else pm[it] = (mask + zo)[g];
+        }
+    };
+    const int pfirst = z0 - 2 * S, plast = z1 - 1 + 2 * S;
+    load_plane(pfirst);
+    for (int pin = pfirst; pin <= plast; ++pin) {
+        // ---- A
+        const bool pin_real = pin >= 0 && pin < vol.D;
+        const int slot_a = ((pin % NS1) + NS1) % NS1;
+#pragma unroll
+        for (int it = 0; it < NITA; ++it) {
+            if (!aexist[it]) continue;
+            float gvar = 0.0f, pw = 0.0f, a2 = 0.0f;
+            if (pin_real && ainside[it]) {
+                const float zz = pz[it], sg = ps[it];
+                float gzv;
+                if (EXPLICIT_GZ) {
+                    gzv = pg[it];
+                } else {
+                    gzv = 0.0f;
+                    if (pm[it]) {
+                        const MixEval e = mix_eval<false>(zz, state, nullptr, nullptr);
+                        gzv = alpha * e.gz;
+                        if (acentre[it] && pin >= z0 && pin < z1) nll += (double)e.nll;
+                    }
+                }
+                const float w = pf[it] - zz;
+                const float gw = -gzv;
+                gvar = -gw * w / (2.0f * sg * sg);
+                pw = gw / sg;
+                a2 = 2.0f * w * sg / n;
+            }
+            LGV[threadIdx.x + it * kStBlock] = gvar;
+            if (abidx[it] >= 0) {
+                LPW[slot_a * BN + abidx[it]] = pw;
+                LA2[slot_a * BN + abidx[it]] = a2;
+            }
+        }
+        if (pin < plast) load_plane(pin + 1);
+        __syncthreads();
+        // ---- B
+        const int q = pin - S;
+        const bool q_real = q >= 0 && q < vol.D && pin >= z0;
+        const int slot_q1 = ((q % NS1) + NS1) % NS1, slot_q2 = ((q % NS2) + NS2) % NS2;
+#pragma unroll
+        for (int it = 0; it < NITB; ++it) {
+            if (bwin[it] < 0) continue;
+            float p = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float row = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) row = fmaf(bwx[it][i], LGV[bwin[it] + j * AX + i], row);
+                p = fmaf(bwy[it][j], row, p);
+            }
+#pragma unroll
+            for (int t = 0; t < NT - 1; ++t) ring1[it][t] = ring1[it][t + 1];
+            ring1[it][NT - 1] = p;
+            if (q_real) {
+                const int e = threadIdx.x + it * kStBlock;
+                const float t1 = adjoint_ring_sum<S>(ring1[it], q, vol.D);
+                LG[slot_q2 * BN + e] = LPW[slot_q1 * BN + e] + LA2[slot_q1 * BN + e] * t1;
+            }
+        }
+        __syncthreads();
+        // ---- C
+        const int r = pin - 2 * S;
+        const int slot_r2 = ((r % NS2) + NS2) % NS2;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            if (!oval[o]) continue;
+            const int yy = ly + o * (LMY / 2);
+            float p = 0.0f;
+            if (q_real) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float row = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) row = fmaf(cwx[i], LG[slot_q2 * BN + (yy + j) * BX + lx + i], row);
+                    p = fmaf(cwy[o][j], row, p);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT - 1; ++t) ring2[o][t] = ring2[o][t + 1];
+            ring2[o][NT - 1] = p;
+            if (r >= z0 && r < z1) {
+                const float t2 = adjoint_ring_sum<S>(ring2[o], r, vol.D);
+                const float ga = LG[slot_r2 * BN + (yy + S) * BX + lx + S];
+                g_m[(int64_t)r * HW + (unsigned)((oy + yy) * vol.W + gxo)] = ga - t2 / n;
+            }
+        }
+    }
+    if (!EXPLICIT_GZ) {
+        nll = wave_sum(nll);
+        if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = nll;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < kStBlock / kWave; ++w) t += red[w];
+            nll_out[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
+int lcc_data_bwd_march_blocks(Vol vol) {
+    static const int seg_env = getenv("IRS_LCC_SEG") ? atoi(getenv("IRS_LCC_SEG")) : 32;
+    return ((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * ((vol.nz + seg_env - 1) / seg_env);
+}
+
+void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* sigma_m, const uint8_t* mask,
+                               const float* g_z_override, const void* dev_state, int chain, float* g_warped,
+                               double* nll_partials, int s, Vol vol, hipStream_t st) {
+    static const int seg_env = getenv("IRS_LCC_SEG") ? atoi(getenv("IRS_LCC_SEG")) : 32;
+    const int seg_len = seg_env;
+    const int nseg = (vol.nz + seg_len - 1) / seg_len;
+    const dim3 grid((vol.W + LMX - 1) / LMX, (vol.H + LMY - 1) / LMY, (unsigned)nseg);
+    const DevState* state = (const DevState*)dev_state;
+#define IRS_LCC_BWD(SS)                                                                                                      \
+    if (g_z_override) hipLaunchKernelGGL((lcc_data_bwd_march_kernel<SS, true>), grid, dim3(kStBlock), 0, st, fhat, z,       \
+                                         sigma_m, mask, g_z_override, state, chain, g_warped, nll_partials, vol, seg_len,   \
+                                         nseg);                                                                             \
+    else hipLaunchKernelGGL((lcc_data_bwd_march_kernel<SS, false>), grid, dim3(kStBlock), 0, st, fhat, z, sigma_m, mask,    \
+                            g_z_override, state, chain, g_warped, nll_partials, vol, seg_len, nseg);
+    if (s == 1) { IRS_LCC_BWD(1) } else { IRS_LCC_BWD(2) }
+#undef IRS_LCC_BWD
+}
+
 }  // namespace irs
