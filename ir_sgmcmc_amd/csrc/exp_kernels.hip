@@ -337,7 +337,6 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
     const int x = ox + lx, y = oy + ly;
     const bool col_in = x < vol.W && y < vol.H;
     const float fx = (float)x, fy = (float)y;
-    const float linx = col_in ? lin.x[x] : 0.0f, liny = col_in ? lin.y[y] : 0.0f;
     const float nxm = (float)(vol.W - 1), nym = (float)(vol.H - 1), nzm = (float)(vol.D - 1);
 
     int sxy[NIT];
@@ -383,23 +382,25 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
             const int i = slot * PN + threadIdx.x + it * kMarchBlock;
-            float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, p0 = -1.0e9f, p1 = -1.0e9f, p2 = -1.0e9f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
-            if (zin) {
-                d0 = PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.inv_pow) : pre[it][0];
-                d1 = PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.inv_pow) : pre[it][1];
-                d2 = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.inv_pow) : pre[it][2];
-                if (sin_[it]) {
-                    const float qx = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(slx[it], d0), 1.0f), 0.5f), nxm);
-                    const float qy = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(sly[it], d1), 1.0f), 0.5f), nym);
-                    const float qz = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lz_, d2), 1.0f), 0.5f), nzm);
-                    p0 = qx <= 0.0f ? 0.0f : (qx >= nxm ? nxm : qx);
-                    p1 = qy <= 0.0f ? 0.0f : (qy >= nym ? nym : qy);
-                    p2 = qz <= 0.0f ? 0.0f : (qz >= nzm ? nzm : qz);
-                    g0 = pre[it][3];
-                    g1 = pre[it][4];
-                    g2 = pre[it][5];
-                }
+            if (!zin) {  // plane outside the volume: no source there (G = 0 removes it from every gather)
+                q_xy[i] = make_float2(0.0f, 0.0f);
+                q_zg[i] = make_float2(0.0f, 0.0f);
+                q_g[i] = make_float2(0.0f, 0.0f);
+                q_d[i] = make_float2(0.0f, 0.0f);
+                q_dz[i] = 0.0f;
+                continue;
             }
+            const float d0 = PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.inv_pow) : pre[it][0];
+            const float d1 = PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.inv_pow) : pre[it][1];
+            const float d2 = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.inv_pow) : pre[it][2];
+            const float qx = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(slx[it], d0), 1.0f), 0.5f), nxm);
+            const float qy = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(sly[it], d1), 1.0f), 0.5f), nym);
+            const float qz = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lz_, d2), 1.0f), 0.5f), nzm);
+            // clip to [0, n-1] (one v_med3).  A halo element outside the volume is a copy of the clamped voxel; it must not
+            // act as a source, which G = 0 achieves whatever its position.
+            const float p0 = __builtin_amdgcn_fmed3f(qx, 0.0f, nxm), p1 = __builtin_amdgcn_fmed3f(qy, 0.0f, nym),
+                        p2 = __builtin_amdgcn_fmed3f(qz, 0.0f, nzm);
+            const float g0 = sin_[it] ? pre[it][3] : 0.0f, g1 = sin_[it] ? pre[it][4] : 0.0f, g2 = sin_[it] ? pre[it][5] : 0.0f;
             q_xy[i] = make_float2(p0, p1);
             q_zg[i] = make_float2(p2, g2);
             q_g[i] = make_float2(g0, g1);
@@ -457,63 +458,72 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
                 const int a = (PH - R + NP) % NP;
                 if (zo >= z0 && zo < z1 && col_in) {
                     const int ci = a * PN + (ly + R) * PX + (lx + R);  // plane zo sits in slot (zo - sbase) % NP == a
-                    const float2 d01 = q_d[ci], Gc01 = q_g[ci];
-                    const float d2 = q_dz[ci], G2 = q_zg[ci].y;
-                    const float G0 = Gc01.x, G1 = Gc01.y;
-                    const AxisTap tx = axis_tap(__fadd_rn(linx, d01.x), vol.W);
-                    const AxisTap ty = axis_tap(__fadd_rn(liny, d01.y), vol.H);
-                    const AxisTap tz = axis_tap(__fadd_rn(lin.z[zo], d2), vol.D);
-                    const int bx0 = tx.i0 - (ox - R), bx1 = tx.i1 - (ox - R), by0 = ty.i0 - (oy - R), by1 = ty.i1 - (oy - R);
-                    const bool in_ring = bx0 >= 0 && bx1 < PX && by0 >= 0 && by1 < M::PY && tz.i0 >= zo - R && tz.i1 <= zo + R &&
-                                         tz.i0 >= sbase;
-                    float gix = 0.0f, giy = 0.0f, giz = 0.0f;
-                    auto corners = [&](auto fetch) {  // grid gradient of the sample taken at this voxel
+                    // the sample this voxel took in the forward step: its clipped position is already in the ring
+                    const float2 pc = q_xy[ci], zg = q_zg[ci], Gc01 = q_g[ci];
+                    const float G0 = Gc01.x, G1 = Gc01.y, G2 = zg.y;
+                    const float fx0 = floorf(pc.x), fy0 = floorf(pc.y), fz0 = floorf(zg.x);
+                    const float wx1 = __fsub_rn(pc.x, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), pc.x);
+                    const float wy1 = __fsub_rn(pc.y, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.0f), pc.y);
+                    const float wz1 = __fsub_rn(zg.x, fz0), wz0 = __fsub_rn(__fadd_rn(fz0, 1.0f), zg.x);
+                    const float gmx = pc.x > 0.0f && pc.x < nxm ? 0.5f * nxm : 0.0f;  // d(i)/d(g): 0 on / outside the border
+                    const float gmy = pc.y > 0.0f && pc.y < nym ? 0.5f * nym : 0.0f;
+                    const float gmz = zg.x > 0.0f && zg.x < nzm ? 0.5f * nzm : 0.0f;
+                    const int ix0 = (int)fx0, iy0 = (int)fy0, iz0 = (int)fz0;
+                    // the "+1" corners are read unconditionally: where ATen clamps them (i0 = n-1) their weight is exactly 0 and
+                    // the ring holds a finite halo value there
+                    const int bx0 = ix0 - (ox - R), by0 = iy0 - (oy - R), rel = iz0 - zo;
+                    const bool in_ring = (unsigned)bx0 < (unsigned)(PX - 1) && (unsigned)by0 < (unsigned)(M::PY - 1) && rel >= -R && rel < R;
+                    float dot[2][2][2];
+                    if (in_ring) {
+                        int sl0 = ((a - R + NP) % NP) * PN, sl1 = ((a - R + 1 + NP) % NP) * PN;  // rel == -R
+#pragma unroll
+                        for (int q = -R + 1; q < R; ++q) {
+                            sl0 = rel == q ? ((a + q + NP) % NP) * PN : sl0;
+                            sl1 = rel == q ? ((a + q + 1 + NP) % NP) * PN : sl1;
+                        }
+                        const int off = by0 * PX + bx0;
+#pragma unroll
+                        for (int cz = 0; cz < 2; ++cz) {
+                            const int bs = (cz ? sl1 : sl0) + off;
+#pragma unroll
+                            for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                                for (int cx = 0; cx < 2; ++cx) {
+                                    const float2 v01 = q_d[bs + cy * PX + cx];
+                                    dot[cz][cy][cx] = fmaf(q_dz[bs + cy * PX + cx], G2, fmaf(v01.y, G1, v01.x * G0));
+                                }
+                        }
+                    } else {  // cannot happen while max|d| < R
 #pragma unroll
                         for (int cz = 0; cz < 2; ++cz)
 #pragma unroll
                             for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
                                 for (int cx = 0; cx < 2; ++cx) {
-                                    float v0, v1, v2;
-                                    fetch(cx, cy, cz, v0, v1, v2);
-                                    const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
-                                    const float dot = v0 * G0 + v1 * G1 + v2 * G2;
-                                    gix += (cx ? dot : -dot) * (wy * wz);
-                                    giy += (cy ? dot : -dot) * (wx * wz);
-                                    giz += (cz ? dot : -dot) * (wx * wy);
+                                    const int64_t idx = ((int64_t)min(iz0 + cz, vol.D - 1) * vol.H + min(iy0 + cy, vol.H - 1)) * vol.W + min(ix0 + cx, vol.W - 1);
+                                    dot[cz][cy][cx] = fmaf(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.inv_pow), G2,
+                                                           fmaf(ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.inv_pow), G1,
+                                                                ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.inv_pow) * G0));
                                 }
-                    };
-                    if (in_ring) {
-                        int slz[2];
-#pragma unroll
-                        for (int cz = 0; cz < 2; ++cz) {
-                            const int rel = (cz ? tz.i1 : tz.i0) - zo;  // in [-R, R]
-                            int sl = a * PN;
-#pragma unroll
-                            for (int q = -R; q <= R; ++q)
-                                if (q != 0) sl = rel == q ? ((a + q + NP) % NP) * PN : sl;
-                            slz[cz] = sl;
-                        }
-                        corners([&](int cx, int cy, int cz, float& v0, float& v1, float& v2) {
-                            const int ti = slz[cz] + (cy ? by1 : by0) * PX + (cx ? bx1 : bx0);
-                            const float2 v01 = q_d[ti];
-                            v0 = v01.x;
-                            v1 = v01.y;
-                            v2 = q_dz[ti];
-                        });
-                    } else {  // cannot happen while max|d| < R
-                        corners([&](int cx, int cy, int cz, float& v0, float& v1, float& v2) {
-                            const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
-                            v0 = ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.inv_pow);
-                            v1 = ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.inv_pow);
-                            v2 = ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.inv_pow);
-                        });
                     }
+                    // J^T G of the trilinear interpolant: differences of the corner dots along one axis, bilinear in the others
+                    const float wyz[2][2] = {{wy0 * wz0, wy1 * wz0}, {wy0 * wz1, wy1 * wz1}};  // [cz][cy]
+                    const float wxz[2][2] = {{wx0 * wz0, wx1 * wz0}, {wx0 * wz1, wx1 * wz1}};  // [cz][cx]
+                    const float wxy[2][2] = {{wx0 * wy0, wx1 * wy0}, {wx0 * wy1, wx1 * wy1}};  // [cy][cx]
+                    float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            gix = fmaf(wyz[u][w], dot[u][w][1] - dot[u][w][0], gix);
+                            giy = fmaf(wxz[u][w], dot[u][1][w] - dot[u][0][w], giy);
+                            giz = fmaf(wxy[u][w], dot[1][u][w] - dot[0][u][w], giz);
+                        }
                     const int64_t pl = (int64_t)zo * vol.H * vol.W;
                     const unsigned g = (unsigned)(y * vol.W + x) * 4u;
-                    st_off(o + pl, g, (G0 + tx.gmul * gix) + acc01[a].x);
-                    st_off(o + V + pl, g, (G1 + ty.gmul * giy) + acc01[a].y);
-                    st_off(o + 2 * V + pl, g, (G2 + tz.gmul * giz) + acc2[a]);
+                    st_off(o + pl, g, (G0 + gmx * gix) + acc01[a].x);
+                    st_off(o + V + pl, g, (G1 + gmy * giy) + acc01[a].y);
+                    st_off(o + 2 * V + pl, g, (G2 + gmz * giz) + acc2[a]);
                 }
                 acc01[a] = make_float2(0.0f, 0.0f);
                 acc2[a] = 0.0f;
