@@ -283,6 +283,10 @@ constexpr int MTX = 32, MTY = 8, kMarchBlock = MTX * MTY;
 #define IRS_MARCH_WAVES 3
 #endif
 
+// hat of (r + c) for a relative position r and a compile-time integer offset c.
+template <int R>
+__device__ __forceinline__ float rel_hat(float r, int c);
+
 // hat function max(0, 1 - |t|).  v_med3_f32 folds into the clamp output modifier of the subtraction (one VALU op);
 // HIP's __saturatef compiles to two compares and two selects.
 // load p[byte_off / 4] with the address formed as (uniform 64-bit base) + (32-bit lane byte offset): the global_load
@@ -295,6 +299,13 @@ __device__ __forceinline__ void st_off(float* __restrict__ base, unsigned byte_o
 }
 __device__ __forceinline__ float clamp01(float t) { return __builtin_amdgcn_fmed3f(t, 0.0f, 1.0f); }
 __device__ __forceinline__ float hat01(float t) { return clamp01(1.0f - fabsf(t)); }
+
+template <int R>
+__device__ __forceinline__ float rel_hat(float r, int c) {
+    if (R == 1 && c == 1) return clamp01(-r);
+    if (R == 1 && c == -1) return clamp01(r);
+    return c == 0 ? hat01(r) : hat01(r + (float)c);
+}
 
 template <bool PRESCALE, int R>
 struct March {
@@ -309,7 +320,9 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
     using M = March<PRESCALE, R>;
     constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
     // ring slot layout (9 floats per source, 8-byte fields so that the gather needs three ds_read_b64 per candidate):
-    //   q_xy = (px, py)   q_zg = (pz, G2)   q_g = (G0, G1)   q_d = (d0, d1)   q_dz = d2
+    //   q_xy = (rx, ry)   q_zg = (rz, G2)   q_g = (G0, G1)   q_d = (d0, d1)   q_dz = d2
+    // where r = clipped sampling position - the source's own coordinate (|r| <= max|d|): every hat weight of the
+    // gather is then a function of r plus a compile-time offset
     __shared__ float2 q_xy[NP * PN], q_zg[NP * PN], q_g[NP * PN], q_d[NP * PN];
     __shared__ float q_dz[NP * PN];
     // XCD-aware tile assignment: consecutive tiles (x fastest, then y, then z-segment, then chain) stay on one L2
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
 
     int sxy[NIT];
     bool sin_[NIT];
-    float slx[NIT], sly[NIT];
+    float slx[NIT], sly[NIT], sfx[NIT], sfy[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = threadIdx.x + it * kMarchBlock;
@@ -352,6 +365,8 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
         sxy[it] = i < PN ? cy * vol.W + cx : -1;
         slx[it] = lin.x[cx];
         sly[it] = lin.y[cy];
+        sfx[it] = (float)cx;
+        sfy[it] = (float)cy;
     }
     float pre[NIT][6];
     auto prefetch = [&](int s) {
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
     };
     auto commit = [&](int s, int slot) {  // registers -> ring slot (with the clipped sampling position)
         const bool zin = s >= 0 && s < vol.D;
-        const float lz_ = zin ? lin.z[s] : 0.0f;
+        const float lz_ = zin ? lin.z[s] : 0.0f, fs_ = (float)s;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
@@ -401,8 +416,8 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
             const float p0 = __builtin_amdgcn_fmed3f(qx, 0.0f, nxm), p1 = __builtin_amdgcn_fmed3f(qy, 0.0f, nym),
                         p2 = __builtin_amdgcn_fmed3f(qz, 0.0f, nzm);
             const float g0 = sin_[it] ? pre[it][3] : 0.0f, g1 = sin_[it] ? pre[it][4] : 0.0f, g2 = sin_[it] ? pre[it][5] : 0.0f;
-            q_xy[i] = make_float2(p0, p1);
-            q_zg[i] = make_float2(p2, g2);
+            q_xy[i] = make_float2(p0 - sfx[it], p1 - sfy[it]);
+            q_zg[i] = make_float2(p2 - fs_, g2);
             q_g[i] = make_float2(g0, g1);
             q_d[i] = make_float2(d0, d1);
             q_dz[i] = d2;
@@ -430,25 +445,24 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
             __syncthreads();
             // ---- contributions of source plane s to output planes s-R .. s+R
             if (s >= 0 && s < vol.D && col_in) {
-                const float fs = (float)s;
 #pragma unroll
                 for (int dy = 0; dy <= 2 * R; ++dy)
 #pragma unroll
                     for (int dx = 0; dx <= 2 * R; ++dx) {
                         const int ri = PH * PN + (ly + dy) * PX + (lx + dx);
-                        const float2 pxy = q_xy[ri], pzg = q_zg[ri], g01 = q_g[ri];
-                        const float hxy = hat01(pxy.x - fx) * hat01(pxy.y - fy);
-                        const float t = pzg.x - fs;  // offset of the sampling position from the source plane
+                        const float2 rxy = q_xy[ri], rzg = q_zg[ri], g01 = q_g[ri];
+                        // weight of source (x + dx - R, y + dy - R, s) on output (x, y, s + oo): hat(r + offset) per axis.
+                        // R == 1 guarantees |r| < 1 (variant selection by the displacement bound), where
+                        // hat(r + 1) = max(0, -r) and hat(r - 1) = max(0, r): one clamped op each
+                        const float hx = rel_hat<R>(rxy.x, dx - R), hy = rel_hat<R>(rxy.y, dy - R);
+                        const float hxy = hx * hy;
 #pragma unroll
                         for (int oo = -R; oo <= R; ++oo) {
                             const int a = (PH + oo + NP) % NP;  // accumulator of output plane s + oo (static index)
-                            // R == 1 guarantees |t| < 1 (variant selection by the displacement bound), where
-                            // hat(t + 1) = max(0, -t) and hat(t - 1) = max(0, t): one clamped op each, no offset add
-                            const float hz = R == 1 && oo != 0 ? clamp01(oo < 0 ? -t : t) : hat01(t - (float)oo);
-                            const float w = hxy * hz;
+                            const float w = hxy * rel_hat<R>(rzg.x, -oo);
                             acc01[a].x = fmaf(w, g01.x, acc01[a].x);
                             acc01[a].y = fmaf(w, g01.y, acc01[a].y);
-                            acc2[a] = fmaf(w, pzg.y, acc2[a]);
+                            acc2[a] = fmaf(w, rzg.y, acc2[a]);
                         }
                     }
             }
@@ -461,17 +475,19 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
                     // the sample this voxel took in the forward step: its clipped position is already in the ring
                     const float2 pc = q_xy[ci], zg = q_zg[ci], Gc01 = q_g[ci];
                     const float G0 = Gc01.x, G1 = Gc01.y, G2 = zg.y;
-                    const float fx0 = floorf(pc.x), fy0 = floorf(pc.y), fz0 = floorf(zg.x);
+                    const float fx0 = floorf(pc.x), fy0 = floorf(pc.y), fz0 = floorf(zg.x);  // of the RELATIVE position
                     const float wx1 = __fsub_rn(pc.x, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), pc.x);
                     const float wy1 = __fsub_rn(pc.y, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.0f), pc.y);
                     const float wz1 = __fsub_rn(zg.x, fz0), wz0 = __fsub_rn(__fadd_rn(fz0, 1.0f), zg.x);
-                    const float gmx = pc.x > 0.0f && pc.x < nxm ? 0.5f * nxm : 0.0f;  // d(i)/d(g): 0 on / outside the border
-                    const float gmy = pc.y > 0.0f && pc.y < nym ? 0.5f * nym : 0.0f;
-                    const float gmz = zg.x > 0.0f && zg.x < nzm ? 0.5f * nzm : 0.0f;
-                    const int ix0 = (int)fx0, iy0 = (int)fy0, iz0 = (int)fz0;
+                    const float pax = pc.x + fx, pay = pc.y + fy, paz = zg.x + (float)zo;  // absolute clipped position
+                    const float gmx = pax > 0.0f && pax < nxm ? 0.5f * nxm : 0.0f;  // d(i)/d(g): 0 on / outside the border
+                    const float gmy = pay > 0.0f && pay < nym ? 0.5f * nym : 0.0f;
+                    const float gmz = paz > 0.0f && paz < nzm ? 0.5f * nzm : 0.0f;
+                    const int rx0 = (int)fx0, ry0 = (int)fy0, rel = (int)fz0;
+                    const int ix0 = x + rx0, iy0 = y + ry0, iz0 = zo + rel;
                     // the "+1" corners are read unconditionally: where ATen clamps them (i0 = n-1) their weight is exactly 0 and
                     // the ring holds a finite halo value there
-                    const int bx0 = ix0 - (ox - R), by0 = iy0 - (oy - R), rel = iz0 - zo;
+                    const int bx0 = lx + R + rx0, by0 = ly + R + ry0;
                     const bool in_ring = (unsigned)bx0 < (unsigned)(PX - 1) && (unsigned)by0 < (unsigned)(M::PY - 1) && rel >= -R && rel < R;
                     float dot[2][2][2];
                     if (in_ring) {
