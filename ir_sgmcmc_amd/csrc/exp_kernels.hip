@@ -279,8 +279,11 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
 // Halo redundancy is (32+2R)(8+2R)/(32*8) in-plane only (1.33x for R=1, vs 1.66x for the 3-D tile).
 // ------------------------------------------------------------------------------------------------
 constexpr int MTX = 32, MTY = 8, kMarchBlock = MTX * MTY;
+#ifndef IRS_GATHER_UNROLL_Y
+#define IRS_GATHER_UNROLL_Y 1
+#endif
 #ifndef IRS_MARCH_WAVES
-#define IRS_MARCH_WAVES 3
+#define IRS_MARCH_WAVES 4
 #endif
 
 // hat of (r + c) for a relative position r and a compile-time integer offset c.
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
             __syncthreads();
             // ---- contributions of source plane s to output planes s-R .. s+R
             if (s >= 0 && s < vol.D && col_in) {
-#pragma unroll
+#pragma unroll IRS_GATHER_UNROLL_Y
                 for (int dy = 0; dy <= 2 * R; ++dy)
 #pragma unroll
                     for (int dx = 0; dx <= 2 * R; ++dx) {
