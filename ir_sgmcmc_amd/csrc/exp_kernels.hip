@@ -667,33 +667,35 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
                 const AxisTap tx = axis_tap(__fadd_rn(linx, d0), vol.W);
                 const AxisTap ty = axis_tap(__fadd_rn(liny, d1), vol.H);
                 const AxisTap tz = axis_tap(__fadd_rn(lin.z[zo], d2), vol.D);
-                const int bx0 = tx.i0 - (ox - R), bx1 = tx.i1 - (ox - R), by0 = ty.i0 - (oy - R), by1 = ty.i1 - (oy - R);
-                const bool in_ring = bx0 >= 0 && bx1 < PX && by0 >= 0 && by1 < M::PY && tz.i0 >= zo - R && tz.i1 <= zo + R;
+                // the "+1" corners are read unconditionally: where ATen clamps them (i0 = n-1) their weight is exactly 0 and the
+                // ring holds a finite (replicated) value there, so the product vanishes exactly
+                const int bx0 = tx.i0 - (ox - R), by0 = ty.i0 - (oy - R), rel = tz.i0 - zo;
+                const bool in_ring = (unsigned)bx0 < (unsigned)(PX - 1) && (unsigned)by0 < (unsigned)(M::PY - 1) && rel >= -R && rel < R;
                 float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
                 if (in_ring) {
                     // (wx * wy) is shared by the two z corners: same products, same rounding as ((wx * wy) * wz)
                     const float wxy[2][2] = {{__fmul_rn(tx.w0, ty.w0), __fmul_rn(tx.w1, ty.w0)},
                                              {__fmul_rn(tx.w0, ty.w1), __fmul_rn(tx.w1, ty.w1)}};
+                    // plane zo + q sits in ring slot (a + q) mod NS; with a compile-time `a` the slots are constants picked by `rel`
+                    int sl0 = ((a - R + NS) % NS) * PN, sl1 = ((a - R + 1 + NS) % NS) * PN;
+#pragma unroll
+                    for (int q = -R + 1; q < R; ++q) {
+                        sl0 = rel == q ? ((a + q + NS) % NS) * PN : sl0;
+                        sl1 = rel == q ? ((a + q + 1 + NS) % NS) * PN : sl1;
+                    }
+                    const int off = by0 * PX + bx0;
 #pragma unroll
                     for (int cz = 0; cz < 2; ++cz) {
-                        const int zz = cz ? tz.i1 : tz.i0;
-                        // plane zz of the volume sits in ring slot (a + (zz - zo)) mod NS; with a compile-time `a` the slot
-                        // of each of the 2R+1 candidate planes is a constant, picked by comparing zz - zo
-                        const int rel = zz - zo;
-                        int sl = a * PN;
-#pragma unroll
-                        for (int q = -R; q <= R; ++q)
-                            if (q != 0) sl = rel == q ? ((a + q + NS) % NS) * PN : sl;
+                        const int bs = (cz ? sl1 : sl0) + off;
 #pragma unroll
                         for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
                             for (int cx = 0; cx < 2; ++cx) {
                                 const float w = __fmul_rn(wxy[cy][cx], cz ? tz.w1 : tz.w0);
-                                const int ti = sl + (cy ? by1 : by0) * PX + (cx ? bx1 : bx0);
-                                const float2 txy = r_xy[ti];
+                                const float2 txy = r_xy[bs + cy * PX + cx];
                                 a0 = __fadd_rn(a0, __fmul_rn(txy.x, w));
                                 a1 = __fadd_rn(a1, __fmul_rn(txy.y, w));
-                                a2 = __fadd_rn(a2, __fmul_rn(r_z[ti], w));
+                                a2 = __fadd_rn(a2, __fmul_rn(r_z[bs + cy * PX + cx], w));
                             }
                     }
                 } else {
