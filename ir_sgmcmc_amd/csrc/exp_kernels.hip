@@ -577,20 +577,30 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
 // z-segment, keeps a ring of 2R+1 planes of d (3 floats per voxel: 12 KB for R = 1) in LDS, prefetches plane s+1 while
 // plane s-R is being interpolated, and reads its 24 taps from the ring (global memory only if a tap leaves the ring).
 // ------------------------------------------------------------------------------------------------
+// forward tile: 64 x 8 columns per 256-thread workgroup, FROWS = 2 output rows per thread.  The staging rate of a marching
+// kernel depends on the LENGTH of the row segments a tile reads (tools/bw_probe.hip, bare load -> LDS -> store skeleton with
+// a one-voxel halo: 32 x 8 -> 4.1 TB/s, 64 x 8 -> 4.8 TB/s, 128 x 4 -> 5.0 TB/s); 64 x 8 also has the smaller halo overhead
+// (1.29x vs 1.33x), and two rows per thread halve the barriers per output.
+constexpr int FTX = 64, FTY = 8, FROWS = 2, kFwdBlock = FTX * FTY / FROWS;
+template <int R>
+struct MarchF {
+    static constexpr int NP = 2 * R + 1, PX = FTX + 2 * R, PY = FTY + 2 * R, PN = PX * PY;
+    static constexpr int NIT = (PN + kFwdBlock - 1) / kFwdBlock;
+};
 template <bool PRESCALE, int R>
-__global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float* __restrict__ din, float* __restrict__ dout,
+__global__ __launch_bounds__(kFwdBlock) void exp_fwd_march_kernel(const float* __restrict__ din, float* __restrict__ dout,
                                                                     Vol vol, Lin lin, Scale3L sc,
                                                                     const unsigned* __restrict__ dmax_in,
                                                                     unsigned* __restrict__ dmax_out, int seg_len, int nseg,
                                                                     int h_lo, int h_hi, int swz_run) {
-    using M = March<PRESCALE, R>;
+    using M = MarchF<R>;
     constexpr int PX = M::PX, PN = M::PN, NIT = M::NIT;
     // ring of 2R+2 slots: one more than a sample can reach, so that the commit of the next source plane never overwrites
     // a plane another wavefront is still sampling -> ONE barrier per plane instead of two
     constexpr int NS = M::NP + 1;
     __shared__ float2 r_xy[NS * PN];  // (d0, d1): one ds_read_b64 per tap
     __shared__ float r_z[NS * PN];    // d2
-    __shared__ float red[3 * (kMarchBlock / kWave)];
+    __shared__ float red[3 * (kFwdBlock / kWave)];
     const int tile_ = xcd_swizzle_runs(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z, swz_run);
     const int tbx = tile_ % gridDim.x, tby = (tile_ / gridDim.x) % gridDim.y, tbz = tile_ / (gridDim.x * gridDim.y);
     const int chain = tbz / nseg, seg = tbz % nseg;
@@ -599,7 +609,7 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
                              (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 2])));
         if (need <= h_lo || need > h_hi) return;
     }
-    const int ox = tbx * MTX, oy = tby * MTY;
+    const int ox = tbx * FTX, oy = tby * FTY;
     const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
@@ -607,15 +617,14 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
     const float* __restrict__ dy_ = dx_ + V;
     const float* __restrict__ dz_ = dy_ + V;
     float* __restrict__ o = dout + cb;
-    const int lx = threadIdx.x % MTX, ly = threadIdx.x / MTX;
-    const int x = ox + lx, y = oy + ly;
-    const bool col_in = x < vol.W && y < vol.H;
-    const float linx = col_in ? lin.x[x] : 0.0f, liny = col_in ? lin.y[y] : 0.0f;
+    const int lx = threadIdx.x % FTX, ly0 = threadIdx.x / FTX;  // outputs (lx, ly0 + j * FTY / FROWS), j < FROWS
+    const int x = ox + lx;
+    const float linx = x < vol.W ? lin.x[x] : 0.0f;
 
     int sxy[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int i = threadIdx.x + it * kMarchBlock;
+        const int i = threadIdx.x + it * kFwdBlock;
         const int px = i % PX, py = i / PX;
         const int cx = min(max(ox - R + px, 0), vol.W - 1), cy = min(max(oy - R + py, 0), vol.H - 1);
         sxy[it] = i < PN ? cy * vol.W + cx : -1;
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
-            const int i = slot * PN + threadIdx.x + it * kMarchBlock;
+            const int i = slot * PN + threadIdx.x + it * kFwdBlock;
             r_xy[i] = make_float2(PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.inv_pow) : pre[it][0],
                                   PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.inv_pow) : pre[it][1]);
             r_z[i] = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.inv_pow) : pre[it][2];
@@ -659,14 +668,20 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
             if (s + 1 <= slast) prefetch(s + 1);
             __syncthreads();
             const int zo = s - R;
-            if (zo >= z0 && zo < z1 && col_in) {
+            if (zo >= z0 && zo < z1) {
+                const float linz = lin.z[zo];
+#pragma unroll
+                for (int j = 0; j < FROWS; ++j) {
+                const int ly = ly0 + j * (FTY / FROWS), y = oy + ly;
+                if (x >= vol.W || y >= vol.H) continue;
+                const float liny = lin.y[y];
                 const int a = (PH - R + NS) % NS;  // slot of plane zo (compile-time)
                 const int ci = a * PN + (ly + R) * PX + (lx + R);
                 const float2 dxy = r_xy[ci];
                 const float d0 = dxy.x, d1 = dxy.y, d2 = r_z[ci];
                 const AxisTap tx = axis_tap(__fadd_rn(linx, d0), vol.W);
                 const AxisTap ty = axis_tap(__fadd_rn(liny, d1), vol.H);
-                const AxisTap tz = axis_tap(__fadd_rn(lin.z[zo], d2), vol.D);
+                const AxisTap tz = axis_tap(__fadd_rn(linz, d2), vol.D);
                 // the "+1" corners are read unconditionally: where ATen clamps them (i0 = n-1) their weight is exactly 0 and the
                 // ring holds a finite (replicated) value there, so the product vanishes exactly
                 const int bx0 = tx.i0 - (ox - R), by0 = ty.i0 - (oy - R), rel = tz.i0 - zo;
@@ -721,6 +736,7 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
                 m0 = fmaxf(m0, fabsf(r0));
                 m1 = fmaxf(m1, fabsf(r1));
                 m2 = fmaxf(m2, fabsf(r2));
+                }
             }
         }
     }
@@ -737,14 +753,14 @@ __global__ __launch_bounds__(kMarchBlock) void exp_fwd_march_kernel(const float*
         const int wid = threadIdx.x / kWave;
         if ((threadIdx.x & (kWave - 1)) == 0) {
             red[wid] = m0;
-            red[(kMarchBlock / kWave) + wid] = m1;
-            red[2 * (kMarchBlock / kWave) + wid] = m2;
+            red[(kFwdBlock / kWave) + wid] = m1;
+            red[2 * (kFwdBlock / kWave) + wid] = m2;
         }
         __syncthreads();
         if (threadIdx.x < 3) {
             float m = 0.0f;
 #pragma unroll
-            for (int w = 0; w < kMarchBlock / kWave; ++w) m = fmaxf(m, red[threadIdx.x * (kMarchBlock / kWave) + w]);
+            for (int w = 0; w < kFwdBlock / kWave; ++w) m = fmaxf(m, red[threadIdx.x * (kFwdBlock / kWave) + w]);
             unsigned* slot = dmax_out + chain * 4 + threadIdx.x;
             if (__float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_nonneg(slot, m);
         }
@@ -756,11 +772,11 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     static const int seg_env = getenv("IRS_MARCH_SEG_FWD") ? atoi(getenv("IRS_MARCH_SEG_FWD")) : 32;
     const int seg_len = seg_env;
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
-    const dim3 grid((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
+    const dim3 grid((vol.W + FTX - 1) / FTX, (vol.H + FTY - 1) / FTY, (unsigned)(nseg * C));
     const Scale3L sc = make_scale_l(vol, no_steps);
     static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
     const int swz_run = swz_env >= 0 ? swz_env : (int)grid.x;
-#define IRS_FWM(P, RR, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), grid, dim3(kMarchBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run)
+#define IRS_FWM(P, RR, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), grid, dim3(kFwdBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run)
     if (!dmax_in) {  // no published bound: the radius-1 ring is correct for any displacement (far taps go to global memory)
         if (prescale_in) IRS_FWM(true, 1, -1, 1 << 30); else IRS_FWM(false, 1, -1, 1 << 30);
     } else if (prescale_in) { IRS_FWM(true, 1, -1, 1); IRS_FWM(true, 2, 1, 1 << 30); }
