@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libirsgmcmc.so')
+LIB_PATH = os.environ.get('IRS_LIB') or os.path.join(_HERE, 'csrc', 'libirsgmcmc.so')  # IRS_LIB: tuning builds
 
 IRS_MAX_COMPONENTS = 8
 IRS_MAX_CHAINS = 8

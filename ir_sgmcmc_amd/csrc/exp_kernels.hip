@@ -42,7 +42,7 @@ __device__ __forceinline__ void atomic_max_nonneg(unsigned* addr, float v) {
 struct TileGrid {
     int ntx, nty, ntz, total;  // tiles per axis, total over all chains
 };
-constexpr int kExpGridCap = 1024;  // also bounds the cost of a variant that is launched but not selected
+constexpr int kExpGridCap = 512;  // also bounds the cost of a variant that is launched but not selected
 
 template <int H>
 struct ExpBox {
@@ -177,6 +177,13 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
     using B = ExpBox<H>;
     __shared__ float lds[3 * B::SN];
     __shared__ float acc[3 * ETN];
+    {   // nothing to do for any chain (the usual case): leave before walking the tile list
+        const int chains = tg.total / (tg.ntx * tg.nty * tg.ntz);
+        bool any = false;
+        for (int c = 0; c < chains; ++c)
+            any |= (int)floorf(fmaxf(fmaxf(__uint_as_float(dmax[c * 4 + 0]), __uint_as_float(dmax[c * 4 + 1])), __uint_as_float(dmax[c * 4 + 2]))) + 1 > gather_radius;
+        if (!any) return;
+    }
   for (int tile = blockIdx.x; tile < tg.total; tile += gridDim.x) {
     int t_ = tile;
     const int ox = (t_ % tg.ntx) * ETX;
@@ -278,7 +285,11 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
 //   (taps from the ring) and store it.
 // Halo redundancy is (32+2R)(8+2R)/(32*8) in-plane only (1.33x for R=1, vs 1.66x for the 3-D tile).
 // ------------------------------------------------------------------------------------------------
-constexpr int MTX = 32, MTY = 8, kMarchBlock = MTX * MTY;
+#ifndef IRS_MTX
+#define IRS_MTX 32
+#define IRS_MTY 8
+#endif
+constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #ifndef IRS_GATHER_UNROLL_Y
 #define IRS_GATHER_UNROLL_Y 1
 #endif
@@ -317,9 +328,10 @@ struct March {
 };
 
 template <bool PRESCALE, int R>
-__global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp_bwd_march_kernel(
-    const float* __restrict__ G, const float* __restrict__ dk, float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
-    const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int swz_run) {
+__device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, const float* __restrict__ dk,
+                                                   float* __restrict__ gout, const Vol vol, const Lin lin, const Scale3L sc,
+                                                   const unsigned* __restrict__ dmax, const int seg_len, const int nseg,
+                                                   const int r_lo, const int swz_run, const int tile_id, const dim3 tiles) {
     using M = March<PRESCALE, R>;
     constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
     // ring slot layout (9 floats per source, 8-byte fields so that the gather needs three ds_read_b64 per candidate):
@@ -329,8 +341,8 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
     __shared__ float2 q_xy[NP * PN], q_zg[NP * PN], q_g[NP * PN], q_d[NP * PN];
     __shared__ float q_dz[NP * PN];
     // XCD-aware tile assignment: consecutive tiles (x fastest, then y, then z-segment, then chain) stay on one L2
-    const int tile_ = xcd_swizzle_runs(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z, swz_run);
-    const int tbx = tile_ % gridDim.x, tby = (tile_ / gridDim.x) % gridDim.y, tbz = tile_ / (gridDim.x * gridDim.y);
+    const int tile_ = xcd_swizzle_runs(tile_id, (int)(tiles.x * tiles.y * tiles.z), swz_run);
+    const int tbx = tile_ % tiles.x, tby = (tile_ / tiles.x) % tiles.y, tbz = tile_ / (tiles.x * tiles.y);
     const int chain = tbz / nseg, seg = tbz % nseg;
     {
         const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
@@ -552,22 +564,38 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
     }
 }
 
+// One tile per workgroup for the common radius-1 variant (XCD-aware order); the rarely selected variants are launched on a
+// small persistent grid that strides over the tiles, so that a launch whose variant is not selected costs ~2 us instead of
+// the dispatch of thousands of workgroups that exit at once.
+template <bool PRESCALE, int R>
+__global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp_bwd_march_kernel(
+    const float* __restrict__ G, const float* __restrict__ dk, float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
+    const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int swz_run, dim3 tiles) {
+    const int total = (int)(tiles.x * tiles.y * tiles.z);
+    for (int id = blockIdx.x; id < total; id += gridDim.x)
+        exp_bwd_march_tile<PRESCALE, R>(G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, r_lo, swz_run, id, tiles);
+}
+
+constexpr int kRareGrid = 512;  // persistent grid of the rarely selected variants (two workgroups per CU)
+
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, hipStream_t st) {
     static const int seg_env = getenv("IRS_MARCH_SEG") ? atoi(getenv("IRS_MARCH_SEG")) : 32;
     const int seg_len = seg_env;
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
-    const dim3 grid((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
+    const dim3 tiles((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
+    const int total = (int)(tiles.x * tiles.y * tiles.z);
     const Scale3L sc = make_scale_l(vol, no_steps);
     static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
-    const int swz_run = swz_env >= 0 ? swz_env : (int)grid.x;  // 0/1: no remap; default: one x-row of tiles per XCD run
-#define IRS_BWM(P, RR, LO) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), grid, dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, swz_run)
+    const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;  // 0/1: no remap; default: one x-row of tiles per XCD run
+#define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, (GRID) == total ? swz_run : 0, tiles)
+    const int rare = total < kRareGrid ? total : kRareGrid;
     if (prescale_in) {
-        IRS_BWM(true, 1, 0);
-        if (max_radius >= 2) IRS_BWM(true, 2, 1);
+        IRS_BWM(true, 1, 0, total);
+        if (max_radius >= 2) IRS_BWM(true, 2, 1, rare);
     } else {
-        IRS_BWM(false, 1, 0);
-        if (max_radius >= 2) IRS_BWM(false, 2, 1);
+        IRS_BWM(false, 1, 0, total);
+        if (max_radius >= 2) IRS_BWM(false, 2, 1, rare);
     }
 #undef IRS_BWM
 }
@@ -581,18 +609,23 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
 // kernel depends on the LENGTH of the row segments a tile reads (tools/bw_probe.hip, bare load -> LDS -> store skeleton with
 // a one-voxel halo: 32 x 8 -> 4.1 TB/s, 64 x 8 -> 4.8 TB/s, 128 x 4 -> 5.0 TB/s); 64 x 8 also has the smaller halo overhead
 // (1.29x vs 1.33x), and two rows per thread halve the barriers per output.
-constexpr int FTX = 64, FTY = 8, FROWS = 2, kFwdBlock = FTX * FTY / FROWS;
+#ifndef IRS_FTX
+#define IRS_FTX 64
+#define IRS_FTY 8
+#define IRS_FROWS 2
+#endif
+constexpr int FTX = IRS_FTX, FTY = IRS_FTY, FROWS = IRS_FROWS, kFwdBlock = FTX * FTY / FROWS;
 template <int R>
 struct MarchF {
     static constexpr int NP = 2 * R + 1, PX = FTX + 2 * R, PY = FTY + 2 * R, PN = PX * PY;
     static constexpr int NIT = (PN + kFwdBlock - 1) / kFwdBlock;
 };
 template <bool PRESCALE, int R>
-__global__ __launch_bounds__(kFwdBlock) void exp_fwd_march_kernel(const float* __restrict__ din, float* __restrict__ dout,
-                                                                    Vol vol, Lin lin, Scale3L sc,
-                                                                    const unsigned* __restrict__ dmax_in,
-                                                                    unsigned* __restrict__ dmax_out, int seg_len, int nseg,
-                                                                    int h_lo, int h_hi, int swz_run) {
+__device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din, float* __restrict__ dout, const Vol vol,
+                                                   const Lin lin, const Scale3L sc, const unsigned* __restrict__ dmax_in,
+                                                   unsigned* __restrict__ dmax_out, const int seg_len, const int nseg,
+                                                   const int h_lo, const int h_hi, const int swz_run, const int tile_id,
+                                                   const dim3 tiles) {
     using M = MarchF<R>;
     constexpr int PX = M::PX, PN = M::PN, NIT = M::NIT;
     // ring of 2R+2 slots: one more than a sample can reach, so that the commit of the next source plane never overwrites
@@ -601,8 +634,8 @@ __global__ __launch_bounds__(kFwdBlock) void exp_fwd_march_kernel(const float* _
     __shared__ float2 r_xy[NS * PN];  // (d0, d1): one ds_read_b64 per tap
     __shared__ float r_z[NS * PN];    // d2
     __shared__ float red[3 * (kFwdBlock / kWave)];
-    const int tile_ = xcd_swizzle_runs(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z, swz_run);
-    const int tbx = tile_ % gridDim.x, tby = (tile_ / gridDim.x) % gridDim.y, tbz = tile_ / (gridDim.x * gridDim.y);
+    const int tile_ = xcd_swizzle_runs(tile_id, (int)(tiles.x * tiles.y * tiles.z), swz_run);
+    const int tbx = tile_ % tiles.x, tby = (tile_ / tiles.x) % tiles.y, tbz = tile_ / (tiles.x * tiles.y);
     const int chain = tbz / nseg, seg = tbz % nseg;
     if (dmax_in) {
         const int need = max(max((int)ceilf(__uint_as_float(dmax_in[chain * 4 + 0])), (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 1]))),
@@ -767,20 +800,35 @@ __global__ __launch_bounds__(kFwdBlock) void exp_fwd_march_kernel(const float* _
     }
 }
 
+template <bool PRESCALE, int R>
+__global__ __launch_bounds__(kFwdBlock) void exp_fwd_march_kernel(const float* __restrict__ din, float* __restrict__ dout,
+                                                                  Vol vol, Lin lin, Scale3L sc,
+                                                                  const unsigned* __restrict__ dmax_in,
+                                                                  unsigned* __restrict__ dmax_out, int seg_len, int nseg,
+                                                                  int h_lo, int h_hi, int swz_run, dim3 tiles) {
+    const int total = (int)(tiles.x * tiles.y * tiles.z);
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+        exp_fwd_march_tile<PRESCALE, R>(din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, h_lo, h_hi, swz_run, id, tiles);
+        __syncthreads();  // the ring and the reduction scratch are reused by the next tile
+    }
+}
+
 void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
                                const unsigned* dmax_in, unsigned* dmax_out, hipStream_t st) {
     static const int seg_env = getenv("IRS_MARCH_SEG_FWD") ? atoi(getenv("IRS_MARCH_SEG_FWD")) : 32;
     const int seg_len = seg_env;
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
-    const dim3 grid((vol.W + FTX - 1) / FTX, (vol.H + FTY - 1) / FTY, (unsigned)(nseg * C));
+    const dim3 tiles((vol.W + FTX - 1) / FTX, (vol.H + FTY - 1) / FTY, (unsigned)(nseg * C));
+    const int total = (int)(tiles.x * tiles.y * tiles.z);
     const Scale3L sc = make_scale_l(vol, no_steps);
     static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
-    const int swz_run = swz_env >= 0 ? swz_env : (int)grid.x;
-#define IRS_FWM(P, RR, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), grid, dim3(kFwdBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run)
+    const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;
+#define IRS_FWM(P, RR, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), dim3(GRID), dim3(kFwdBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles)
+    const int rare = total < kRareGrid ? total : kRareGrid;
     if (!dmax_in) {  // no published bound: the radius-1 ring is correct for any displacement (far taps go to global memory)
-        if (prescale_in) IRS_FWM(true, 1, -1, 1 << 30); else IRS_FWM(false, 1, -1, 1 << 30);
-    } else if (prescale_in) { IRS_FWM(true, 1, -1, 1); IRS_FWM(true, 2, 1, 1 << 30); }
-    else { IRS_FWM(false, 1, -1, 1); IRS_FWM(false, 2, 1, 1 << 30); }
+        if (prescale_in) IRS_FWM(true, 1, -1, 1 << 30, total); else IRS_FWM(false, 1, -1, 1 << 30, total);
+    } else if (prescale_in) { IRS_FWM(true, 1, -1, 1, total); IRS_FWM(true, 2, 1, 1 << 30, rare); }
+    else { IRS_FWM(false, 1, -1, 1, total); IRS_FWM(false, 2, 1, 1 << 30, rare); }
 #undef IRS_FWM
 }
 
