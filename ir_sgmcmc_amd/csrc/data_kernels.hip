@@ -100,8 +100,7 @@ int stats_blocks(Vol vol) {
 
 void launch_stats(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, Vol vol,
                   hipStream_t st) {
-    hipLaunchKernelGGL(stats_kernel, dim3(stats_blocks(vol)), dim3(kBlock), 0, st, z, mask, (const DevState*)dev_state,
-                       want_vd, partials, vol);
+    launch_stats_march(want_vd, z, mask, dev_state, partials, stats_blocks(vol), vol, st);
 }
 
 // SSD residual z = F - M o phi (builder-defined data term)

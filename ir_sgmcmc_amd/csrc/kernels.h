@@ -91,6 +91,8 @@ void launch_sgld_update(float* v, const float* sigma, const float* g_d0, const f
                         float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st);
 void launch_gradient_operator(const float* v, float* nabla, int transformation, int C, Vol vol, hipStream_t st);
 void launch_log_det_jacobian(const float* t, float* log_det, long long* nan_count, int C, Vol vol, hipStream_t st);
+void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, int blocks,
+                        Vol vol, hipStream_t st);  // stencil_kernels.hip
 int stats_blocks(Vol vol);
 int energy_blocks(Vol vol);
 

@@ -607,4 +607,116 @@ void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* s
 #undef IRS_LCC_BWD
 }
 
+// ------------------------------------------------------------------------------------------------
+// Mixture statistics for virtual decimation and the GMM step (utils/util.py:330-347,446-485; trainer.py:68-77):
+// per masked voxel the VD-rescaled residual x and the responsibilities; sums of 1, x^2, the 2K GMM-gradient partials and the
+// lag-1 products x[i] x[i+1] along the three axes.  z-marching over 64 x 4 column tiles: the mixture is evaluated ONCE per
+// voxel (+ a one-voxel halo on the high x / y side and one run-out plane for the z pairs: 1.3 evaluations per voxel; the
+// pointwise version evaluated it for every neighbour again, up to 4 per voxel), the neighbours come from an LDS plane
+// (x, y) and a register (z).  partials: [gridDim.x][kStatVals], reduced by the scalar kernels in fixed order.
+// ------------------------------------------------------------------------------------------------
+constexpr int QTX = 64, QTY = 4, QPX = QTX + 1, QPN = QPX * (QTY + 1);
+
+__global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __restrict__ z, const uint8_t* __restrict__ mask,
+                                                               const DevState* __restrict__ state, int want_vd,
+                                                               double* __restrict__ partials, Vol vol, int seg_len, int nseg,
+                                                               int ntx, int nty) {
+    constexpr int NIT = (QPN + kStBlock - 1) / kStBlock;
+    __shared__ float X[QPN];
+    __shared__ double smem[kStatVals * (kStBlock / kWave)];
+    double acc[kStatVals];
+#pragma unroll
+    for (int j = 0; j < kStatVals; ++j) acc[j] = 0.0;
+    const int64_t HW = (int64_t)vol.H * vol.W;
+    const int lx = threadIdx.x % QTX, ly = threadIdx.x / QTX;
+    const int K = state->K;
+    const bool gmm = state->mode == IRS_DATA_GMM_LCC;
+    const int total = ntx * nty * nseg;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int ox = (tile % ntx) * QTX, oy = ((tile / ntx) % nty) * QTY, seg = tile / (ntx * nty);
+        const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
+        unsigned off[NIT];
+        bool valid[NIT], owned[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = threadIdx.x + it * kStBlock;
+            const int ex = i % QPX, ey = i / QPX;
+            const int gx = ox + ex, gy = oy + ey;
+            valid[it] = i < QPN && gx < vol.W && gy < vol.H;
+            owned[it] = valid[it] && ex < QTX && ey < QTY;
+            if (!want_vd) valid[it] = owned[it];  // no neighbour products: the halo is not needed
+            off[it] = valid[it] ? (unsigned)(gy * vol.W + gx) : 0u;
+        }
+        const int zend = want_vd && z1 < vol.D ? z1 + 1 : z1;  // one run-out plane closes the z pairs of the segment
+        float pz[NIT];
+        uint8_t pm[NIT];
+        auto load_plane = [&](int p) {
+            const int64_t zo = (int64_t)p * HW;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (valid[it]) {
+                    pm[it] = (mask + zo)[off[it]];
+                    pz[it] = (z + zo)[off[it]];
+                }
+        };
+        load_plane(z0);
+        float xprev = 0.0f;
+        for (int zc = z0; zc < zend; ++zc) {
+            const bool inseg = zc < z1;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + it * kStBlock;
+                float xv = 0.0f;
+                if (valid[it] && pm[it]) {
+                    if (owned[it] && inseg) {
+                        float resp[IRS_MAX_COMPONENTS], q[IRS_MAX_COMPONENTS];
+                        const MixEval e = mix_eval<true>(pz[it], state, resp, q);
+                        xv = e.x;
+                        acc[0] += 1.0;
+                        acc[1] += (double)(e.x * e.x);
+                        if (gmm) {
+#pragma unroll
+                            for (int k = 0; k < IRS_MAX_COMPONENTS; ++k)
+                                if (k < K) {
+                                    acc[5 + k] += (double)(resp[k] * (1.0f - q[k]));
+                                    acc[5 + IRS_MAX_COMPONENTS + k] += (double)resp[k];
+                                }
+                        }
+                    } else {
+                        xv = mix_eval<false>(pz[it], state, nullptr, nullptr).x;
+                    }
+                }
+                if (i < QPN) X[i] = xv;
+            }
+            if (zc + 1 < zend) load_plane(zc + 1);
+            __syncthreads();
+            if (want_vd) {
+                // lag-1 neighbours along D (reference "cov_x", dim 2), H (dim 3), W (dim 4); x = 0 off the mask / volume
+                const float own = X[ly * QPX + lx];
+                if (inseg) {
+                    acc[3] += (double)(own * X[(ly + 1) * QPX + lx]);
+                    acc[4] += (double)(own * X[ly * QPX + lx + 1]);
+                }
+                if (zc > z0) acc[2] += (double)(xprev * own);
+                xprev = own;
+            }
+            __syncthreads();
+        }
+    }
+    block_sum<kStatVals>(acc, smem);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int j = 0; j < kStatVals; ++j) partials[(int64_t)blockIdx.x * kStatVals + j] = acc[j];
+}
+
+void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, int blocks,
+                        Vol vol, hipStream_t st) {
+    static const int seg_env = getenv("IRS_STATS_SEG") ? atoi(getenv("IRS_STATS_SEG")) : 32;
+    const int seg_len = seg_env;
+    const int nseg = (vol.nz + seg_len - 1) / seg_len;
+    const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + QTY - 1) / QTY;
+    hipLaunchKernelGGL(stats_march_kernel, dim3(blocks), dim3(kStBlock), 0, st, z, mask, (const DevState*)dev_state, want_vd,
+                       partials, vol, seg_len, nseg, ntx, nty);
+}
+
 }  // namespace irs
