@@ -53,46 +53,6 @@ void launch_data_bwd(int mode, const float* fhat_or_fixed, int64_t f_stride, con
     launch_lcc_data_bwd_march(fhat_or_fixed, z, sigma_m, mask, g_z_override, dev_state, chain, g_warped, nll_partials, s, vol, st);
 }
 
-// ------------------------------------------------------------------------------------------------
-// per-chain statistics with the CURRENT mixture (before its Adam step): n_mask, sum x^2, the three lag-1 products
-// sum x(p) x(p + e_a) (utils/util.py:466-475), and the sums that make up d(NLL)/d(log_std_k), d(NLL)/d(log pi_k).
-// partials: [gridDim.x][kStatVals]
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void stats_kernel(const float* __restrict__ z, const uint8_t* __restrict__ mask,
-                                                       const DevState* __restrict__ state, int want_vd,
-                                                       double* __restrict__ partials, Vol vol) {
-    __shared__ double smem[kStatVals * (kBlock / kWave)];
-    double acc[kStatVals];
-#pragma unroll
-    for (int j = 0; j < kStatVals; ++j) acc[j] = 0.0;
-    const int64_t plane = (int64_t)vol.W * vol.H;
-    IRS_ROWS_BEGIN(vol, x, y, zc, v)
-        if (!mask[v]) continue;
-        float resp[IRS_MAX_COMPONENTS], q[IRS_MAX_COMPONENTS];
-        const MixEval e = mix_eval<true>(z[v], state, resp, q);
-        acc[0] += 1.0;
-        acc[1] += (double)(e.x * e.x);
-        if (state->mode == IRS_DATA_GMM_LCC) {
-#pragma unroll
-            for (int k = 0; k < IRS_MAX_COMPONENTS; ++k)
-                if (k < state->K) {
-                    acc[5 + k] += (double)(resp[k] * (1.0f - q[k]));
-                    acc[5 + IRS_MAX_COMPONENTS + k] += (double)resp[k];
-                }
-        }
-        if (want_vd) {
-            // lag-1 neighbours along D (reference "cov_x", dim 2), H (dim 3), W (dim 4)
-            if (zc + 1 < vol.D && mask[v + plane]) acc[2] += (double)(e.x * mix_eval<false>(z[v + plane], state, nullptr, nullptr).x);
-            if (y + 1 < vol.H && mask[v + vol.W]) acc[3] += (double)(e.x * mix_eval<false>(z[v + vol.W], state, nullptr, nullptr).x);
-            if (x + 1 < vol.W && mask[v + 1]) acc[4] += (double)(e.x * mix_eval<false>(z[v + 1], state, nullptr, nullptr).x);
-        }
-    IRS_ROWS_END
-    block_sum<kStatVals>(acc, smem);
-    if (threadIdx.x == 0)
-#pragma unroll
-        for (int j = 0; j < kStatVals; ++j) partials[(int64_t)blockIdx.x * kStatVals + j] = acc[j];
-}
-
 int stats_blocks(Vol vol) {
     const int64_t b = (vol.V + kBlock - 1) / kBlock;
     return (int)(b < kMaxPartialBlocks ? b : kMaxPartialBlocks);
