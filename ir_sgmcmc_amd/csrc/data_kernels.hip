@@ -106,32 +106,11 @@ void launch_masked_moments(const float* z, const uint8_t* mask, double* partials
 // regulariser energy y_c = sum over 3 components x 3 axes of (forward difference)^2, where the difference array is
 // replicate-padded, i.e. the last interior difference counts twice (utils/diff_op.py:83-85).  partials: [C][blocks]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void reg_energy_kernel(const float* __restrict__ v, double* __restrict__ partials,
-                                                            Vol vol) {
-    __shared__ double smem[kBlock / kWave];
-    const int64_t plane = (int64_t)vol.W * vol.H;
-    const float* f = v + (int64_t)blockIdx.y * 3 * vol.V;
-    double acc[1] = {0.0};
-    IRS_ROWS_BEGIN(vol, x, y, z, p)
-        float e = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float* fc = f + c * vol.V;
-            const float v0 = fc[p];
-            if (x + 1 < vol.W) { const float d = fc[p + 1] - v0; e += (x + 2 == vol.W ? 2.0f : 1.0f) * d * d; }
-            if (y + 1 < vol.H) { const float d = fc[p + vol.W] - v0; e += (y + 2 == vol.H ? 2.0f : 1.0f) * d * d; }
-            if (z + 1 < vol.D) { const float d = fc[p + plane] - v0; e += (z + 2 == vol.D ? 2.0f : 1.0f) * d * d; }
-        }
-        acc[0] += (double)e;
-    IRS_ROWS_END
-    block_sum<1>(acc, smem);
-    if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = acc[0];
-}
 
 int energy_blocks(Vol vol) { return stats_blocks(vol); }
 
 void launch_reg_energy(const float* v, double* partials, int C, Vol vol, hipStream_t st) {
-    hipLaunchKernelGGL(reg_energy_kernel, dim3(energy_blocks(vol), C), dim3(kBlock), 0, st, v, partials, vol);
+    launch_reg_energy_march(v, partials, energy_blocks(vol), C, vol, st);
 }
 
 // out[c] = sum_b partials[c][b] (fixed order) -- used by the stand-alone irs_reg_energy
@@ -167,42 +146,9 @@ void launch_reduce_partials(const double* partials, int nblocks, int nvals, doub
 // d(energy)/d(v_s) = 2 D^T D v_s with the last forward difference of each axis weighted twice.
 // The Sobolev backward is the identity (straight-through), so nothing else sits between v_s and v.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dtd_axis(const float* __restrict__ f, int64_t p, int pos, int n, int64_t stride) {
-    // sum over the axis' difference terms touching position `pos`: w_{pos-1} d_{pos-1} - w_pos d_pos
-    const float v0 = f[p];
-    float r = 0.0f;
-    if (pos >= 1) r += (pos - 1 == n - 2 ? 2.0f : 1.0f) * (v0 - f[p - stride]);
-    if (pos <= n - 2) r -= (pos == n - 2 ? 2.0f : 1.0f) * (f[p + stride] - v0);
-    return r;
-}
-
-__global__ __launch_bounds__(kBlock) void sgld_update_kernel(float* __restrict__ v, const float* __restrict__ sigma,
-                                                             const float* __restrict__ g, const float* __restrict__ v_s,
-                                                             const DevState* __restrict__ state, float lr, float s0,
-                                                             float s1, float s2, float* __restrict__ grad_out, Vol vol) {
-    IRS_VOXEL(vol, chain, x, y, z, p);
-    const int64_t cb = (int64_t)chain * 3 * vol.V;
-    const int64_t plane = (int64_t)vol.W * vol.H;
-    const float coef2 = 2.0f * (float)state->coef[chain];
-    const float sc[3] = {s0, s1, s2};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int64_t i = cb + c * vol.V + p;
-        const float* f = v_s + cb + c * vol.V;
-        const float lap = dtd_axis(f, p, x, vol.W, 1) + dtd_axis(f, p, y, vol.H, vol.W) + dtd_axis(f, p, z, vol.D, plane);
-        const float gr = g[i] * sc[c] + coef2 * lap;
-        const float sg = sigma ? sigma[i] : 1.0f;
-        const float gs = sg * sg * gr;  // SGLD.backward: sigma^2 * grad (utils/functions.py:83-84) == v.grad in the reference
-        if (grad_out) grad_out[i] = gs;
-        v[i] = v[i] - lr * gs;
-    }
-}
-
 void launch_sgld_update(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
                         float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st) {
-    const dim3 grid = vox_grid(vol, C);
-    hipLaunchKernelGGL(sgld_update_kernel, grid, dim3(kBlock), 0, st, v, sigma, g_d0, v_s, (const DevState*)dev_state, lr,
-                       s0, s1, s2, grad_out, vol);
+    launch_sgld_update_march(v, sigma, g_d0, v_s, dev_state, lr, s0, s1, s2, grad_out, C, vol, st);
 }
 
 // ------------------------------------------------------------------------------------------------

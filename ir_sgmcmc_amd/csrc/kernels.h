@@ -93,6 +93,9 @@ void launch_gradient_operator(const float* v, float* nabla, int transformation, 
 void launch_log_det_jacobian(const float* t, float* log_det, long long* nan_count, int C, Vol vol, hipStream_t st);
 void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, int blocks,
                         Vol vol, hipStream_t st);  // stencil_kernels.hip
+void launch_reg_energy_march(const float* v, double* partials, int blocks, int C, Vol vol, hipStream_t st);
+void launch_sgld_update_march(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
+                              float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st);
 int stats_blocks(Vol vol);
 int energy_blocks(Vol vol);
 

@@ -719,4 +719,200 @@ void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const 
                        partials, vol, seg_len, nseg, ntx, nty);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Regulariser energy y_c = sum over the 9 forward differences of v_s, the replicated last difference counted twice
+// (model/loss.py:152-161, utils/diff_op.py:62-96).  z-marching over 64 x 4 column tiles: every value is read once
+// (+ a one-voxel halo on the high x / y side), the x / y neighbours come from an LDS plane, the z neighbour from a register.
+// partials: [C][gridDim.x]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kStBlock) void reg_energy_march_kernel(const float* __restrict__ v, double* __restrict__ partials,
+                                                                    Vol vol, int seg_len, int nseg, int ntx, int nty) {
+    constexpr int NIT = (QPN + kStBlock - 1) / kStBlock;
+    __shared__ float F[3 * QPN];
+    __shared__ double smem[kStBlock / kWave];
+    const float* __restrict__ f = v + (int64_t)blockIdx.y * 3 * vol.V;
+    const int64_t HW = (int64_t)vol.H * vol.W;
+    const int lx = threadIdx.x % QTX, ly = threadIdx.x / QTX;
+    double acc[1] = {0.0};
+    const int total = ntx * nty * nseg;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int ox = (tile % ntx) * QTX, oy = ((tile / ntx) % nty) * QTY, seg = tile / (ntx * nty);
+        const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
+        const int x = ox + lx, y = oy + ly;
+        const bool col_in = x < vol.W && y < vol.H;
+        const float wx = x + 1 < vol.W ? (x + 2 == vol.W ? 2.0f : 1.0f) : 0.0f;
+        const float wy = y + 1 < vol.H ? (y + 2 == vol.H ? 2.0f : 1.0f) : 0.0f;
+        unsigned off[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = threadIdx.x + it * kStBlock;
+            const int ex = i % QPX, ey = i / QPX;
+            off[it] = (unsigned)(min(oy + ey, vol.H - 1) * vol.W + min(ox + ex, vol.W - 1)) * 4u;
+        }
+        float pre[NIT][3];
+        auto load_plane = [&](int p) {
+            const float* __restrict__ base = f + (int64_t)p * HW;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (threadIdx.x + it * kStBlock < QPN) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) pre[it][c] = ldg_off(base + c * vol.V, off[it]);
+                }
+        };
+        const int zend = z1 < vol.D ? z1 + 1 : z1;  // one run-out plane closes the z differences of the segment
+        load_plane(z0);
+        float prev[3] = {0.0f, 0.0f, 0.0f};
+        for (int zc = z0; zc < zend; ++zc) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + it * kStBlock;
+                if (i < QPN) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) F[c * QPN + i] = pre[it][c];
+                }
+            }
+            if (zc + 1 < zend) load_plane(zc + 1);
+            __syncthreads();
+            if (col_in) {
+                const bool inseg = zc < z1;
+                const float wz = zc > z0 ? (zc + 1 == vol.D ? 2.0f : 1.0f) : 0.0f;  // weight of the difference (zc - 1, zc)
+                float e = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v0 = F[c * QPN + ly * QPX + lx];
+                    if (inseg) {
+                        const float dx = F[c * QPN + ly * QPX + lx + 1] - v0, dy = F[c * QPN + (ly + 1) * QPX + lx] - v0;
+                        e += wx * dx * dx;
+                        e += wy * dy * dy;
+                    }
+                    const float dz = v0 - prev[c];
+                    e += wz * dz * dz;
+                    prev[c] = v0;
+                }
+                acc[0] += (double)e;
+            }
+            __syncthreads();
+        }
+    }
+    block_sum<1>(acc, smem);
+    if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = acc[0];
+}
+
+void launch_reg_energy_march(const float* v, double* partials, int blocks, int C, Vol vol, hipStream_t st) {
+    const int seg_len = 32;
+    const int nseg = (vol.nz + seg_len - 1) / seg_len;
+    const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + QTY - 1) / QTY;
+    hipLaunchKernelGGL(reg_energy_march_kernel, dim3(blocks, C), dim3(kStBlock), 0, st, v, partials, vol, seg_len, nseg, ntx, nty);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SGLD / SGD update (trainer.py:341-356; utils/functions.py:83-84):
+//   grad_v = sigma^2 (g_data * s_c + 2 coef D^T D v_s),   v <- v - lr grad_v
+// D^T D is the adjoint of the forward-difference stencil with the replicated (double-weight) last difference.  The
+// Sobolev backward is the identity, so nothing else sits between v_s and v.  z-marching over 64 x 4 column tiles: v_s
+// goes through an LDS ring of planes (one-voxel halo), the other streams are read and written once, coalesced.
+// ------------------------------------------------------------------------------------------------
+constexpr int UPX = QTX + 2, UPY = QTY + 2, UPN = UPX * UPY, UNS = 4;
+
+__global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __restrict__ v, const float* __restrict__ sigma,
+                                                                     const float* __restrict__ g, const float* __restrict__ v_s,
+                                                                     const DevState* __restrict__ state, float lr, float s0,
+                                                                     float s1, float s2, float* __restrict__ grad_out, Vol vol,
+                                                                     int seg_len, int nseg, int ntx, int nty) {
+    constexpr int NIT = (UPN + kStBlock - 1) / kStBlock;
+    __shared__ float F[UNS * 3 * UPN];
+    const int tile = blockIdx.x;
+    const int chain = tile / (ntx * nty * nseg);
+    const int t_ = tile % (ntx * nty * nseg);
+    const int ox = (t_ % ntx) * QTX, oy = ((t_ / ntx) % nty) * QTY, seg = t_ / (ntx * nty);
+    const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
+    const int64_t HW = (int64_t)vol.H * vol.W;
+    const int64_t cb = (int64_t)chain * 3 * vol.V;
+    const float* __restrict__ f = v_s + cb;
+    const int lx = threadIdx.x % QTX, ly = threadIdx.x / QTX;
+    const int x = ox + lx, y = oy + ly;
+    const bool col_in = x < vol.W && y < vol.H;
+    const float coef2 = 2.0f * (float)state->coef[chain];
+    const float sc[3] = {s0, s1, s2};
+    // weights of the two difference terms touching a position: w(q) = 2 for the last (replicated) difference q = n - 2
+    auto wm = [](int pos, int n) { return pos >= 1 ? (pos - 1 == n - 2 ? 2.0f : 1.0f) : 0.0f; };
+    auto wp = [](int pos, int n) { return pos <= n - 2 ? (pos == n - 2 ? 2.0f : 1.0f) : 0.0f; };
+    const float wxm = wm(x, vol.W), wxp = wp(x, vol.W), wym = wm(y, vol.H), wyp = wp(y, vol.H);
+
+    unsigned off[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * kStBlock;
+        const int ex = i % UPX, ey = i / UPX;
+        off[it] = (unsigned)(min(max(oy - 1 + ey, 0), vol.H - 1) * vol.W + min(max(ox - 1 + ex, 0), vol.W - 1)) * 4u;
+    }
+    float pre[NIT][3];
+    auto load_plane = [&](int p) {
+        const float* __restrict__ base = f + (int64_t)min(max(p, 0), vol.D - 1) * HW;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (threadIdx.x + it * kStBlock < UPN) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pre[it][c] = ldg_off(base + c * vol.V, off[it]);
+            }
+    };
+    auto commit = [&](int p) {
+        const int slot = ((p % UNS) + UNS) % UNS;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = threadIdx.x + it * kStBlock;
+            if (i < UPN) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) F[(slot * 3 + c) * UPN + i] = pre[it][c];
+            }
+        }
+    };
+    load_plane(z0 - 1);
+    commit(z0 - 1);
+    load_plane(z0);
+    commit(z0);
+    load_plane(z0 + 1);
+    const unsigned own = col_in ? (unsigned)(y * vol.W + x) * 4u : 0u;
+    for (int zc = z0; zc < z1; ++zc) {
+        commit(zc + 1);
+        if (zc + 1 < z1) load_plane(zc + 2);
+        __syncthreads();  // ring of 4: plane zc + 1 landed in the slot of plane zc - 3, which nobody reads any more
+        if (col_in) {
+            const int sm = (((zc - 1) % UNS) + UNS) % UNS, s0_ = ((zc % UNS) + UNS) % UNS, sp = (((zc + 1) % UNS) + UNS) % UNS;
+            const float wzm = wm(zc, vol.D), wzp = wp(zc, vol.D);
+            const int ci = (ly + 1) * UPX + lx + 1;
+            const int64_t pl = (int64_t)zc * HW;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* __restrict__ P = F + (s0_ * 3 + c) * UPN;
+                const float v0 = P[ci];
+                float rx = wxm * (v0 - P[ci - 1]);
+                rx -= wxp * (P[ci + 1] - v0);
+                float ry = wym * (v0 - P[ci - UPX]);
+                ry -= wyp * (P[ci + UPX] - v0);
+                float rz = wzm * (v0 - F[(sm * 3 + c) * UPN + ci]);
+                rz -= wzp * (F[(sp * 3 + c) * UPN + ci] - v0);
+                const float lap = rx + ry + rz;
+                const int64_t base = cb + c * vol.V + pl;
+                const float gr = ldg_off(g + base, own) * sc[c] + coef2 * lap;
+                const float sg = sigma ? ldg_off(sigma + base, own) : 1.0f;
+                const float gs = sg * sg * gr;  // SGLD.backward: sigma^2 * grad == v.grad in the reference
+                float* __restrict__ vp = reinterpret_cast<float*>(reinterpret_cast<char*>(v + base) + own);
+                if (grad_out) *reinterpret_cast<float*>(reinterpret_cast<char*>(grad_out + base) + own) = gs;
+                *vp = *vp - lr * gs;
+            }
+        }
+    }
+}
+
+void launch_sgld_update_march(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
+                              float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st) {
+    static const int seg_env = getenv("IRS_UPDATE_SEG") ? atoi(getenv("IRS_UPDATE_SEG")) : 32;
+    const int seg_len = seg_env;
+    const int nseg = (vol.nz + seg_len - 1) / seg_len;
+    const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + QTY - 1) / QTY;
+    hipLaunchKernelGGL(sgld_update_march_kernel, dim3((unsigned)(ntx * nty * nseg * C)), dim3(kStBlock), 0, st, v, sigma, g_d0,
+                       v_s, (const DevState*)dev_state, lr, s0, s1, s2, grad_out, vol, seg_len, nseg, ntx, nty);
+}
+
 }  // namespace irs
