@@ -35,12 +35,11 @@ __device__ __forceinline__ void atomic_max_bits(unsigned* slot, float m) {  // m
 // SobolevGrad.forward (utils/functions.py:98-109, utils/util.py:394-404): replicate-pad by S, then the (2S+1)-tap
 // 1-D kernel along z, then y, then x (the reference's order; each pass accumulates taps in index order with fmaf,
 // exactly like the per-axis kernel conv_axis_kernel, so the three implementations are bit-identical).
-// Tile 32 x 16 columns (two outputs per thread); the z pass runs on the tile + S halo columns (1.63x for S = 3).
+// Tile SMX x SMY columns, SMX * SMY / 256 outputs per thread; the z pass runs on the tile + S halo columns.
 // Optionally publishes max|v_s| / 2^steps per channel = the displacement bound of d_0 in voxels (exp_kernels.hip).
 // ------------------------------------------------------------------------------------------------
-constexpr int SMX = 32, SMY = 16;
 
-template <int S>
+template <int S, int SMX, int SMY>
 __global__ __launch_bounds__(kStBlock) void sobolev_march_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                  Taps taps, Vol vol, unsigned* __restrict__ dmax0,
                                                                  float inv_pow, int seg_len, int nseg) {
@@ -80,7 +79,9 @@ __global__ __launch_bounds__(kStBlock) void sobolev_march_kernel(const float* __
         const int j = threadIdx.x + it * kStBlock;
         ybase[it] = j < NY ? j : -1;  // P1 index of tap 0 is the same j: row qy + t of P1 <-> output row qy of P2
     }
-    const int lx = threadIdx.x % SMX, ly = threadIdx.x / SMX;  // ly in [0, 8): outputs (lx, ly) and (lx, ly + 8)
+    constexpr int NOUT = SMX * SMY / kStBlock, ROWS = kStBlock / SMX;  // outputs per thread: rows ly + o * ROWS
+    static_assert(SMX * SMY % kStBlock == 0 && kStBlock % SMX == 0, "tile shape");
+    const int lx = threadIdx.x % SMX, ly = threadIdx.x / SMX;
 
     float win[NIT][NT];
     auto load_plane = [&](int p, float (&dstv)[NIT]) {
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(kStBlock) void sobolev_march_kernel(const float* __
         }
         __syncthreads();
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const int yy = ly + o * (SMY / 2);
+        for (int o = 0; o < NOUT; ++o) {
+            const int yy = ly + o * ROWS;
             const int gx = ox + lx, gy = oy + yy;
             if (gx >= vol.W || gy >= vol.H) continue;
             float acc = 0.0f;
@@ -161,9 +162,19 @@ void launch_sobolev_march(const float* in, float* out, const Taps& taps, int pla
     static const int seg_env = getenv("IRS_SOBOLEV_SEG") ? atoi(getenv("IRS_SOBOLEV_SEG")) : 32;
     const int seg_len = seg_env;
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
-    const dim3 grid((vol.W + SMX - 1) / SMX, (vol.H + SMY - 1) / SMY, (unsigned)(nseg * planes));
     const float inv_pow = 1.0f / (float)(1 << no_steps);
-#define IRS_SOB(SS) hipLaunchKernelGGL((sobolev_march_kernel<SS>), grid, dim3(kStBlock), 0, st, in, out, taps, vol, dmax0, inv_pow, seg_len, nseg)
+    // big tiles (64 x 32, eight outputs per thread: 1.33x halo work in the z pass, a quarter of the barriers per output)
+    // when they still fill the GPU, 32 x 16 otherwise
+    const int64_t big_blocks = (int64_t)((vol.W + 63) / 64) * ((vol.H + 31) / 32) * nseg * planes;
+    const char* force = getenv("IRS_SOBOLEV_TILE");  // "big" / "small": used by the parity test of the two shapes
+    const bool big = force ? force[0] == 'b' : big_blocks >= 512;
+    const int tx = big ? 64 : 32, ty = big ? 32 : 16;
+    const dim3 grid((vol.W + tx - 1) / tx, (vol.H + ty - 1) / ty, (unsigned)(nseg * planes));
+#define IRS_SOB(SS)                                                                                                        \
+    if (big) hipLaunchKernelGGL((sobolev_march_kernel<SS, 64, 32>), grid, dim3(kStBlock), 0, st, in, out, taps, vol, dmax0, \
+                                inv_pow, seg_len, nseg);                                                                   \
+    else hipLaunchKernelGGL((sobolev_march_kernel<SS, 32, 16>), grid, dim3(kStBlock), 0, st, in, out, taps, vol, dmax0,    \
+                            inv_pow, seg_len, nseg)
     switch (taps.s) {
         case 1: IRS_SOB(1); break;
         case 2: IRS_SOB(2); break;

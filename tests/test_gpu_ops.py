@@ -43,6 +43,23 @@ def test_perturb_smooth(dims, s):
     assert maxdiff(out, 27.0 * ones) < 1e-4
 
 
+@pytest.mark.parametrize('s', [1, 2, 3])
+def test_sobolev_tile_shapes(s, monkeypatch):
+    """The Sobolev kernel picks a 64x32 or a 32x16 column tile from the volume size; both must agree with the oracle (and
+    with each other bit for bit -- same tap order) on a ragged volume that leaves every tile edge partially filled."""
+    dims = (37, 45, 70)
+    g = torch.Generator().manual_seed(5)
+    v = torch.randn(1, 3, *dims, generator=g)
+    k = G.sobolev_kernel_1d(s, 0.5)
+    ref = O.separable_conv3d_replicate(v, k)
+    outs = {}
+    for shape in ('small', 'big'):
+        monkeypatch.setenv('IRS_SOBOLEV_TILE', shape)
+        outs[shape] = G.perturb_smooth(dev(v), k)
+        assert maxdiff(outs[shape], ref) < 2e-6
+    assert torch.equal(outs['small'], outs['big'])
+
+
 def test_philox_noise_statistics():
     v = torch.zeros(1, 3, 64, 64, 64, device=DEV)
     a = G.perturb_smooth(v, None, tau=0.5, seed=7, iteration=3)   # sqrt(2 tau) = 1 -> N(0,1)
