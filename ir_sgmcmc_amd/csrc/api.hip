@@ -84,6 +84,8 @@ struct irs_ctx {
     double *stat_partials, *energy_partials, *nll_partials;
     double *stat_sum, *energy_sum, *nll_sum;  // reduced partial sums (staged / slab path)
     unsigned* dmax;  // [no_steps][C][4] max |d_k| in voxels per axis (float bits), by-product of the forward steps
+    unsigned* hint = nullptr;  // pinned host copy of dmax as of the last finished transition (written by finalize_kernel, read
+                     // by the host WITHOUT synchronisation: a hint that only decides which variants are launched)
     DevState* state;
     int fhat_chains;
     bool fixed_set;
@@ -91,6 +93,32 @@ struct irs_ctx {
     hipEvent_t ev[8];
     hipEvent_t ev_bwd[64];
 };
+
+namespace {
+constexpr int kHintWords = 4 * IRS_MAX_CHAINS * 32;  // same extent as the dmax scratch
+
+// Host-side guess of "max |d_k| stays well below one voxel" from the bounds of the last transition the host has seen
+// finish (never waited for: stale by a transition or two, and displacements move by O(lr) per transition).  Only a launch
+// decision for the FORWARD step k: when true, the radius-1 kernel is launched alone -- it is correct for any displacement
+// (taps that leave its LDS ring are read from global memory), so a wrong guess costs time, not parity.  The adjoint keeps
+// launching every variant: an in-kernel generic fallback for its radius-1 kernel was measured to cost more (7 % on
+// every launch, from the larger kernel) than the two idle launches it saves.
+bool predicted_small(const irs_ctx* c, int k) {
+    const int mode = env_int("IRS_PREDICT_VARIANTS", 1);  // 0: always launch every variant; 2: always predict small (tests)
+    if (mode == 2) return true;
+    if (!mode || !c->hint) return false;
+    const volatile unsigned* h = c->hint + (size_t)k * c->C * 4;
+    float m = 0.0f;
+    for (int i = 0; i < c->C * 4; ++i) {
+        const unsigned bits = h[i];
+        float f;
+        memcpy(&f, &bits, sizeof(f));
+        if (!(f >= 0.0f)) return false;  // NaN / garbage
+        m = f > m ? f : m;
+    }
+    return m < 0.75f;
+}
+}  // namespace
 
 extern "C" {
 
@@ -153,7 +181,7 @@ int irs_svf_exp_fwd(const float* v, float* steps, float* transformation, float* 
     const int64_t field = (int64_t)C * 3 * vol.V;
     for (int k = 0; k < no_steps; ++k) {
         const float* in = k == 0 ? v : steps + (int64_t)(k - 1) * field;
-        if (use_lds_exp()) launch_exp_step_fwd_march(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, nullptr, nullptr, st);
+        if (use_lds_exp()) launch_exp_step_fwd_march(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, nullptr, nullptr, false, st);
         else launch_exp_step_fwd(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, st);
     }
     if (transformation || displacement)
@@ -513,6 +541,9 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
     }
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 64 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev_bwd[i]);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->hint, sizeof(unsigned) * kHintWords, hipHostMallocDefault);
+    if (e == hipSuccess)
+        for (int i = 0; i < kHintWords; ++i) c->hint[i] = 0x7f800000u;  // +inf: nothing known yet, launch every variant
     if (e != hipSuccess) {
         (void)hipFree(c->slab);
         delete c;
@@ -530,6 +561,7 @@ void irs_destroy(irs_ctx* c) {
     for (int i = 0; i < 64; ++i)
         if (c->ev_bwd[i]) (void)hipEventDestroy(c->ev_bwd[i]);
     if (c->lin.dev) (void)hipFree(c->lin.dev);
+    if (c->hint) (void)hipHostFree(c->hint);
     if (c->slab) (void)hipFree(c->slab);
     delete c;
 }
@@ -632,7 +664,7 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
         float* out = c->steps + (int64_t)k * field;
         if (lds)
             launch_exp_step_fwd_march(in, out, k == 0, cfg.no_steps, C, c->vol, lin, c->dmax + (int64_t)k * c->C * 4,
-                                      c->dmax + (int64_t)(k + 1) * c->C * 4, st);
+                                      c->dmax + (int64_t)(k + 1) * c->C * 4, predicted_small(c, k), st);
         else launch_exp_step_fwd(in, out, k == 0, cfg.no_steps, C, c->vol, lin, st);
     }
     if (timed) HIP_TRY(hipEventRecord(c->ev[2], st));
@@ -746,7 +778,8 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     } else {
         launch_sgld_update(io->v, io->sigma, g0, vs, c->state, cfg.lr, s[0], s[1], s[2], io->grad_v, C, volv, st);
     }
-    launch_finalize(c->state, c->nll_partials, c->nll_blocks, c->dcfg, true, st);
+    launch_finalize(c->state, c->nll_partials, c->nll_blocks, c->dcfg, true, use_lds_exp() ? c->dmax : nullptr, c->hint,
+                    4 * C * (cfg.no_steps + 1), st);
     LAUNCH_CHECK();
     if (timed) HIP_TRY(hipEventRecord(c->ev[5], st));
     return 0;
@@ -830,7 +863,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
         case IRS_ST_EXP_FWD: {
             const float* in = k == 0 ? vs : c->steps + (int64_t)(k - 1) * field;
             launch_exp_step_fwd_march(in, c->steps + (int64_t)k * field, k == 0, cfg.no_steps, C, w, lin, c->dmax + (int64_t)k * C * 4,
-                                      c->dmax + (int64_t)(k + 1) * C * 4, st);
+                                      c->dmax + (int64_t)(k + 1) * C * 4, false, st);
             break;
         }
         case IRS_ST_OUTPUTS:
@@ -890,7 +923,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
             break;
         }
         case IRS_ST_FINALIZE:
-            launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, st);
+            launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, nullptr, nullptr, 0, st);
             break;
         default:
             return fail("irs_stage: unknown stage %d", stage);

@@ -347,7 +347,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     {
         const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
                            (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
-        if (hs > R || hs <= r_lo) return;
+        if (hs > R || hs <= r_lo) return;  // another variant of this step owns the chain
     }
     const int ox = tbx * MTX, oy = tby * MTY;
     const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(kFwdBlock) void exp_fwd_march_kernel(const float* _
 }
 
 void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
-                               const unsigned* dmax_in, unsigned* dmax_out, hipStream_t st) {
+                               const unsigned* dmax_in, unsigned* dmax_out, bool only_r1, hipStream_t st) {
     static const int seg_env = getenv("IRS_MARCH_SEG_FWD") ? atoi(getenv("IRS_MARCH_SEG_FWD")) : 32;
     const int seg_len = seg_env;
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
@@ -825,7 +825,7 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;
 #define IRS_FWM(P, RR, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), dim3(GRID), dim3(kFwdBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles)
     const int rare = total < kRareGrid ? total : kRareGrid;
-    if (!dmax_in) {  // no published bound: the radius-1 ring is correct for any displacement (far taps go to global memory)
+    if (!dmax_in || only_r1) {  // no bound / predicted small: the radius-1 ring is correct for any displacement (far taps go to global memory)
         if (prescale_in) IRS_FWM(true, 1, -1, 1 << 30, total); else IRS_FWM(false, 1, -1, 1 << 30, total);
     } else if (prescale_in) { IRS_FWM(true, 1, -1, 1, total); IRS_FWM(true, 2, 1, 1 << 30, rare); }
     else { IRS_FWM(false, 1, -1, 1, total); IRS_FWM(false, 2, 1, 1 << 30, rare); }

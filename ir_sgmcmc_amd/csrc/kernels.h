@@ -53,7 +53,7 @@ void launch_scale_channels(const float* in, float* out, float s0, float s1, floa
 // ---- exp_kernels.hip (z-marching squaring step + owner-computes gather adjoint, LDS-scatter fallback)
 // dmax_in: published bound of the input field (nullptr = unknown), dmax_out: receives the bound of the output field
 void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale, int no_steps, int C, Vol vol, Lin lin,
-                               const unsigned* dmax_in, unsigned* dmax_out, hipStream_t st);
+                               const unsigned* dmax_in, unsigned* dmax_out, bool only_r1, hipStream_t st);
 // the adjoint is launched as a set: gather radius 1, gather radius 2 and the scatter fallback; exactly one of them does
 // the work, chosen on the device from the bound max|d_k|
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,

@@ -95,6 +95,7 @@ void launch_chain_scalar(DevState* s, const double* stat_partials, int nblocks, 
                          hipStream_t st);
 void launch_reg_scalar(DevState* s, const double* energy_partials, int nblocks, DevCfg cfg, hipStream_t st);
 void launch_finalize(DevState* s, const double* nll_partials, int nblocks_per_chain, DevCfg cfg, bool advance,
+                     const unsigned* bounds, unsigned* hint, int nbounds,
                      hipStream_t st);
 void launch_gmm_init_from_moments(DevState* s, const double* moment_partials, int nblocks, DevCfg cfg, hipStream_t st);
 

@@ -197,8 +197,14 @@ void launch_reg_scalar(DevState* s, const double* energy_partials, int nblocks, 
 
 // data_term[c] = alpha_c * sum(-log p(z_c)) with the parameters in force for chain c; advance the Philox counter
 __global__ __launch_bounds__(kBlock) void finalize_kernel(DevState* s, const double* __restrict__ partials,
-                                                          int nblocks_per_chain, DevCfg cfg, int advance) {
+                                                          int nblocks_per_chain, DevCfg cfg, int advance,
+                                                          const unsigned* __restrict__ bounds, unsigned* __restrict__ hint,
+                                                          int nbounds) {
     __shared__ double smem[kBlock / kWave];
+    // publish the displacement bounds of this transition to pinned host memory (the host reads them unsynchronised, as a
+    // hint for which kernel variants to launch next time)
+    if (bounds && hint)
+        for (int i = threadIdx.x; i < nbounds; i += kBlock) hint[i] = bounds[i];
     for (int c = 0; c < cfg.C; ++c) {
         double acc[1] = {0.0};
         for (int b = threadIdx.x; b < nblocks_per_chain; b += kBlock) acc[0] += partials[(int64_t)c * nblocks_per_chain + b];
@@ -210,9 +216,9 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(DevState* s, const dou
 }
 
 void launch_finalize(DevState* s, const double* nll_partials, int nblocks_per_chain, DevCfg cfg, bool advance,
-                     hipStream_t st) {
+                     const unsigned* bounds, unsigned* hint, int nbounds, hipStream_t st) {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, st, s, nll_partials, nblocks_per_chain, cfg,
-                       advance ? 1 : 0);
+                       advance ? 1 : 0, bounds, hint, nbounds);
 }
 
 // GMM.init_parameters (model/loss.py:61-65) from the unbiased std of the masked residuals (trainer.py:537-541)

@@ -169,3 +169,37 @@ def test_in_kernel_noise_path_runs_and_is_reproducible():
         res.append(v.clone())
     assert float((res[0] - res[1]).abs().max()) < 1e-3 * float(res[0].abs().max())   # atomics: order noise only
     assert float((res[0] - res[2]).abs().max()) > 1e-2 * float(res[0].abs().max())
+
+
+@pytest.mark.parametrize('amp', [0.3, 1.6, 3.5])
+def test_variant_prediction_never_changes_the_result(amp, monkeypatch):
+    """Which forward squaring-step variants get launched is decided on the host from the (unsynchronised) displacement
+    bounds of an earlier transition.  Whatever the decision -- every variant (mode 0), the production heuristic (1), or
+    always 'small' (2: the radius-1 kernel alone, far taps from global memory) -- the transition is the same."""
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    from ir_sgmcmc_amd.ops import perturb_smooth, sobolev_kernel_1d
+    N = 24
+    f1, m1 = synthetic_pair((N, N, N), seed=0)
+    fixed = to_dev({k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'})
+    moving = to_dev({k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'})
+    g = torch.Generator().manual_seed(3)
+    v0 = perturb_smooth(torch.randn(1, 3, N, N, N, generator=g).to(DEV), sobolev_kernel_1d(3, 0.5))
+    v0 = v0 * (amp / float(v0.abs().max()))
+    eps = torch.randn(1, 3, N, N, N, generator=g).to(DEV)
+    res = {}
+    for mode in (0, 1, 2):
+        monkeypatch.setenv('IRS_PREDICT_VARIANTS', str(mode))
+        eng = TransitionEngine(EngineConfig(dims=(N, N, N), seed=1), DEV)
+        fd, md = eng.prepare(fixed, moving)
+        eng.gmm_init(fd, md)
+        v = v0.clone()
+        out = outputs_for(eng.cfg)
+        for _ in range(3):   # the heuristic only has bounds to look at from the second transition on
+            eng.transition(fd, md, v, eps=eps, outputs=out)
+        torch.cuda.synchronize()
+        res[mode] = (v.clone(), out['grad_v'].clone(), out['displacement'].clone())
+    for mode in (1, 2):
+        assert float((res[mode][2] - res[0][2]).abs().max()) < 1e-5                       # displacement [voxels]
+        scale = float(res[0][1].abs().max())
+        assert float((res[mode][1] - res[0][1]).abs().max()) < 1e-4 * scale                # gradient (summation order only)
+        assert float((res[mode][0] - res[0][0]).abs().max()) < 1e-5 * float(res[0][0].abs().max())
