@@ -31,12 +31,32 @@ class SyntheticDataLoader:
 
 
 class BiobankDataLoader(SyntheticDataLoader):
-    """The reference's loader reads .nii.gz with SimpleITK from `data_dir` (data_loader/datasets.py:70-105).  Image
-    file i/o is a "next" row of the scope table and SimpleITK is not available here, so a
-    config that names BiobankDataLoader resolves to the synthetic pair of the same `dims` with a warning."""
+    """Reference contract (data_loader/data_loaders.py:5-19): `.nii.gz` triples under `data_dir` through BiobankDataset
+    (numpy NIfTI reader instead of SimpleITK).  When `data_dir` holds no usable pair -- the reference ships no image data --
+    the loader resolves to the synthetic pair of the same `dims`, with a warning."""
 
     def __init__(self, data_dir=None, dims=None, sigma_v_init=0.5, u_v_init=0.1, cps=None, save_dirs=None, **kw):
-        import logging
-        logging.getLogger('default').warning(
-            f'BiobankDataLoader: reading {data_dir!r} needs SimpleITK (out of scope); using the synthetic pair at {dims}')
         super().__init__(dims, sigma_v_init, u_v_init, cps, save_dirs, **kw)
+        self.data_dir, self.dataset = data_dir, None
+        try:
+            from .datasets import BiobankDataset
+            self.dataset = BiobankDataset(dims, data_dir, save_dirs, sigma_v_init, u_v_init, cps=cps)
+        except (FileNotFoundError, NotADirectoryError, TypeError) as e:
+            import logging
+            logging.getLogger('default').warning(f'BiobankDataLoader: {e}; using the synthetic pair at {dims}')
+
+    @property
+    def im_spacing(self):
+        return self.dataset.im_spacing if self.dataset is not None else None
+
+    @im_spacing.setter
+    def im_spacing(self, value):   # the synthetic base class assigns None in its constructor
+        pass
+
+    def __iter__(self):
+        if self.dataset is None:
+            yield from super().__iter__()
+            return
+        fixed, moving, vp = self.dataset[0]
+        add = lambda d: {k: v.unsqueeze(0) for k, v in d.items()}   # the DataLoader's batch dimension
+        yield add(fixed), add(moving), add(vp)

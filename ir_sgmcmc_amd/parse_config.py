@@ -138,7 +138,9 @@ class ConfigParser:
 
     @property
     def save_dirs(self):
-        return {'dir': self._dir, 'samples': self._dir / 'samples'}
+        return {'dir': self._dir, 'tensors': self._dir / 'tensors', 'samples': self._dir / 'samples', 'images': self._dir / 'images',
+                'fields': self._dir / 'fields', 'grids': self._dir / 'grids', 'norms': self._dir / 'norms',
+                'checkpoints': self._dir / 'checkpoints'}
 
 
 def _update_config(config, modification):

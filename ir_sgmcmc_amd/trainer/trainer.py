@@ -18,6 +18,7 @@ import torch
 
 from ..base import BaseTrainer
 from ..engine import EngineConfig, TransitionEngine
+from ..logger import save_displacement_mean_and_std_dev, save_sample
 from ..utils import calc_norm, calc_no_non_diffeomorphic_voxels, calc_DSC_GPU, sample_q_v
 
 
@@ -132,6 +133,44 @@ class Trainer(BaseTrainer):
             self._scalars_cache = self.engine.scalars()
         return self._scalars_cache
 
+    # ---------------------------------------------------------------- checkpoint / resume (absent in the reference)
+    def state_dict(self):
+        """Everything a chain needs to continue bit-for-bit: the velocity field, the SGLD pre-conditioner, the device-side
+        hyper-parameter state (GMM / regulariser parameters, their Adam moments and step counts, the Philox iteration
+        counter) and the running posterior moments."""
+        import ctypes
+        st = self.engine.state()
+        sigma = getattr(self, '_sigma', None)
+        return {'v_curr_state': self.v_curr_state.detach().cpu(), 'sigma': None if sigma is None else sigma.detach().cpu(),
+                'tau': self.SGLD_params['tau'], 'engine_state': bytes(ctypes.string_at(ctypes.byref(st), ctypes.sizeof(st))),
+                'sample_no': getattr(self, '_sample_no', 0),
+                'moments': {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in getattr(self, '_moments', {}).items()},
+                'config_name': self.config['name']}
+
+    def load_state_dict(self, sd):
+        import ctypes
+        from .. import _lib as L
+        if self.engine is None:
+            raise RuntimeError('load_state_dict: call _engine_init(fixed, moving) first')
+        st = L.IrsState()
+        raw = sd['engine_state']
+        if len(raw) != ctypes.sizeof(st):
+            raise ValueError('checkpoint was written by an incompatible build (state struct size differs)')
+        ctypes.memmove(ctypes.byref(st), raw, len(raw))
+        self.engine.set_state(st)
+        self.v_curr_state = sd['v_curr_state'].to(self.device).contiguous()
+        self._sigma = None if sd['sigma'] is None else sd['sigma'].to(self.device).contiguous()
+        self.SGLD_params = {'tau': sd['tau'], 'sigma': self._sigma if self._sigma is not None else torch.ones_like(self.v_curr_state)}
+        self._sample_no = int(sd['sample_no'])
+        self._moments = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in sd.get('moments', {}).items()}
+        self.sync_parameters()
+
+    def save_checkpoint(self, file_path):
+        torch.save(self.state_dict(), file_path)
+
+    def load_checkpoint(self, file_path):
+        self.load_state_dict(torch.load(file_path, map_location='cpu', weights_only=False))
+
     # ---------------------------------------------------------------- reference-named pieces
     def _step_GMM(self, residuals=None, alpha=1.0):
         """trainer.py:68-77 happens inside the fused transition (csrc/scalar_kernels.hip: chain_scalar_kernel)."""
@@ -205,7 +244,17 @@ class Trainer(BaseTrainer):
         mean = torch.zeros_like(self._outputs['displacement'][0])
         m2 = torch.zeros_like(mean)
         n_rec = 0
-        for sample_no in range(1, n_total + 1):
+        cfg_trainer = self.config['trainer']
+        checkpoint_period, save_samples = int(cfg_trainer.get('checkpoint_period', 0)), bool(cfg_trainer.get('save_samples', False))
+        spacing = self.data_loader.im_spacing if getattr(self.data_loader, 'im_spacing', None) is not None else torch.ones(3)
+        first = 1
+        if cfg_trainer.get('resume'):
+            self.load_checkpoint(cfg_trainer['resume'])
+            first = self._sample_no + 1
+            if self._moments:
+                mean, m2, n_rec = self._moments['mean'], self._moments['m2'], int(self._moments['n'])
+            log(f'resumed from {cfg_trainer["resume"]} at sample {self._sample_no}')
+        for sample_no in range(first, n_total + 1):
             if sample_no < self.no_iters_burn_in and sample_no % self.log_period_MCMC == 0:
                 log(f'burn-in sample no. {sample_no}/{self.no_iters_burn_in}')
             loss_terms, output, aux = self._SGLD_transition(fixed, moving, data_loss, reg_loss)
@@ -235,6 +284,10 @@ class Trainer(BaseTrainer):
                         for j, name in enumerate(self.structures_dict):
                             self.metrics.update(f'MCMC/chain_{idx}/DSC/{name}', float(DSC[idx][j]))
                 no_voxels = int(np.prod(displacement.shape[2:]))
+                if save_samples:
+                    for idx in range(self.no_chains):
+                        save_sample(self.config.save_dirs, spacing, sample_no, output['im_moving_warped'][idx:idx + 1],
+                                    displacement[idx:idx + 1], log_det_J[idx:idx + 1], 'MCMC', chain_no=idx)
                 for idx in range(self.no_chains):
                     n_rec += 1
                     delta = displacement[idx] - mean
@@ -245,8 +298,16 @@ class Trainer(BaseTrainer):
                         log(f'chain {idx}, sample {sample_no}: detected {no_folds} voxels where the sampled '
                             f'transformation is not diffeomorphic; exiting..')
                         raise SystemExit(1)
+            if checkpoint_period and sample_no % checkpoint_period == 0:
+                self._sample_no, self._moments = sample_no, {'mean': mean, 'm2': m2, 'n': n_rec}
+                folder = self.config.save_dirs['checkpoints']
+                folder.mkdir(parents=True, exist_ok=True)
+                self.save_checkpoint(folder / f'checkpoint_{sample_no:07}.pt')
         self.displacement_mean = mean
         self.displacement_std = torch.sqrt(m2 / max(n_rec - 1, 1))
+        if n_rec > 0 and cfg_trainer.get('save_outputs', True):
+            save_displacement_mean_and_std_dev(self.logger, self.config.save_dirs, spacing, self.displacement_mean,
+                                               self.displacement_std, fixed['mask'][0].to(mean.dtype), 'MCMC')
 
         # speed test (trainer.py:467-476): 100 x [transition + nearest-neighbour warp of the segmentation]
         n_speed = 100

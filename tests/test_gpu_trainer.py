@@ -88,6 +88,33 @@ def test_run_mcmc_end_to_end(tmp_path):
     assert t.engine.state().iteration == 4 + 8 + 100   # burn-in + samples + the reference's 100-sample speed test
 
 
+def test_checkpoint_resume_continues_the_chain_bit_for_bit(tmp_path):
+    """A run that is stopped at a checkpoint and resumed ends exactly where the uninterrupted run ends: velocity field,
+    hyper-parameter state (incl. Adam moments and the Philox counter) and the running posterior moments are all restored.
+    It also leaves the reference's output files behind (posterior mean / std as .vtk, samples as .nii.gz / .vtk)."""
+    kw = dict(no_iters_burn_in=4, no_samples_MCMC=8, log_period_MCMC=2, checkpoint_period=6, save_samples=True)
+    a, _ = make_trainer(tmp_path / 'a', 'synthetic_gmm_lognormal.json', (16, 16, 16), **kw)
+    a.run()
+    ck = a.config.save_dirs['checkpoints'] / 'checkpoint_0000006.pt'
+    assert ck.is_file() and (a.config.save_dirs['checkpoints'] / 'checkpoint_0000012.pt').is_file()
+    b, _ = make_trainer(tmp_path / 'b', 'synthetic_gmm_lognormal.json', (16, 16, 16), resume=str(ck), **kw)
+    b.run()
+    assert torch.equal(a.v_curr_state, b.v_curr_state)
+    assert torch.equal(a.displacement_mean, b.displacement_mean) and torch.equal(a.displacement_std, b.displacement_std)
+    sa, sb = a.engine.state(), b.engine.state()
+    assert sa.iteration == sb.iteration == 112
+    assert list(sa.gmm_log_std) == list(sb.gmm_log_std) and list(sa.reg_param) == list(sb.reg_param)
+    # files
+    from ir_sgmcmc_amd.utils.imageio import read_nifti, read_vtk_vectors
+    samples = a.config.save_dirs['samples']
+    kind, dims, mean = read_vtk_vectors(str(samples / 'MCMC_sample_mean.vtk'))
+    assert kind == 'STRUCTURED_POINTS' and dims == (16, 16, 16)
+    assert np.allclose(mean, a.displacement_mean.cpu().numpy(), atol=1e-6)
+    assert (samples / 'MCMC_sample_std_dev_masked.vtk').is_file()
+    im, _ = read_nifti(str(samples / 'MCMC' / 'chain_1_sample_0000012_im_moving_warped.nii.gz'))
+    assert im.shape == (16, 16, 16) and np.isfinite(im).all()
+
+
 def test_module_classes_compose_under_autograd_like_the_reference():
     """SGLD.apply -> SobolevGrad.apply -> SVF_3D -> add_noise -> RegistrationModule -> GMM.map -> losses, then
     loss.backward() and SGD: the reference's own composition, every volume op a HIP kernel."""
