@@ -32,7 +32,7 @@ extern "C" {
 #define IRS_MAX_HALF_WIDTH 4 /* Sobolev / LCC half widths up to 4 */
 
 enum { IRS_DATA_GMM_LCC = 0, IRS_DATA_SSD = 1 };
-enum { IRS_REG_L2 = 0, IRS_REG_LOGNORMAL = 1 };
+enum { IRS_REG_L2 = 0, IRS_REG_LOGNORMAL = 1, IRS_REG_STUDENT = 2, IRS_REG_LOGNORMAL_L2 = 3 };
 
 /* ------------------------------------------------------------------------------------------------
  * stateless operators (unit-parity surface; the Python modules SVF_3D, RegistrationModule, GMM.map,
@@ -138,7 +138,8 @@ typedef struct irs_config {
     float reg_lr0, reg_lr1, reg_lr_decay; /* (lr_loc, lr_log_scale) or (lr_log_w_reg, -) */
     float loc_prior_nu, loc_prior_w_reg;  /* LogEnergyExpGammaPrior */
     float reg_scale_prior_loc, reg_scale_prior_scale; /* LogScaleNormalPrior on log_scale */
-    double w_reg_prior_shape, w_reg_prior_rate;       /* LogPrecisionExpGammaPrior */
+    double w_reg_prior_shape, w_reg_prior_rate;       /* LogPrecisionExpGammaPrior (learnable RegLoss_L2);
+                                                         RegLoss_Student (model/loss.py:201-241): {a0, 2 b0} */
     uint64_t seed;          /* Philox key for in-kernel noise */
 } irs_config;
 

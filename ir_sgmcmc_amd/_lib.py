@@ -16,7 +16,7 @@ IRS_MAX_COMPONENTS = 8
 IRS_MAX_CHAINS = 8
 IRS_MAX_HALF_WIDTH = 4
 IRS_DATA_GMM_LCC, IRS_DATA_SSD = 0, 1
-IRS_REG_L2, IRS_REG_LOGNORMAL = 0, 1
+IRS_REG_L2, IRS_REG_LOGNORMAL, IRS_REG_STUDENT, IRS_REG_LOGNORMAL_L2 = 0, 1, 2, 3
 
 
 class IrsConfig(C.Structure):

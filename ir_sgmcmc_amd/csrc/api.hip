@@ -423,7 +423,11 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
         if (!lcc_ok(cfg->lcc_s, D, H, W)) return fail("irs_create: LCC half width must be 1 or 2");
         if (cfg->gmm_components < 1 || cfg->gmm_components > IRS_MAX_COMPONENTS) return fail("irs_create: 1..%d mixture components", IRS_MAX_COMPONENTS);
     } else if (!(cfg->ssd_sigma > 0.0f)) return fail("irs_create: ssd_sigma must be positive");
-    if (cfg->reg_loss != IRS_REG_L2 && cfg->reg_loss != IRS_REG_LOGNORMAL) return fail("irs_create: unknown regulariser");
+    if (cfg->reg_loss < IRS_REG_L2 || cfg->reg_loss > IRS_REG_LOGNORMAL_L2) return fail("irs_create: unknown regulariser");
+    if ((cfg->reg_loss == IRS_REG_STUDENT || cfg->reg_loss == IRS_REG_LOGNORMAL_L2) && cfg->reg_learnable)
+        return fail("irs_create: RegLoss_Student / RegLoss_LogNormal_L2 have no learnable parameters");
+    if (cfg->reg_loss == IRS_REG_STUDENT && !(cfg->w_reg_prior_rate > 0.0 && cfg->w_reg_prior_shape > 0.0))
+        return fail("irs_create: RegLoss_Student needs a0 > 0 and b0 > 0 (w_reg_prior_shape / w_reg_prior_rate)");
     const bool any_cps = cfg->cps[0] || cfg->cps[1] || cfg->cps[2];
     if (any_cps && (cfg->cps[0] < 1 || cfg->cps[1] < 1 || cfg->cps[2] < 1 || cfg->cps[0] > 8 || cfg->cps[1] > 8 || cfg->cps[2] > 8))
         return fail("irs_create: control point spacing must be 1..8 on every axis");
@@ -531,7 +535,7 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
     init.K = d.K;
     init.mode = d.mode;
     init.ssd_inv_sigma = cfg->data_loss == IRS_DATA_SSD ? 1.0f / cfg->ssd_sigma : 0.0f;
-    if (cfg->reg_loss == IRS_REG_L2) init.st.reg_param[0] = log((double)cfg->w_reg);
+    if (cfg->reg_loss == IRS_REG_L2 || cfg->reg_loss == IRS_REG_LOGNORMAL_L2) init.st.reg_param[0] = log((double)cfg->w_reg);
     // (RegLoss_LogNormal's loc / log_scale need digamma: the host wrapper sets them through irs_set_state)
     for (int ch = 0; ch < IRS_MAX_CHAINS; ++ch) init.sc.alpha[ch] = 1.0;
     hipError_t e = hipMemcpy(c->state, &init, sizeof(init), hipMemcpyHostToDevice);

@@ -159,6 +159,24 @@ __global__ __launch_bounds__(kBlock) void reg_scalar_kernel(DevState* s, const d
                                                  cfg.reg_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
             s->st.reg_adam_step[0] = st0 + 1;
         }
+    } else if (cfg.reg_loss == IRS_REG_STUDENT) {
+        // model/loss.py:234-241: (a0 + dof/2) log(2 b0 + y)      (a0, 2 b0 travel in w_reg_prior_shape / _rate)
+        const double a0 = cfg.w_reg_prior_shape, b2 = cfg.w_reg_prior_rate;
+        for (int c = 0; c < cfg.C; ++c) {
+            const double y = ysh[c];
+            s->sc.reg_energy[c] = y;
+            s->sc.reg_term[c] = log(b2 + y) * (a0 + 0.5 * dof);
+            s->coef[c] = (a0 + 0.5 * dof) / (b2 + y);
+        }
+    } else if (cfg.reg_loss == IRS_REG_LOGNORMAL_L2) {
+        // model/loss.py:315-321 + :262-270: -log Gamma(y; dof/2, w/2) + (dof/2 - 1) log y  (= w y / 2 + const)
+        const double shape = 0.5 * dof, rate = 0.5 * exp(s->st.reg_param[0]);
+        for (int c = 0; c < cfg.C; ++c) {
+            const double y = ysh[c], ly = log(y);
+            s->sc.reg_energy[c] = y;
+            s->sc.reg_term[c] = -(shape * log(rate) + (shape - 1.0) * ly - rate * y - lgamma(shape)) + (0.5 * dof - 1.0) * ly;
+            s->coef[c] = rate;
+        }
     } else {
         // model/loss.py:266-312: log y + log s + 0.5 ((log y - loc)/s)^2 + (dof/2 - 1) log y
         const double loc = s->st.reg_param[0], ls = s->st.reg_param[1], sc = exp(ls);

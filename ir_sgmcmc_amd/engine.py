@@ -37,8 +37,9 @@ class EngineConfig:
     gmm_lr_decay: float = 0.001
     scale_prior: Tuple[float, float] = (0.0, 2.3)
     dirichlet_alpha: Sequence[float] = field(default_factory=lambda: [0.5])
-    reg_loss: str = 'RegLoss_L2'
+    reg_loss: str = 'RegLoss_L2'   # 'RegLoss_L2' | 'RegLoss_LogNormal' | 'RegLoss_Student' | 'RegLoss_LogNormal_L2'
     w_reg: float = 1.4
+    student: Tuple[float, float] = (1e-6, 2e-6)          # RegLoss_Student (a0, 2 b0), model/loss.py:224-232
     reg_learnable: bool = False
     reg_lr: Tuple[float, float] = (0.01, 0.01)
     reg_lr_decay: float = 0.001
@@ -89,7 +90,8 @@ class TransitionEngine:
             conc = conc * cfg.gmm_components
         for i, x in enumerate(conc):
             c.dirichlet_concentration[i] = float(x)
-        c.reg_loss = {'RegLoss_L2': L.IRS_REG_L2, 'RegLoss_LogNormal': L.IRS_REG_LOGNORMAL}[cfg.reg_loss]
+        c.reg_loss = {'RegLoss_L2': L.IRS_REG_L2, 'RegLoss_LogNormal': L.IRS_REG_LOGNORMAL, 'RegLoss_Student': L.IRS_REG_STUDENT,
+                      'RegLoss_LogNormal_L2': L.IRS_REG_LOGNORMAL_L2}[cfg.reg_loss]
         c.reg_learnable = int(cfg.reg_learnable)
         c.w_reg, c.dof = cfg.w_reg, cfg.dof
         c.reg_lr0, c.reg_lr1, c.reg_lr_decay = cfg.reg_lr[0], cfg.reg_lr[1], cfg.reg_lr_decay
@@ -98,6 +100,8 @@ class TransitionEngine:
         c.reg_scale_prior_loc, c.reg_scale_prior_scale = cfg.reg_scale_prior
         shape = 0.5 * cfg.dof  # parse_config.py:136-140
         c.w_reg_prior_shape, c.w_reg_prior_rate = shape, 1.0 / shape
+        if cfg.reg_loss == 'RegLoss_Student':
+            c.w_reg_prior_shape, c.w_reg_prior_rate = float(cfg.student[0]), float(cfg.student[1])
         c.seed = cfg.seed
         self._c = c
         ctx = C.c_void_p()

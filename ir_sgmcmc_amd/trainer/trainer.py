@@ -80,14 +80,18 @@ class Trainer(BaseTrainer):
         else:
             ec.update(ssd_sigma=data_loss.sigma)
         rname = type(reg_loss).__name__
-        if rname not in ('RegLoss_L2', 'RegLoss_LogNormal'):
-            raise NotImplementedError(rname + ' is not wired into the fused transition yet')
+        if rname not in ('RegLoss_L2', 'RegLoss_LogNormal', 'RegLoss_Student', 'RegLoss_LogNormal_L2'):
+            raise NotImplementedError(rname + ' is not wired into the fused transition')
         ec.update(reg_loss=rname, reg_learnable=bool(reg_loss.learnable))
         if rname == 'RegLoss_L2':
             ec.update(w_reg=float(reg_loss.log_w_reg.exp()))
             if reg_loss.learnable:
                 o = cfg['optimizer_reg']['args']
                 ec.update(reg_lr=(o['lr_log_w_reg'], 0.0), reg_lr_decay=o['lr_decay'])
+        elif rname == 'RegLoss_Student':
+            ec.update(student=(float(reg_loss.a0), float(reg_loss.b0_twice)))
+        elif rname == 'RegLoss_LogNormal_L2':
+            ec.update(w_reg=float(reg_loss.gamma_distr.rate) * 2.0)
         else:
             ec.update(w_reg=float(reg_loss.w_reg))
             if reg_loss.learnable:
@@ -108,7 +112,7 @@ class Trainer(BaseTrainer):
                 st.gmm_log_std[k], st.gmm_logits[k] = float(data_loss.log_std[k]), float(data_loss.logits[k])
         if type(reg_loss).__name__ == 'RegLoss_L2':
             st.reg_param[0] = float(reg_loss.log_w_reg)
-        else:
+        elif type(reg_loss).__name__ == 'RegLoss_LogNormal':
             st.reg_param[0], st.reg_param[1] = float(reg_loss.loc), float(reg_loss.log_scale)
         self.engine.set_state(st)
 
@@ -123,7 +127,7 @@ class Trainer(BaseTrainer):
                 data_loss.logits.copy_(torch.tensor(list(st.gmm_logits)[:K]))
             if type(reg_loss).__name__ == 'RegLoss_L2':
                 reg_loss.log_w_reg.fill_(st.reg_param[0])
-            else:
+            elif type(reg_loss).__name__ == 'RegLoss_LogNormal':
                 reg_loss.loc.fill_(st.reg_param[0])
                 reg_loss.log_scale.fill_(st.reg_param[1])
         return st

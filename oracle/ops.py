@@ -468,6 +468,23 @@ def reg_student(y, dof, a0=1e-6, b0_twice=2e-6):
     return torch.log(b0_twice + y) * (a0 + 0.5 * dof), y.log()
 
 
+def student_params(nu0=2e-6, lambda0=1e-6, a0=1e-6, b0=1e-6):
+    """RegLoss_Student.__init__ (model/loss.py:206-232): nu0 overrides a0, lambda0 overrides b0 -> (a0, 2 b0)"""
+    a = nu0 / 2.0 if nu0 != 2e-6 else a0
+    if lambda0 != 1e-6:
+        b0 = a / lambda0
+    return a, b0 * 2.0
+
+
+def reg_lognormal_l2(y, w_reg, dof):
+    """RegLoss_LogNormal_L2 (model/loss.py:315-321 through RegLoss_EnergyBased._loss :262-270):
+    -log Gamma(y; dof/2, w/2) + (dof/2 - 1) log y, with the reference's fp32 parameters and operation order."""
+    shape, rate = torch.tensor(0.5 * dof), torch.tensor(0.5 * w_reg)
+    ly = y.log()
+    gamma_log_pdf = shape * torch.log(rate) + (shape - 1) * ly - rate * ly.exp() - torch.lgamma(shape)
+    return -1.0 * gamma_log_pdf + (0.5 * dof - 1.0) * ly, ly
+
+
 # --------------------------------------------------------------------------------------------
 # a10  Adam with rate decay (scalars only)                       optimizers/adam_rate_decay.py:32-99
 # --------------------------------------------------------------------------------------------

@@ -49,7 +49,8 @@ class OracleConfig:
     scale_prior: Tuple[float, float] = (0.0, 2.3)  # LogScaleNormalPrior(loc, scale)
     dirichlet_alpha: float = 0.5
     # regulariser
-    reg_loss: str = 'RegLoss_L2'  # or 'RegLoss_LogNormal'
+    reg_loss: str = 'RegLoss_L2'  # or 'RegLoss_LogNormal', 'RegLoss_Student', 'RegLoss_LogNormal_L2'
+    student: Tuple[float, float, float, float] = (2e-6, 1e-6, 1e-6, 1e-6)  # RegLoss_Student(nu0, lambda0, a0, b0)
     w_reg: float = 1.4
     reg_learnable: bool = False
     reg_lr: Tuple[float, float] = (0.01, 0.01)  # (lr_loc, lr_log_scale) or (lr_log_w_reg, -)
@@ -102,6 +103,9 @@ class OracleChain:
                 self.adam_reg = ops.AdamRateDecay([{'params': [self.loc], 'lr': cfg.reg_lr[0]},
                                                    {'params': [self.log_scale], 'lr': cfg.reg_lr[1]}],
                                                   lr_decay=cfg.reg_lr_decay)
+        elif cfg.reg_loss in ('RegLoss_Student', 'RegLoss_LogNormal_L2'):
+            if cfg.reg_learnable:
+                raise ValueError(cfg.reg_loss + ' has no learnable parameters (model/loss.py:206,316)')
         else:
             raise ValueError(cfg.reg_loss)
 
@@ -173,6 +177,10 @@ class OracleChain:
         y = ops.reg_energy(v_s)
         if cfg.reg_loss == 'RegLoss_L2':
             return ops.reg_l2(y, self.log_w_reg, cfg.dof)
+        if cfg.reg_loss == 'RegLoss_Student':
+            return ops.reg_student(y, cfg.dof, *ops.student_params(*cfg.student))
+        if cfg.reg_loss == 'RegLoss_LogNormal_L2':
+            return ops.reg_lognormal_l2(y, cfg.w_reg, cfg.dof)
         return ops.reg_lognormal(y, self.loc, self.log_scale, cfg.dof)
 
     # ---------------------------------------------------------------- the transition

@@ -23,7 +23,7 @@ class Golden:
         meta = json.loads(bytes(self.z['config']).decode())
         self.N = meta.pop('N')
         self.sigma = meta.pop('sigma')
-        for k in ('cps',):
+        for k in ('cps', 'student'):
             if meta.get(k) is not None:
                 meta[k] = tuple(meta[k])
         self.cfg = OracleConfig(dims=(self.N,) * 3, **meta)

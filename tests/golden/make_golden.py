@@ -48,6 +48,8 @@ VARIANTS = {
                                                                no_chains=2, reg_loss='RegLoss_LogNormal',
                                                                reg_learnable=True, sobolev_s=1), init='noise'),
     'n16_svf_big_displacement': dict(N=16, T=2, cfg=dict(w_reg=0.2), init='big'),
+    'n16_svf_student_c1': dict(N=16, T=2, cfg=dict(reg_loss='RegLoss_Student', student=(2e-6, 0.7, 1e-6, 1e-6)), init='smooth_noise'),
+    'n16_svf_lognormal_l2_c1': dict(N=16, T=2, cfg=dict(reg_loss='RegLoss_LogNormal_L2', w_reg=0.9), init='smooth_noise'),
     'n32_svf_l2_vd_c1': dict(N=32, T=2, cfg=dict(), init='smooth_noise'),
     'n32_svf_lognormal_learn_c2': dict(N=32, T=1, cfg=dict(no_chains=2, reg_loss='RegLoss_LogNormal',
                                                             reg_learnable=True), init='vi', sigma=0.5),
@@ -96,7 +98,13 @@ def build_reference(ref, cfg, fixed, moving, v0, sigma):
                        'proportion_prior': ref.distr.DirichletPrior(cfg.gmm_components, cfg.dirichlet_alpha)},
               'reg': {}}
     reg_cls = getattr(ref.loss, cfg.reg_loss)
-    reg = reg_cls(w_reg=cfg.w_reg, diff_op='GradientOperator', dims=list(cfg.dims), learnable=cfg.reg_learnable)
+    if cfg.reg_loss == 'RegLoss_Student':
+        nu0, lambda0, a0, b0 = cfg.student
+        reg = reg_cls(diff_op='GradientOperator', dims=list(cfg.dims), nu0=nu0, lambda0=lambda0, a0=a0, b0=b0)
+    elif cfg.reg_loss == 'RegLoss_LogNormal_L2':
+        reg = reg_cls(w_reg=cfg.w_reg, diff_op='GradientOperator', dims=list(cfg.dims))
+    else:
+        reg = reg_cls(w_reg=cfg.w_reg, diff_op='GradientOperator', dims=list(cfg.dims), learnable=cfg.reg_learnable)
     losses['reg']['loss'] = reg
     t.optimizer_reg = None
     if cfg.reg_learnable:
@@ -218,7 +226,7 @@ def run_variant(ref, name, spec, write):
         if cfg.reg_loss == 'RegLoss_LogNormal':
             ref_out['reg_loc'] = reg.loc.detach().numpy().copy()
             ref_out['reg_log_scale'] = reg.log_scale.detach().numpy().copy()
-        else:
+        elif cfg.reg_loss == 'RegLoss_L2':
             ref_out['reg_log_w'] = reg.log_w_reg.detach().numpy().copy()
 
         # ---- oracle vs reference
@@ -236,7 +244,7 @@ def run_variant(ref, name, spec, write):
         }
         if cfg.reg_loss == 'RegLoss_LogNormal':
             cmp['reg_params'] = max(maxdiff(ref_out['reg_loc'], orc.loc), maxdiff(ref_out['reg_log_scale'], orc.log_scale))
-        else:
+        elif cfg.reg_loss == 'RegLoss_L2':
             cmp['reg_params'] = maxdiff(ref_out['reg_log_w'], orc.log_w_reg)
         for k, v in cmp.items():
             worst[k] = max(worst.get(k, 0.0), v)

@@ -19,8 +19,13 @@ def engine_config(oc: OracleConfig, seed=0):
                         data_loss=oc.data_loss, gmm_components=oc.gmm_components, lcc_s=oc.lcc_s, ssd_sigma=oc.ssd_sigma,
                         gmm_lr_log_std=oc.gmm_lr_log_std, gmm_lr_logits=oc.gmm_lr_logits, gmm_lr_decay=oc.gmm_lr_decay,
                         scale_prior=oc.scale_prior, dirichlet_alpha=[oc.dirichlet_alpha], reg_loss=oc.reg_loss,
-                        w_reg=oc.w_reg, reg_learnable=oc.reg_learnable, reg_lr=oc.reg_lr, reg_lr_decay=oc.reg_lr_decay,
+                        student=O_student(oc), w_reg=oc.w_reg, reg_learnable=oc.reg_learnable, reg_lr=oc.reg_lr, reg_lr_decay=oc.reg_lr_decay,
                         loc_prior_nu=oc.reg_loc_prior_nu, reg_scale_prior=oc.reg_scale_prior, seed=seed)
+
+
+def O_student(oc):
+    from oracle import ops as O
+    return O.student_params(*oc.student)
 
 
 def to_dev(d):
@@ -83,7 +88,7 @@ def test_transition_matches_reference_fixture(name):
         if g.has(it, 'reg_loc'):
             check(T, 'reg_loc', st.reg_param[0], ref('reg_loc'), 1e-5)
             check(T, 'reg_log_scale', st.reg_param[1], ref('reg_log_scale'), 1e-5)
-        else:
+        elif g.has(it, 'reg_log_w'):
             check(T, 'reg_log_w', st.reg_param[0], ref('reg_log_w'), 1e-5)
         cs = ref('curr_state')
         # (the 64^3 fixture stores sub-sampled outputs only, so v cannot be re-synchronised between its transitions)

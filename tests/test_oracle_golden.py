@@ -45,7 +45,7 @@ def _replay(name):
         if g.has(it, 'reg_loc'):
             assert torch.allclose(orc.loc.detach().double(), g.t(it, 'reg_loc').double(), atol=1e-5)
             assert torch.allclose(orc.log_scale.detach().double(), g.t(it, 'reg_log_scale').double(), atol=1e-5)
-        else:
+        elif g.has(it, 'reg_log_w'):
             assert torch.allclose(orc.log_w_reg.detach(), g.t(it, 'reg_log_w'), atol=1e-6)
 
 
