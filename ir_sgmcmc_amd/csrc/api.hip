@@ -207,8 +207,8 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
         if (lds) {
             launch_field_absmax(dk, k == 0, no_steps, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, C, vol, st);
             const int rad = env_int("IRS_EXP_GATHER", 2);
-            if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, st);
-            launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, rad, st);
+            if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, nullptr, st);
+            launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, rad, nullptr, st);
         } else {
             HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
             launch_exp_step_bwd(G, dk, out, k == 0, no_steps, C, vol, lin, st);
@@ -299,7 +299,7 @@ int irs_warp_fwd(const float* im, int Cim, const float* d_last, const float* uni
     const Vol vol = make_vol(D, H, W);
     Lin lin;
     if (cached_lin(D, H, W, st, &lin)) return fail("irs_warp_fwd: identity grid allocation failed");
-    launch_warp_fwd(im, Cim == 1 ? 0 : vol.V, d_last, unif, alpha, warped, C, vol, lin, seed, iteration, nullptr, st);
+    launch_warp_fwd(im, Cim == 1 ? 0 : vol.V, d_last, unif, alpha, warped, nullptr, C, vol, lin, seed, iteration, nullptr, st);
     LAUNCH_CHECK();
     return 0;
 }
@@ -630,7 +630,7 @@ static int check_io(const irs_ctx* c, const irs_io* io, const char* who) {
 
 // velocity (v + noise, smoothed) -> vs; dense velocity -> d_1..d_n; warp -> warped; residual -> z (+ sigM)
 static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_noise, bool with_jitter, float* vs,
-                        float* warped, float* z, int chains, hipStream_t st, int timed) {
+                        float* warped, float* z, float* gradm, int chains, hipStream_t st, int timed) {
     const irs_config& cfg = c->cfg;
     const int C = chains;
     const uint64_t* it = &c->state->st.iteration;
@@ -675,7 +675,7 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     const float* d_last = c->steps + (int64_t)(cfg.no_steps - 1) * field;
     // 4. warp (+ jitter) and residual
     const float alpha = with_jitter ? cfg.uniform_alpha : 0.0f;
-    launch_warp_fwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif, alpha, warped, C, c->vol, lin,
+    launch_warp_fwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif, alpha, warped, gradm, C, c->vol, lin,
                     cfg.seed, 0, it, st);
     if (cfg.data_loss == IRS_DATA_GMM_LCC)
         launch_lcc_fwd_march(c->fhat, c->fhat_chains == 1 ? 0 : c->vol.V, warped, z, c->sigM, cfg.lcc_s, C, c->vol, st);
@@ -693,7 +693,7 @@ int irs_gmm_init(irs_ctx* c, const irs_io* io, const float* v_sample, int warm_u
     const size_t bytes = (size_t)3 * c->volv.V * sizeof(float);
     if (v_sample) HIP_TRY(hipMemcpyAsync(c->gA, v_sample, bytes, hipMemcpyDeviceToDevice, st));
     else HIP_TRY(hipMemsetAsync(c->gA, 0, bytes, st));
-    if (forward_pass(c, io, c->gA, false, false, c->vs, c->warped, c->z, 1, st, 0)) return 1;
+    if (forward_pass(c, io, c->gA, false, false, c->vs, c->warped, c->z, nullptr, 1, st, 0)) return 1;
     launch_masked_moments(c->z, io->mask, c->stat_partials, c->vol, st);
     launch_gmm_init_from_moments(c->state, c->stat_partials, stats_blocks(c->vol), c->dcfg, st);
     launch_stats(c->cfg.virtual_decimation, c->z, io->mask, c->state, c->stat_partials, c->vol, st);
@@ -719,7 +719,10 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     const uint64_t* it = &c->state->st.iteration;
 
     if (timed) HIP_TRY(hipEventRecord(c->ev[0], st));
-    if (forward_pass(c, io, io->v, true, cfg.uniform_alpha > 0.0f, vs, warped, z, C, st, timed)) return 1;
+    // fused backward warp: the forward warp also writes d(warped)/d(d_last) into gA, and the first adjoint squaring step
+    // multiplies it with g_warped while staging (kernels.h: gscale); only on the LDS path, which owns every variant of it
+    const bool fuse_warp_bwd = use_lds_exp() && env_int("IRS_FUSE_WARP_BWD", 1) != 0;
+    if (forward_pass(c, io, io->v, true, cfg.uniform_alpha > 0.0f, vs, warped, z, fuse_warp_bwd ? c->gA : nullptr, C, st, timed)) return 1;
     const int64_t field = (int64_t)C * 3 * vol.V;
     const float* d_last = c->steps + (int64_t)(cfg.no_steps - 1) * field;
     if (io->transformation || io->displacement) launch_svf_outputs(d_last, io->transformation, io->displacement, C, vol, lin, st);
@@ -740,8 +743,9 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
                         c->gM + (int64_t)ch * vol.V, c->nll_partials + (int64_t)ch * c->nll_blocks, cfg.lcc_s, 1, vol, st);
     }
     // back through the warp and the squaring steps
-    launch_warp_bwd(io->moving_im, io->moving_chains == 1 ? 0 : vol.V, d_last, io->unif,
-                    cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f, c->gM, c->gA, C, vol, lin, cfg.seed, 0, it, st);
+    if (!fuse_warp_bwd)
+        launch_warp_bwd(io->moving_im, io->moving_chains == 1 ? 0 : vol.V, d_last, io->unif,
+                        cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f, c->gM, c->gA, C, vol, lin, cfg.seed, 0, it, st);
     LAUNCH_CHECK();
     if (timed) HIP_TRY(hipEventRecord(c->ev[3], st));
     const float* dense = c->ffd ? c->dense : vs;
@@ -760,8 +764,10 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
             if (lds) {
                 const unsigned* dm = c->dmax + (int64_t)k * C * 4;
                 const int rad = env_int("IRS_EXP_GATHER", 2);  // largest gather radius to launch (0: scatter only)
-                if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, st);
-                launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, st);
+                // fused backward warp: gA holds d(warped)/d(d_last); the first step scales it by g_warped while staging
+                const float* gscale = fuse_warp_bwd && k == cfg.no_steps - 1 ? c->gM : nullptr;
+                if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, gscale, st);
+                launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, gscale, st);
             }
             else launch_exp_step_bwd(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, st);
             if (timed) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k + 1], st));
@@ -875,7 +881,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
             break;
         case IRS_ST_WARP:
             launch_warp_fwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif,
-                            cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f, warped, C, w, lin, cfg.seed, 0, it, st);
+                            cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f, warped, nullptr, C, w, lin, cfg.seed, 0, it, st);
             break;
         case IRS_ST_RESIDUAL:
             if (cfg.data_loss == IRS_DATA_GMM_LCC)
@@ -912,8 +918,8 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
             float* out = ob == IRS_BUF_GRAD_A ? c->gA : c->gB;
             const float* dk = k == 0 ? vs : c->steps + (int64_t)(k - 1) * field;
             const unsigned* dm = c->dmax + (int64_t)k * C * 4;
-            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, st);
-            launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, 2, st);
+            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, nullptr, st);
+            launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, 2, nullptr, st);
             break;
         }
         case IRS_ST_UPDATE: {

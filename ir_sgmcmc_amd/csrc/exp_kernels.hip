@@ -90,9 +90,9 @@ static dim3 exp_grid(Vol vol, int C, TileGrid* tg) {
 template <bool PRESCALE, int H>
 __device__ __forceinline__ void adjoint_source(const int x, const int y, const int z, const float d0, const float d1,
                                                const float d2, const int ox, const int oy, const int oz,
-                                               const float* __restrict__ Gc, const float* __restrict__ c0,
-                                               const float* __restrict__ lds, float* __restrict__ acc, const Vol vol,
-                                               const Lin lin, const Scale3L sc) {
+                                               const float* __restrict__ Gc, const float* __restrict__ gs_,
+                                               const float* __restrict__ c0, const float* __restrict__ lds,
+                                               float* __restrict__ acc, const Vol vol, const Lin lin, const Scale3L sc) {
     using B = ExpBox<H>;
     const int64_t V = vol.V;
     const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
@@ -104,7 +104,8 @@ __device__ __forceinline__ void adjoint_source(const int x, const int y, const i
     const bool any = ax1 >= 0 && ax0 < ETX && ay1 >= 0 && ay0 < ETY && az1 >= 0 && az0 < ETZ;
     if (!any && !self_in) return;
     const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-    const float G0 = Gc[g], G1 = Gc[V + g], G2 = Gc[2 * V + g];
+    const float gsc = gs_ ? gs_[g] : 1.0f;  // optional scalar factor of the incoming gradient (fused backward warp)
+    const float G0 = Gc[g] * gsc, G1 = Gc[V + g] * gsc, G2 = Gc[2 * V + g] * gsc;
     if (any) {
         // per-axis weights with out-of-tile corners zeroed: the scatter becomes 8 unconditional-weight products
         const float wx0 = (unsigned)ax0 < (unsigned)ETX ? tx.w0 : 0.0f, wx1 = (unsigned)ax1 < (unsigned)ETX ? tx.w1 : 0.0f;
@@ -173,7 +174,7 @@ template <bool PRESCALE, int H>
 __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __restrict__ G, const float* __restrict__ dk,
                                                                 float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
                                                                 const unsigned* __restrict__ dmax, TileGrid tg,
-                                                                int gather_radius) {
+                                                                int gather_radius, const float* __restrict__ gscale) {
     using B = ExpBox<H>;
     __shared__ float lds[3 * B::SN];
     __shared__ float acc[3 * ETN];
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
     const int64_t cb = (int64_t)chain * 3 * V;
     const float* c0 = dk + cb;
     const float* Gc = G + cb;
+    const float* gsc_ = gscale ? gscale + (int64_t)chain * V : nullptr;
 
     stage_field<PRESCALE, H>(c0, lds, ox, oy, oz, vol, sc);
     for (int i = threadIdx.x; i < 3 * ETN; i += kExpBlock) acc[i] = 0.0f;
@@ -217,8 +219,8 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
             const int lx = i % B::SX, ly = (i / B::SX) % B::SY, lz = i / (B::SX * B::SY);
             const int x = ox - H + lx, y = oy - H + ly, z = oz - H + lz;
             if ((unsigned)x >= (unsigned)vol.W || (unsigned)y >= (unsigned)vol.H || (unsigned)z >= (unsigned)vol.D) continue;
-            adjoint_source<PRESCALE, H>(x, y, z, lds[i], lds[B::SN + i], lds[2 * B::SN + i], ox, oy, oz, Gc, c0, lds, acc, vol,
-                                        lin, sc);
+            adjoint_source<PRESCALE, H>(x, y, z, lds[i], lds[B::SN + i], lds[2 * B::SN + i], ox, oy, oz, Gc, gsc_, c0, lds, acc,
+                                        vol, lin, sc);
         }
     } else {
         // general path: run-time source box, displacements from global memory outside the staged box
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
                 d1 = ldp<PRESCALE>(c0 + V, g, sc.nm1[1], sc.inv_pow);
                 d2 = ldp<PRESCALE>(c0 + 2 * V, g, sc.nm1[2], sc.inv_pow);
             }
-            adjoint_source<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, Gc, c0, lds, acc, vol, lin, sc);
+            adjoint_source<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, Gc, gsc_, c0, lds, acc, vol, lin, sc);
         }
     }
     __syncthreads();
@@ -261,11 +263,11 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
 }
 
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
-                             Lin lin, const unsigned* dmax, int halo, int gather_radius, hipStream_t st) {
+                             Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, hipStream_t st) {
     TileGrid tz;
     const dim3 grid = exp_grid(vol, C, &tz);
     const Scale3L sc = make_scale_l(vol, no_steps);
-#define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius)
+#define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale)
     if (prescale_in) {
         if (halo <= 1) IRS_BWD(true, 1); else IRS_BWD(true, 2);
     } else {
@@ -331,7 +333,8 @@ template <bool PRESCALE, int R>
 __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, const float* __restrict__ dk,
                                                    float* __restrict__ gout, const Vol vol, const Lin lin, const Scale3L sc,
                                                    const unsigned* __restrict__ dmax, const int seg_len, const int nseg,
-                                                   const int r_lo, const int swz_run, const int tile_id, const dim3 tiles) {
+                                                   const int r_lo, const int swz_run, const int tile_id, const dim3 tiles,
+                                                   const float* __restrict__ gscale) {
     using M = March<PRESCALE, R>;
     constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
     // ring slot layout (9 floats per source, 8-byte fields so that the gather needs three ds_read_b64 per candidate):
@@ -359,6 +362,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     const float* __restrict__ Gx_ = G + cb;
     const float* __restrict__ Gy_ = Gx_ + V;
     const float* __restrict__ Gz_ = Gy_ + V;
+    const float* __restrict__ gs_ = gscale ? gscale + (int64_t)chain * V : nullptr;  // fused backward warp: G *= gs
     float* __restrict__ o = gout + cb;
 
     const int lx = threadIdx.x % MTX, ly = threadIdx.x / MTX;
@@ -383,7 +387,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
         sfx[it] = (float)cx;
         sfy[it] = (float)cy;
     }
-    float pre[NIT][6];
+    float pre[NIT][6], pgs[NIT];
     auto prefetch = [&](int s) {
         if (s < 0 || s >= vol.D) return;
         const int64_t zo = (int64_t)s * vol.H * vol.W;
@@ -403,6 +407,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
             pre[it][3] = ld_off(p3_, g);
             pre[it][4] = ld_off(p4_, g);
             pre[it][5] = ld_off(p5_, g);
+            if (gs_) pgs[it] = ld_off(gs_ + zo, g);
         }
     };
     auto commit = [&](int s, int slot) {  // registers -> ring slot (with the clipped sampling position)
@@ -430,7 +435,9 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
             // act as a source, which G = 0 achieves whatever its position.
             const float p0 = __builtin_amdgcn_fmed3f(qx, 0.0f, nxm), p1 = __builtin_amdgcn_fmed3f(qy, 0.0f, nym),
                         p2 = __builtin_amdgcn_fmed3f(qz, 0.0f, nzm);
-            const float g0 = sin_[it] ? pre[it][3] : 0.0f, g1 = sin_[it] ? pre[it][4] : 0.0f, g2 = sin_[it] ? pre[it][5] : 0.0f;
+            const float gm_ = gs_ ? pgs[it] : 1.0f;
+            const float g0 = sin_[it] ? pre[it][3] * gm_ : 0.0f, g1 = sin_[it] ? pre[it][4] * gm_ : 0.0f,
+                        g2 = sin_[it] ? pre[it][5] * gm_ : 0.0f;
             q_xy[i] = make_float2(p0 - sfx[it], p1 - sfy[it]);
             q_zg[i] = make_float2(p2 - fs_, g2);
             q_g[i] = make_float2(g0, g1);
@@ -570,16 +577,17 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
 template <bool PRESCALE, int R>
 __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp_bwd_march_kernel(
     const float* __restrict__ G, const float* __restrict__ dk, float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
-    const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int swz_run, dim3 tiles) {
+    const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int swz_run, dim3 tiles,
+    const float* __restrict__ gscale) {
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     for (int id = blockIdx.x; id < total; id += gridDim.x)
-        exp_bwd_march_tile<PRESCALE, R>(G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, r_lo, swz_run, id, tiles);
+        exp_bwd_march_tile<PRESCALE, R>(G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, r_lo, swz_run, id, tiles, gscale);
 }
 
 constexpr int kRareGrid = 512;  // persistent grid of the rarely selected variants (two workgroups per CU)
 
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
-                               Lin lin, const unsigned* dmax, int max_radius, hipStream_t st) {
+                               Lin lin, const unsigned* dmax, int max_radius, const float* gscale, hipStream_t st) {
     static const int seg_env = getenv("IRS_MARCH_SEG") ? atoi(getenv("IRS_MARCH_SEG")) : 32;
     const int seg_len = seg_env;
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
@@ -588,7 +596,7 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
     const Scale3L sc = make_scale_l(vol, no_steps);
     static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;  // 0/1: no remap; default: one x-row of tiles per XCD run
-#define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, (GRID) == total ? swz_run : 0, tiles)
+#define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, (GRID) == total ? swz_run : 0, tiles, gscale)
     const int rare = total < kRareGrid ? total : kRareGrid;
     if (prescale_in) {
         IRS_BWM(true, 1, 0, total);

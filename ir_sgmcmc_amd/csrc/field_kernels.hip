@@ -278,15 +278,20 @@ __device__ __forceinline__ void grid_point(const float* __restrict__ d, const fl
     }
 }
 
+// `gradm` (optional, (C,3,D,H,W)): d(warped)/d(d_last) = the trilinear gradient of the moving image at the sampling
+// position, with the clamp mask -- exactly what warp_bwd_kernel multiplies the upstream gradient with.  The fused transition
+// lets the forward warp write it (the 8 taps are loaded anyway) and folds the product with g_warped into the staging of the
+// first adjoint squaring step, so the backward warp and its 24 B/voxel round trip disappear.
 __global__ __launch_bounds__(kBlock) void warp_fwd_kernel(const float* __restrict__ im, int64_t im_stride,
                                                           const float* __restrict__ d, const float* __restrict__ unif,
-                                                          Jitter jt, float* __restrict__ out, Vol vol, Lin lin) {
+                                                          Jitter jt, float* __restrict__ out, float* __restrict__ gradm,
+                                                          Vol vol, Lin lin) {
     IRS_VOXEL(vol, chain, x, y, z, vox);
     float g[3];
     grid_point(d, unif, jt, (int64_t)chain * 3 * vol.V, chain, vox, vol, lin, x, y, z, g);
     const AxisTap tx = axis_tap(g[0], vol.W), ty = axis_tap(g[1], vol.H), tz = axis_tap(g[2], vol.D);
     const float* src = im + (int64_t)chain * im_stride;
-    float acc = 0.0f;
+    float acc = 0.0f, gix = 0.0f, giy = 0.0f, giz = 0.0f;
 #pragma unroll
     for (int cz = 0; cz < 2; ++cz)
 #pragma unroll
@@ -294,11 +299,23 @@ __global__ __launch_bounds__(kBlock) void warp_fwd_kernel(const float* __restric
             const int64_t rowoff = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W;
 #pragma unroll
             for (int cx = 0; cx < 2; ++cx) {
-                const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
-                acc = __fadd_rn(acc, __fmul_rn(src[rowoff + (cx ? tx.i1 : tx.i0)], w));
+                const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
+                const float val = src[rowoff + (cx ? tx.i1 : tx.i0)];
+                acc = __fadd_rn(acc, __fmul_rn(val, __fmul_rn(__fmul_rn(wx, wy), wz)));
+                if (gradm) {  // same expressions as warp_bwd_kernel
+                    gix += (cx ? val : -val) * (wy * wz);
+                    giy += (cy ? val : -val) * (wx * wz);
+                    giz += (cz ? val : -val) * (wx * wy);
+                }
             }
         }
     out[(int64_t)chain * vol.V + vox] = acc;
+    if (gradm) {
+        const int64_t cb3 = (int64_t)chain * 3 * vol.V;
+        gradm[cb3 + vox] = tx.gmul * gix;
+        gradm[cb3 + vol.V + vox] = ty.gmul * giy;
+        gradm[cb3 + 2 * vol.V + vox] = tz.gmul * giz;
+    }
 }
 
 static Jitter make_jitter(float alpha, Vol vol, uint64_t seed, uint64_t iteration, const uint64_t* dev_iter) {
@@ -314,11 +331,11 @@ static Jitter make_jitter(float alpha, Vol vol, uint64_t seed, uint64_t iteratio
 }
 
 void launch_warp_fwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha, float* out,
-                     int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration, const uint64_t* dev_iteration,
-                     hipStream_t st) {
+                     float* gradm, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
+                     const uint64_t* dev_iteration, hipStream_t st) {
     const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL(warp_fwd_kernel, grid, dim3(kBlock), 0, st, im, im_stride, d, unif,
-                       make_jitter(alpha, vol, seed, iteration, dev_iteration), out, vol, lin);
+                       make_jitter(alpha, vol, seed, iteration, dev_iteration), out, gradm, vol, lin);
 }
 
 __global__ __launch_bounds__(kBlock) void warp_bwd_kernel(const float* __restrict__ im, int64_t im_stride,

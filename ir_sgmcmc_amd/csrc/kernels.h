@@ -35,8 +35,8 @@ void launch_exp_step_bwd(const float* G, const float* dk, float* gout, bool pres
 void launch_svf_outputs(const float* d, float* transformation, float* displacement, int C, Vol vol, Lin lin,
                         hipStream_t st);
 void launch_warp_fwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha, float* out,
-                     int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration, const uint64_t* dev_iteration,
-                     hipStream_t st);
+                     float* gradm, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
+                     const uint64_t* dev_iteration, hipStream_t st);
 void launch_warp_bwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha,
                      const float* g_warped, float* g_d, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
                      const uint64_t* dev_iteration, hipStream_t st);
@@ -57,9 +57,9 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale, int
 // the adjoint is launched as a set: gather radius 1, gather radius 2 and the scatter fallback; exactly one of them does
 // the work, chosen on the device from the bound max|d_k|
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
-                               Lin lin, const unsigned* dmax, int max_radius, hipStream_t st);
+                               Lin lin, const unsigned* dmax, int max_radius, const float* gscale, hipStream_t st);
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
-                             Lin lin, const unsigned* dmax, int halo, int gather_radius, hipStream_t st);
+                             Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, hipStream_t st);
 void launch_field_absmax(const float* d, bool prescale, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st);
 
 // ---- data_kernels.hip
