@@ -211,11 +211,14 @@ int irs_transition(irs_ctx* ctx, const irs_io* io, void* stream);
 typedef struct irs_timings {
     float total_ms;            /* whole transition */
     float exp_fwd_ms;          /* the no_steps scaling-and-squaring forward launches */
-    float exp_bwd_kernel_ms;   /* sum over the no_steps adjoint-step KERNEL launches only (events around each launch) */
+    float exp_bwd_kernel_ms;   /* sum over the no_steps radius-1 adjoint KERNEL launches (events around each launch) */
     float exp_bwd_total_ms;    /* adjoint loop including the gradient-buffer memsets */
     float smooth_ms;           /* perturbation + Sobolev smoothing (+ FFD up-sampling) */
     float data_ms;             /* warp, LCC map, statistics, GMM step, data term + adjoints, warp backward */
     float update_ms;           /* gradient assembly + SGLD update + bookkeeping */
+    float exp_bwd_primary_avg_ms; /* mean launch duration of the dominant kernel alone: the radius-1 adjoint step without
+                                     input prescale (steps 1 .. no_steps-1), events around exactly that launch -- the
+                                     number rocprofv3 reports for exp_bwd_march_kernel<false,1> */
 } irs_timings;
 int irs_transition_timed(irs_ctx* ctx, const irs_io* io, void* stream, irs_timings* out);
 

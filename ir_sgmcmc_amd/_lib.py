@@ -65,7 +65,7 @@ class IrsIO(C.Structure):
 
 class IrsTimings(C.Structure):
     _fields_ = [(n, C.c_float) for n in ('total_ms', 'exp_fwd_ms', 'exp_bwd_kernel_ms', 'exp_bwd_total_ms', 'smooth_ms',
-                                         'data_ms', 'update_ms')]
+                                         'data_ms', 'update_ms', 'exp_bwd_primary_avg_ms')]
 
 
 _P, _I, _F, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64
