@@ -38,7 +38,9 @@ int fail(const char* fmt, ...) {
     } while (0)
 
 bool dims_ok(int C, int D, int H, int W) {
-    return C >= 1 && D >= 2 && H >= 2 && W >= 2 && (int64_t)D * H * W < ((int64_t)1 << 40);
+    // < 2^30 voxels per volume: kernels address within a volume with 32-bit byte offsets (a 1024^3 transition would need
+    // 240 GB of workspace anyway)
+    return C >= 1 && D >= 2 && H >= 2 && W >= 2 && (int64_t)D * H * W < ((int64_t)1 << 30);
 }
 
 SplineTaps make_spline(int cps) {

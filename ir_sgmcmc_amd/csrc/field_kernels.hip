@@ -296,11 +296,12 @@ __global__ __launch_bounds__(kBlock) void warp_fwd_kernel(const float* __restric
     for (int cz = 0; cz < 2; ++cz)
 #pragma unroll
         for (int cy = 0; cy < 2; ++cy) {
-            const int64_t rowoff = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W;
+            // 32-bit element offsets from the (uniform) image base: a chain's volume has < 2^31 voxels (dims_ok)
+            const unsigned rowoff = (unsigned)(((cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W);
 #pragma unroll
             for (int cx = 0; cx < 2; ++cx) {
                 const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
-                const float val = src[rowoff + (cx ? tx.i1 : tx.i0)];
+                const float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + (size_t)((rowoff + (unsigned)(cx ? tx.i1 : tx.i0)) * 4u));
                 acc = __fadd_rn(acc, __fmul_rn(val, __fmul_rn(__fmul_rn(wx, wy), wz)));
                 if (gradm) {  // same expressions as warp_bwd_kernel
                     gix += (cx ? val : -val) * (wy * wz);
