@@ -166,6 +166,38 @@ def main():
         elapsed = float(t.item())
     assert bool(torch.isfinite(v).all()), 'chain diverged'
 
+    # ---- side measurements on rank 0 of a single-GPU run (outside the timed region) ------------------------------------
+    extras = {}
+    if world == 1 and dev.type == 'cuda':
+        # (1) the reference's own speed definition (trainer.py:467-476): every sample also warps the segmentation
+        #     (nearest neighbour) with the sampled transformation
+        from ir_sgmcmc_amd.ops import warp
+        seg = f1['seg'].unsqueeze(0).to(dev).contiguous() if 'seg' in f1 else torch.zeros(1, 1, *dims, dtype=torch.int16, device=dev)
+        outs = {'transformation': torch.empty(1, 3, *dims, device=dev), 'displacement': torch.empty(1, 3, *dims, device=dev)}
+        for _ in range(2):
+            eng.transition(fixed, moving, v, outputs=outs)
+            warp(seg, outs['transformation'])
+        sync()
+        n_seg = max(3, args.steps // 2)
+        t1 = time.perf_counter()
+        for _ in range(n_seg):
+            eng.transition(fixed, moving, v, outputs=outs)
+            warp(seg, outs['transformation'])
+        sync()
+        extras['with_transformation_output_and_seg_warp'] = {'value': n_seg / (time.perf_counter() - t1), 'unit': 'transitions/s',
+                                                             'definition': 'trainer.py:467-476 (transition + nearest-neighbour warp of the segmentation)'}
+        # (2) what a plain device copy of one field reaches on this box (planar fp32, same bytes as one squaring step reads + writes)
+        a, b = torch.empty(3 * V, device=dev), torch.empty(3 * V, device=dev)
+        for _ in range(3):
+            b.copy_(a)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            b.copy_(a)
+        sync()
+        extras['device_copy_GBps'] = 20 * 2 * 3 * V * 4 / (time.perf_counter() - t1) / 1e9
+        del a, b, outs
+
     # per-stage HIP-event timings (outside the timed region), averaged over a few transitions
     reps = max(3, min(10, args.steps))
     acc = None
@@ -203,11 +235,12 @@ def main():
                          'traffic': pmc_traffic_bytes(N), 'algorithmic_bytes_per_launch': BWD_STEP_BYTES_PER_VOXEL * V,
                          'avg_launch_ms': bwd_kernel_ms},
             'transition_roofline': {'algorithmic_bytes': BYTES_PER_VOXEL[args.loss] * V,
+                                    'frac_of_device_copy': (BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9 / extras['device_copy_GBps']) if 'device_copy_GBps' in extras else None,
                                     'achieved_GBps': BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9,
                                     'frac_of_8TBps': BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             'exp_step_fwd': {'avg_launch_ms': fwd_kernel_ms,
                              'achieved_GBps': FWD_STEP_BYTES_PER_VOXEL * V / (fwd_kernel_ms * 1e-3) / 1e9},
-            'stage_ms': tm, 'workspace_GB': eng.workspace_bytes / 1e9,
+            'stage_ms': tm, 'workspace_GB': eng.workspace_bytes / 1e9, **extras,
         }
         if not args.no_cpu_baseline and world == 1:
             n_small = min(args.cpu_size, N)
