@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/irsgmcmc.h"
 
@@ -28,6 +29,17 @@ __host__ __device__ inline Vol window(Vol v, int zlo, int zhi) {
     v.z0 = zlo;
     v.nz = zhi > zlo ? zhi - zlo : 0;
     return v;
+}
+
+// Segment length of the z-marching kernels.  32 planes amortise the run-in of a segment (2R .. 4S extra planes) when the
+// launch still has enough workgroups to fill 256 CUs; smaller volumes trade run-in overhead for parallelism, down to
+// `min_len`.  `forced` (> 0) is the environment override of the kernel family.
+inline int pick_seg_len(int nz, int64_t tiles_per_layer, int min_len, int forced) {
+    if (forced > 0) return forced;
+    static const int64_t want = getenv("IRS_SEG_MIN_BLOCKS") ? atoll(getenv("IRS_SEG_MIN_BLOCKS")) : 1024;
+    int len = 32;
+    while (len > min_len && tiles_per_layer * ((nz + len - 1) / len) < want) len >>= 1;
+    return len < 1 ? 1 : len;
 }
 
 inline dim3 vox_grid(const Vol& vol, int planes) {

@@ -589,8 +589,8 @@ constexpr int kRareGrid = 512;  // persistent grid of the rarely selected varian
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, const float* gscale, hipEvent_t after_primary,
                                hipStream_t st) {
-    static const int seg_env = getenv("IRS_MARCH_SEG") ? atoi(getenv("IRS_MARCH_SEG")) : 32;
-    const int seg_len = seg_env;
+    static const int seg_env = getenv("IRS_MARCH_SEG") ? atoi(getenv("IRS_MARCH_SEG")) : 0;
+    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * C, 8, seg_env);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const dim3 tiles((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
     const int total = (int)(tiles.x * tiles.y * tiles.z);
@@ -824,8 +824,8 @@ __global__ __launch_bounds__(kFwdBlock) void exp_fwd_march_kernel(const float* _
 
 void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
                                const unsigned* dmax_in, unsigned* dmax_out, bool only_r1, hipStream_t st) {
-    static const int seg_env = getenv("IRS_MARCH_SEG_FWD") ? atoi(getenv("IRS_MARCH_SEG_FWD")) : 32;
-    const int seg_len = seg_env;
+    static const int seg_env = getenv("IRS_MARCH_SEG_FWD") ? atoi(getenv("IRS_MARCH_SEG_FWD")) : 0;
+    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + FTX - 1) / FTX) * ((vol.H + FTY - 1) / FTY) * C, 8, seg_env);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const dim3 tiles((vol.W + FTX - 1) / FTX, (vol.H + FTY - 1) / FTY, (unsigned)(nseg * C));
     const int total = (int)(tiles.x * tiles.y * tiles.z);

@@ -159,8 +159,8 @@ __global__ __launch_bounds__(kStBlock) void sobolev_march_kernel(const float* __
 
 void launch_sobolev_march(const float* in, float* out, const Taps& taps, int planes, Vol vol, unsigned* dmax0, int no_steps,
                           hipStream_t st) {
-    static const int seg_env = getenv("IRS_SOBOLEV_SEG") ? atoi(getenv("IRS_SOBOLEV_SEG")) : 32;
-    const int seg_len = seg_env;
+    static const int seg_env = getenv("IRS_SOBOLEV_SEG") ? atoi(getenv("IRS_SOBOLEV_SEG")) : 0;
+    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + 31) / 32) * ((vol.H + 15) / 16) * planes, 8, seg_env);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const float inv_pow = 1.0f / (float)(1 << no_steps);
     // big tiles (64 x 32, eight outputs per thread: 1.33x halo work in the z pass, a quarter of the barriers per output)
@@ -345,10 +345,15 @@ __global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __
     }
 }
 
+// the LCC kernels re-read 4S planes per segment: never shorter than 16 planes
+static int lcc_seg_len(Vol vol, int C) {
+    static const int seg_env = getenv("IRS_LCC_SEG") ? atoi(getenv("IRS_LCC_SEG")) : 0;
+    return pick_seg_len(vol.nz, (int64_t)((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * C, 16, seg_env);
+}
+
 void launch_lcc_fwd_march(const float* fhat, int64_t fhat_stride, const float* im, float* z, float* sigma_out, int s, int C,
                           Vol vol, hipStream_t st) {
-    static const int seg_env = getenv("IRS_LCC_SEG") ? atoi(getenv("IRS_LCC_SEG")) : 32;
-    const int seg_len = seg_env;
+    const int seg_len = lcc_seg_len(vol, C);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + LMX - 1) / LMX, (vol.H + LMY - 1) / LMY, (unsigned)(nseg * C));
     const bool map = fhat != nullptr;
@@ -596,15 +601,14 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
 }
 
 int lcc_data_bwd_march_blocks(Vol vol) {
-    static const int seg_env = getenv("IRS_LCC_SEG") ? atoi(getenv("IRS_LCC_SEG")) : 32;
-    return ((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * ((vol.nz + seg_env - 1) / seg_env);
+    const int seg_len = lcc_seg_len(vol, 1);
+    return ((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * ((vol.nz + seg_len - 1) / seg_len);
 }
 
 void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* sigma_m, const uint8_t* mask,
                                const float* g_z_override, const void* dev_state, int chain, float* g_warped,
                                double* nll_partials, int s, Vol vol, hipStream_t st) {
-    static const int seg_env = getenv("IRS_LCC_SEG") ? atoi(getenv("IRS_LCC_SEG")) : 32;
-    const int seg_len = seg_env;
+    const int seg_len = lcc_seg_len(vol, 1);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + LMX - 1) / LMX, (vol.H + LMY - 1) / LMY, (unsigned)nseg);
     const DevState* state = (const DevState*)dev_state;
@@ -722,8 +726,8 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
 
 void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, int blocks,
                         Vol vol, hipStream_t st) {
-    static const int seg_env = getenv("IRS_STATS_SEG") ? atoi(getenv("IRS_STATS_SEG")) : 32;
-    const int seg_len = seg_env;
+    static const int seg_env = getenv("IRS_STATS_SEG") ? atoi(getenv("IRS_STATS_SEG")) : 0;
+    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY), 8, seg_env);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + QTY - 1) / QTY;
     hipLaunchKernelGGL(stats_march_kernel, dim3(blocks), dim3(kStBlock), 0, st, z, mask, (const DevState*)dev_state, want_vd,
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(kStBlock) void reg_energy_march_kernel(const float*
 }
 
 void launch_reg_energy_march(const float* v, double* partials, int blocks, int C, Vol vol, hipStream_t st) {
-    const int seg_len = 32;
+    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY), 8, 0);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + QTY - 1) / QTY;
     hipLaunchKernelGGL(reg_energy_march_kernel, dim3(blocks, C), dim3(kStBlock), 0, st, v, partials, vol, seg_len, nseg, ntx, nty);
@@ -918,8 +922,8 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
 
 void launch_sgld_update_march(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
                               float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st) {
-    static const int seg_env = getenv("IRS_UPDATE_SEG") ? atoi(getenv("IRS_UPDATE_SEG")) : 32;
-    const int seg_len = seg_env;
+    static const int seg_env = getenv("IRS_UPDATE_SEG") ? atoi(getenv("IRS_UPDATE_SEG")) : 0;
+    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY) * C, 8, seg_env);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + QTY - 1) / QTY;
     hipLaunchKernelGGL(sgld_update_march_kernel, dim3((unsigned)(ntx * nty * nseg * C)), dim3(kStBlock), 0, st, v, sigma, g_d0,
