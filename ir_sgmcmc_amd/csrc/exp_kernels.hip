@@ -1,9 +1,10 @@
 // Scaling-and-squaring step and its adjoint for gfx950 -- the dominant kernels of a transition (720 of its 878
 // algorithmic bytes per voxel).  Reference semantics: utils/transformation.py:70-73 and autograd through it.
 //
-// Both directions use a z-MARCHING schedule: a 256-thread workgroup owns a 32x8 column of output voxels over a segment of
-// 32 planes, keeps a ring of the last 2R+1 source planes in LDS, has the next plane's global loads in flight while it
-// works on the current one, and is placed so that x-adjacent tiles (which share halo cache lines) sit on one XCD.
+// Both directions use a z-MARCHING schedule: a 256-thread workgroup owns a column tile of output voxels (adjoint 32x8,
+// forward 64x8 with two rows per thread) over a segment of up to 32 planes, keeps a ring of the last source planes in LDS,
+// has the next plane's global loads in flight while it works on the current one, and is placed so that x-adjacent tiles
+// (which share halo cache lines) sit on one XCD.
 //
 //   forward   d_out = d + sample(d, id + d): taps from the ring (global memory only if a tap leaves it: any displacement
 //             is handled, the ring radius R in {1, 2} is a speed knob picked on the device from the published bound
@@ -277,15 +278,16 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
 }
 
 // ------------------------------------------------------------------------------------------------
-// adjoint step, z-marching gather (same mathematics as exp_bwd_gather_kernel, better schedule).
+// adjoint step, z-marching gather.
 // A 256-thread workgroup owns a 32x8 column of outputs over a z-segment and marches through the source planes, keeping
 // only a ring of NP = 2R+1 planes of source records in LDS (R=1: 37 KB -> 4 workgroups per CU).  Per plane step s:
-//   write the prefetched plane s into ring slot s mod NP (d, clipped sampling position p, G: 9 floats per source, SoA),
+//   write the prefetched plane s into ring slot s mod NP (d, clipped sampling position relative to the source voxel, G:
+//   9 floats per source, 8-byte fields),
 //   issue the global loads of plane s+1 (in flight during the compute), barrier,
 //   every thread reads the (2R+1)^2 records around its (x,y) once and adds them into the NP output accumulators it holds
 //   in registers (planes s-R..s+R), then output plane s-R is complete: add the identity path + grid-gradient
 //   (taps from the ring) and store it.
-// Halo redundancy is (32+2R)(8+2R)/(32*8) in-plane only (1.33x for R=1, vs 1.66x for the 3-D tile).
+// Halo redundancy is (32+2R)(8+2R)/(32*8) in-plane only (1.33x for R=1).
 // ------------------------------------------------------------------------------------------------
 #ifndef IRS_MTX
 #define IRS_MTX 32
