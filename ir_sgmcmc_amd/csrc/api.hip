@@ -105,7 +105,7 @@ constexpr int kHintWords = 4 * IRS_MAX_CHAINS * 32;  // same extent as the dmax 
 // (taps that leave its LDS ring are read from global memory), so a wrong guess costs time, not parity.  The adjoint keeps
 // launching every variant: an in-kernel generic fallback for its radius-1 kernel was measured to cost more (7 % on
 // every launch, from the larger kernel) than the two idle launches it saves.
-bool predicted_small(const irs_ctx* c, int k) {
+bool predicted_below(const irs_ctx* c, int k, float bound) {
     const int mode = env_int("IRS_PREDICT_VARIANTS", 1);  // 0: always launch every variant; 2: always predict small (tests)
     if (mode == 2) return true;
     if (!mode || !c->hint) return false;
@@ -118,8 +118,10 @@ bool predicted_small(const irs_ctx* c, int k) {
         if (!(f >= 0.0f)) return false;  // NaN / garbage
         m = f > m ? f : m;
     }
-    return m < 0.75f;
+    return m < bound;
 }
+
+bool predicted_small(const irs_ctx* c, int k) { return predicted_below(c, k, 0.75f); }
 }  // namespace
 
 extern "C" {
@@ -209,7 +211,7 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
         if (lds) {
             launch_field_absmax(dk, k == 0, no_steps, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, C, vol, st);
             const int rad = env_int("IRS_EXP_GATHER", 2);
-            if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, nullptr, nullptr, st);
+            if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, false, nullptr, nullptr, st);
             launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, rad, nullptr, st);
         } else {
             HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
@@ -770,9 +772,13 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
                 const float* gscale = fuse_warp_bwd && k == cfg.no_steps - 1 ? c->gM : nullptr;
                 // timed mode: the end event of step k closes right after the radius-1 kernel, so that exp_bwd_kernel_ms is
                 // the time of the dominant kernel alone (as rocprofv3 reports it), not of the idle variants after it
-                if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, gscale,
+                // the any-radius LDS-scatter kernel is launched only when the bound of d_k, as last seen by the host, is near
+                // 2 voxels; otherwise the (rarely selected) radius-2 kernel owns everything above one voxel -- through its
+                // generic in-kernel fallback if the bound exceeds its ring after all
+                const bool skip_any = rad >= 2 && predicted_below(c, k, 1.5f);
+                if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, skip_any, gscale,
                                                    timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
-                launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, gscale, st);
+                if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, gscale, st);
             }
             else launch_exp_step_bwd(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, st);
             if (timed && !(lds && env_int("IRS_EXP_GATHER", 2))) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k + 1], st));
@@ -923,7 +929,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
             float* out = ob == IRS_BUF_GRAD_A ? c->gA : c->gB;
             const float* dk = k == 0 ? vs : c->steps + (int64_t)(k - 1) * field;
             const unsigned* dm = c->dmax + (int64_t)k * C * 4;
-            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, nullptr, nullptr, st);
+            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, false, nullptr, nullptr, st);
             launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, 2, nullptr, st);
             break;
         }

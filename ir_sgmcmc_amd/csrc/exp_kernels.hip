@@ -331,12 +331,68 @@ struct March {
     static constexpr int NIT = (PN + kMarchBlock - 1) / kMarchBlock;
 };
 
+// Slow but always-correct adjoint of one squaring step for one (x, y) column over [z0, z1): every source within `hs` voxels is
+// read from global memory.  Lives only in the rarely selected radius-2 kernel, and only runs when the host did not launch the
+// any-radius LDS-scatter kernel for this step (it predicts the displacement bound from earlier transitions, see api.hip) and
+// the bound then turned out larger than 2 voxels -- a transient that costs time, never parity.
+template <bool PRESCALE>
+__device__ __forceinline__ void exp_bwd_generic_column(const float* __restrict__ Gc, const float* __restrict__ gsc,
+                                                       const float* __restrict__ c0, float* __restrict__ oc, const Vol vol,
+                                                       const Lin lin, const Scale3L sc, const int x, const int y, const int z0,
+                                                       const int z1, const int hs) {
+    const int64_t V = vol.V;
+    const float nxm = (float)(vol.W - 1), nym = (float)(vol.H - 1), nzm = (float)(vol.D - 1);
+    for (int zo = z0; zo < z1; ++zo) {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+        for (int sz = max(zo - hs, 0); sz <= min(zo + hs, vol.D - 1); ++sz)
+            for (int sy = max(y - hs, 0); sy <= min(y + hs, vol.H - 1); ++sy)
+                for (int sx = max(x - hs, 0); sx <= min(x + hs, vol.W - 1); ++sx) {
+                    const int64_t idx = ((int64_t)sz * vol.H + sy) * vol.W + sx;
+                    const float d0 = ldp<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow), d1 = ldp<PRESCALE>(c0 + V, idx, sc.nm1[1], sc.inv_pow),
+                                d2 = ldp<PRESCALE>(c0 + 2 * V, idx, sc.nm1[2], sc.inv_pow);
+                    const float px = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.x[sx], d0), 1.0f), 0.5f), nxm), 0.0f, nxm);
+                    const float py = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.y[sy], d1), 1.0f), 0.5f), nym), 0.0f, nym);
+                    const float pz = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.z[sz], d2), 1.0f), 0.5f), nzm), 0.0f, nzm);
+                    const float w = hat01(px - (float)x) * hat01(py - (float)y) * hat01(pz - (float)zo);
+                    if (w > 0.0f) {
+                        const float gm = gsc ? gsc[idx] : 1.0f;
+                        a0 = fmaf(w, Gc[idx] * gm, a0);
+                        a1 = fmaf(w, Gc[idx + V] * gm, a1);
+                        a2 = fmaf(w, Gc[idx + 2 * V] * gm, a2);
+                    }
+                }
+        // grid gradient of the sample taken at this voxel
+        const int64_t own = ((int64_t)zo * vol.H + y) * vol.W + x;
+        const float gmo = gsc ? gsc[own] : 1.0f;
+        const float G0 = Gc[own] * gmo, G1 = Gc[own + V] * gmo, G2 = Gc[own + 2 * V] * gmo;
+        const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], ldp<PRESCALE>(c0, own, sc.nm1[0], sc.inv_pow)), vol.W);
+        const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], ldp<PRESCALE>(c0 + V, own, sc.nm1[1], sc.inv_pow)), vol.H);
+        const AxisTap tz = axis_tap(__fadd_rn(lin.z[zo], ldp<PRESCALE>(c0 + 2 * V, own, sc.nm1[2], sc.inv_pow)), vol.D);
+        float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+        for (int cz = 0; cz < 2; ++cz)
+            for (int cy = 0; cy < 2; ++cy)
+                for (int cx = 0; cx < 2; ++cx) {
+                    const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
+                    const float dot = fmaf(ldp<PRESCALE>(c0 + 2 * V, idx, sc.nm1[2], sc.inv_pow), G2,
+                                           fmaf(ldp<PRESCALE>(c0 + V, idx, sc.nm1[1], sc.inv_pow), G1,
+                                                ldp<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow) * G0));
+                    const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
+                    gix += (cx ? dot : -dot) * (wy * wz);
+                    giy += (cy ? dot : -dot) * (wx * wz);
+                    giz += (cz ? dot : -dot) * (wx * wy);
+                }
+        oc[own] = (G0 + tx.gmul * gix) + a0;
+        oc[own + V] = (G1 + ty.gmul * giy) + a1;
+        oc[own + 2 * V] = (G2 + tz.gmul * giz) + a2;
+    }
+}
+
 template <bool PRESCALE, int R>
 __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, const float* __restrict__ dk,
                                                    float* __restrict__ gout, const Vol vol, const Lin lin, const Scale3L sc,
                                                    const unsigned* __restrict__ dmax, const int seg_len, const int nseg,
-                                                   const int r_lo, const int swz_run, const int tile_id, const dim3 tiles,
-                                                   const float* __restrict__ gscale) {
+                                                   const int r_lo, const int own_rest, const int swz_run, const int tile_id,
+                                                   const dim3 tiles, const float* __restrict__ gscale) {
     using M = March<PRESCALE, R>;
     constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
     // ring slot layout (9 floats per source, 8-byte fields so that the gather needs three ds_read_b64 per candidate):
@@ -349,15 +405,20 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     const int tile_ = xcd_swizzle_runs(tile_id, (int)(tiles.x * tiles.y * tiles.z), swz_run);
     const int tbx = tile_ % tiles.x, tby = (tile_ / tiles.x) % tiles.y, tbz = tile_ / (tiles.x * tiles.y);
     const int chain = tbz / nseg, seg = tbz % nseg;
-    {
-        const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
-                           (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
-        if (hs > R || hs <= r_lo) return;  // another variant of this step owns the chain
-    }
+    const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
+                       (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
+    if (hs <= r_lo || (hs > R && !(R == 2 && own_rest))) return;  // another variant of this step owns the chain
     const int ox = tbx * MTX, oy = tby * MTY;
     const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
+    if (R == 2 && hs > R) {  // the any-radius kernel was not launched for this step and the bound outgrew the ring
+        const int gx = ox + (int)(threadIdx.x % MTX), gy = oy + (int)(threadIdx.x / MTX);
+        if (gx < vol.W && gy < vol.H)
+            exp_bwd_generic_column<PRESCALE>(G + cb, gscale ? gscale + (int64_t)chain * V : nullptr, dk + cb, gout + cb, vol, lin, sc, gx,
+                                             gy, z0, z1, hs);
+        return;
+    }
     const float* __restrict__ dx_ = dk + cb;
     const float* __restrict__ dy_ = dx_ + V;
     const float* __restrict__ dz_ = dy_ + V;
@@ -579,18 +640,18 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
 template <bool PRESCALE, int R>
 __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp_bwd_march_kernel(
     const float* __restrict__ G, const float* __restrict__ dk, float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
-    const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int swz_run, dim3 tiles,
+    const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int own_rest, int swz_run, dim3 tiles,
     const float* __restrict__ gscale) {
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     for (int id = blockIdx.x; id < total; id += gridDim.x)
-        exp_bwd_march_tile<PRESCALE, R>(G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, r_lo, swz_run, id, tiles, gscale);
+        exp_bwd_march_tile<PRESCALE, R>(G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, r_lo, own_rest, swz_run, id, tiles, gscale);
 }
 
 constexpr int kRareGrid = 512;  // persistent grid of the rarely selected variants (two workgroups per CU)
 
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
-                               Lin lin, const unsigned* dmax, int max_radius, const float* gscale, hipEvent_t after_primary,
-                               hipStream_t st) {
+                               Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale,
+                               hipEvent_t after_primary, hipStream_t st) {
     static const int seg_env = getenv("IRS_MARCH_SEG") ? atoi(getenv("IRS_MARCH_SEG")) : 0;
     const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * C, 8, seg_env);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
@@ -599,7 +660,7 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
     const Scale3L sc = make_scale_l(vol, no_steps);
     static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;  // 0/1: no remap; default: one x-row of tiles per XCD run
-#define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, (GRID) == total ? swz_run : 0, tiles, gscale)
+#define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale)
     const int rare = total < kRareGrid ? total : kRareGrid;
     // the radius-1 kernel first (the one the roofline is quoted on: `after_primary` brackets exactly its launch), then the
     // rarely selected radius-2 variant on the small persistent grid

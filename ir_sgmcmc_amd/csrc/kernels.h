@@ -57,8 +57,8 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale, int
 // the adjoint is launched as a set: gather radius 1, gather radius 2 and the scatter fallback; exactly one of them does
 // the work, chosen on the device from the bound max|d_k|
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
-                               Lin lin, const unsigned* dmax, int max_radius, const float* gscale, hipEvent_t after_primary,
-                               hipStream_t st);
+                               Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale,
+                               hipEvent_t after_primary, hipStream_t st);
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
                              Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, hipStream_t st);
 void launch_field_absmax(const float* d, bool prescale, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st);

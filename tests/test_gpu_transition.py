@@ -176,11 +176,12 @@ def test_in_kernel_noise_path_runs_and_is_reproducible():
     assert float((res[0] - res[2]).abs().max()) > 1e-2 * float(res[0].abs().max())
 
 
-@pytest.mark.parametrize('amp', [0.3, 1.6, 3.5])
+@pytest.mark.parametrize('amp', [0.3, 1.6, 3.5, 7.0])
 def test_variant_prediction_never_changes_the_result(amp, monkeypatch):
-    """Which forward squaring-step variants get launched is decided on the host from the (unsynchronised) displacement
-    bounds of an earlier transition.  Whatever the decision -- every variant (mode 0), the production heuristic (1), or
-    always 'small' (2: the radius-1 kernel alone, far taps from global memory) -- the transition is the same."""
+    """Which squaring-step variants get launched is decided on the host from the (unsynchronised) displacement bounds of an
+    earlier transition.  Whatever the decision -- every variant (mode 0), the production heuristic (1), or always 'small'
+    (2: forward steps on the radius-1 kernel alone with far taps from global memory; adjoint steps without the any-radius
+    kernel, the radius-2 kernel falling back to its generic gather above two voxels) -- the transition is the same."""
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from ir_sgmcmc_amd.ops import perturb_smooth, sobolev_kernel_1d
     N = 24
