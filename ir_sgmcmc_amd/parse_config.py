@@ -95,6 +95,11 @@ class ConfigParser:
         self['transformation_module'].setdefault('args', {})['dims'] = self['data_loader']['args']['dims']
         return self.init_obj('transformation_module', transformation), self.init_obj('registration_module', registration)
 
+    def init_optimizer_q_v(self, var_params_q_v):
+        a = self['optimizer_q_v']['args']   # parse_config.py:226-232
+        return Adam([{'params': [var_params_q_v['mu']], 'lr': a['lr_mu']}, {'params': [var_params_q_v['log_var']], 'lr': a['lr_log_var']},
+                     {'params': [var_params_q_v['u']], 'lr': a['lr_u']}], lr_decay=a['lr_decay'])
+
     def init_optimizer_GMM(self, data_loss):
         if self['optimizer_GMM']['type'] != 'Adam':
             raise RuntimeError('only the Adam optimiser is supported for the GMM')

@@ -4,8 +4,8 @@ Kept surface (same names, arguments and return values as the reference):
   `Trainer(config, data_loader, losses, transformation_module, registration_module, metrics)`, `.run()`,
   `_SGLD_transition(fixed, moving, data_loss, reg_loss) -> (loss_terms, output, aux)`  (trainer.py:291-356),
   `step(...)` (alias asked for by BASELINE.json), `_run_MCMC` (:358-476), `_step_GMM` (:68-77).
-The VI stage (`_run_VI`, `_test_VI`) is out of scope: configs with `"VI": true` only use
-the VI *initialisation* of the chains (mu + eps sigma + x u with the data loader's initial variational parameters).
+The VI stage (`_run_VI`, `_test_VI`, trainer/vi.py) is composed in torch from the HIP-backed modules, as the reference
+composes it; it hands its hyper-parameters and optimiser moments to the fused engine before the MCMC stage.
 
 Inside `_SGLD_transition` nothing runs in torch: one call into the C ABI launches the whole transition on the current
 HIP stream (ir_sgmcmc_amd/csrc/api.hip: transition_impl).  The hyper-parameters of the loss objects are mirrored into
@@ -20,6 +20,7 @@ from ..base import BaseTrainer
 from ..engine import EngineConfig, TransitionEngine
 from ..logger import save_displacement_mean_and_std_dev, save_sample
 from ..utils import calc_norm, calc_no_non_diffeomorphic_voxels, calc_DSC_GPU, sample_q_v
+from .vi import VIMixin
 
 
 class LazyScalar:
@@ -42,7 +43,7 @@ class LazyScalar:
         return f'{self.item():.6g}'
 
 
-class Trainer(BaseTrainer):
+class Trainer(VIMixin, BaseTrainer):
     def __init__(self, config, data_loader, losses, transformation_module, registration_module, metrics, device='cuda:0'):
         super().__init__(config, data_loader, losses, transformation_module, registration_module, metrics, device)
         self.Sobolev_grad = config['Sobolev_grad']['enabled']
@@ -176,10 +177,6 @@ class Trainer(BaseTrainer):
         self.load_state_dict(torch.load(file_path, map_location='cpu', weights_only=False))
 
     # ---------------------------------------------------------------- reference-named pieces
-    def _step_GMM(self, residuals=None, alpha=1.0):
-        """trainer.py:68-77 happens inside the fused transition (csrc/scalar_kernels.hip: chain_scalar_kernel)."""
-        raise RuntimeError('_step_GMM is fused into _SGLD_transition / __GMM_init on the device')
-
     def _SGLD_init(self, var_params_q_v):
         """Trainer.__SGLD_init (trainer.py:585-611)"""
         shape = [self.no_chains, 3, *var_params_q_v['mu'].shape[-3:]]
@@ -331,7 +328,16 @@ class Trainer(BaseTrainer):
             moving = {k: v.to(self.device) for k, v in moving.items()}
             self._engine_init(fixed, moving)
             self._GMM_init(fixed, moving, var_params_q_v)
+            var_params_q_v = {k: v.to(self.device) for k, v in var_params_q_v.items()}
+            self._sobolev_init()
+            self._init_optimizers()
             if self.VI:
-                self.logger.info('VI stage is out of scope here: chains start from the initial variational parameters')
+                start = time.perf_counter()
+                self._run_VI(fixed, moving, var_params_q_v)
+                torch.cuda.synchronize()
+                self.logger.info(f'VI took {time.perf_counter() - start:.2f} seconds')
+                self._test_VI(fixed, moving, var_params_q_v)
+                self._push_hyperparameters_to_engine()
+                var_params_q_v = {k: v.detach() for k, v in var_params_q_v.items()}
             if self.MCMC:
                 self._run_MCMC(fixed, moving, var_params_q_v)

@@ -122,6 +122,36 @@ def calc_DSC_GPU(no_samples, seg_fixed, seg_moving, structures_dict):
     return DSC.numpy()
 
 
+def rescale_residuals(res, mask, data_loss):
+    """VD-rescaled residual x = sum_k r_k (z / sigma_k)^2 (utils/util.py:330-347).  The reference obtains it as
+    sum_k s_k * d(-log p)/d(s_k) with a nested backward; the closed form with the responsibilities r_k is the same number."""
+    with torch.no_grad():
+        z = torch.where(mask, res, torch.zeros_like(res)).reshape(1, -1, 1)
+        s = z * torch.exp(-1.0 * data_loss.log_std)
+        t = (data_loss.log_proportions - data_loss.log_std) - 0.5 * s ** 2
+        r = torch.softmax(t, dim=-1)
+        return torch.sum(r * s * s, dim=-1).view(res.shape)
+
+
+@torch.no_grad()
+def calc_VD_factor(residual, mask):
+    """virtual decimation factor from the lag-1 correlations of the rescaled residual (utils/util.py:446-485)"""
+    var_res = torch.mean(residual[mask] ** 2)
+    n = mask.sum()
+    rm = torch.where(mask, residual, torch.zeros_like(residual))
+    cov = [torch.sum(rm[:, :, :-1] * rm[:, :, 1:]) / n, torch.sum(rm[:, :, :, :-1] * rm[:, :, :, 1:]) / n,
+           torch.sum(rm[:, :, :, :, :-1] * rm[:, :, :, :, 1:]) / n]
+    sq = [torch.clamp(-2.0 / math.pi * torch.log(c / var_res), max=1.0) for c in cov]
+    return torch.sqrt(sq[0] * sq[1] * sq[2])
+
+
+@torch.no_grad()
+def max_field_update(field_old, field_new):
+    """largest voxel-wise update of a vector field in the L2 norm and its index (utils/util.py:281-299)"""
+    diff = torch.abs(calc_norm(field_new) - calc_norm(field_old))   # difference of the norms, as the reference defines it
+    return torch.max(diff), torch.argmax(diff)
+
+
 class MetricTracker:
     """running means keyed by name (utils/util.py:488-510 without the pandas dependency)"""
 

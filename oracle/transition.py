@@ -253,3 +253,91 @@ class OracleChain:
                    displacement=displacement.detach(), im_moving_warped=im_warped.detach(),
                    residuals=z.detach())
         return out
+
+
+# ------------------------------------------------------------------------------------------------
+# VI stage (trainer/trainer.py:79-223): q(v) = N(mu, diag(exp(log_var)) + u u^T), an antithetic sample pair per iteration.
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class OracleVIConfig:
+    lr_mu: float = 0.01
+    lr_log_var: float = 0.01
+    lr_u: float = 0.01
+    lr_decay: float = 0.001
+
+
+def entropy_terms(sample=None, mu=None, log_var=None, u=None):
+    """EntropyMultivariateNormal.forward (model/loss.py:342-372): the sample-dependent term, or (sample=None) the
+    log-determinant term."""
+    sigma = torch.exp(0.5 * log_var)
+    dims = (1, 2, 3, 4)
+    if sample is None:
+        return 0.5 * (torch.log1p(torch.sum(torch.pow(u / sigma, 2), dim=dims)) + torch.sum(log_var, dim=dims))
+    sample_n, u_n = (sample - mu) / sigma, u / sigma
+    t1 = torch.sum(torch.pow(sample_n, 2), dim=dims)
+    t2 = torch.pow(torch.sum(sample_n * u_n, dim=dims), 2) / (1.0 + torch.sum(torch.pow(u_n, 2), dim=dims))
+    return 0.5 * (t1 - t2)
+
+
+class OracleVI:
+    """`Trainer._run_VI` body on top of an OracleChain (which owns the GMM / regulariser parameters and their optimisers)."""
+
+    def __init__(self, chain: OracleChain, var_params, vi: OracleVIConfig = OracleVIConfig()):
+        self.chain, self.vi = chain, vi
+        self.vp = {k: v.clone().requires_grad_(True) for k, v in var_params.items()}
+        self.adam = ops.AdamRateDecay([{'params': [self.vp['mu']], 'lr': vi.lr_mu}, {'params': [self.vp['log_var']], 'lr': vi.lr_log_var},
+                                       {'params': [self.vp['u']], 'lr': vi.lr_u}], lr_decay=vi.lr_decay)
+
+    def sample_loss(self, fixed, moving, v_unsmoothed, unif):
+        """__calc_sample_loss_VI (trainer.py:79-117); steps the GMM as a side effect."""
+        ch, cfg = self.chain, self.chain.cfg
+        v_s = ch.smooth(v_unsmoothed)
+        transformation, displacement = ch.transform(v_s)
+        grid = transformation if cfg.uniform_noise is None else ops.jitter_grid(transformation, cfg.uniform_noise, unif)
+        warped = ops.warp_trilinear(moving['im'], grid)
+        z = ch.residual(fixed['im'], warped)
+        alpha = ch.vd_alpha(z, fixed['mask'])
+        zm = z[fixed['mask']]
+        ch.step_gmm(zm, alpha)
+        data = ch.nll(zm) * alpha
+        reg, log_y = ch.reg_terms(v_s)
+        terms = {'data': data, 'reg': reg.sum(),
+                 'entropy': entropy_terms(v_unsmoothed, self.vp['mu'], self.vp['log_var'], self.vp['u']).sum()}
+        if cfg.reg_learnable:
+            if cfg.reg_loss == 'RegLoss_LogNormal':
+                terms['reg_loc_prior'] = ops.expgamma_log_pdf(log_y, 0.5 * cfg.reg_loc_prior_nu * cfg.dof,
+                                                              0.5 * cfg.reg_loc_prior_nu * cfg.w_reg).sum()
+            else:
+                shape = 0.5 * cfg.dof
+                terms['w_reg_prior'] = ops.expgamma_log_pdf(ch.log_w_reg, shape, 1.0 / shape)
+        return terms, {'displacement': displacement.detach(), 'im_moving_warped': warped.detach(), 'alpha': float(alpha)}
+
+    def step(self, fixed, moving, eps, x, unif_pair=(None, None)):
+        """One VI iteration with the antithetic pair mu +- (eps sigma + x u) (utils/sampler.py:4-21)."""
+        ch, cfg, vp = self.chain, self.chain.cfg, self.vp
+        sigma = torch.exp(0.5 * vp['log_var'])
+        pert = eps * sigma + x * vp['u']
+        t1, out, = self.sample_loss(fixed, moving, vp['mu'] + pert, unif_pair[0])[:2]
+        t2, _ = self.sample_loss(fixed, moving, vp['mu'] - pert, unif_pair[1])
+        data = (t1['data'] + t2['data']) / 2.0
+        if cfg.data_loss == 'GMM':
+            data = data - ch.gmm_prior_terms()
+        reg = (t1['reg'] + t2['reg']) / 2.0
+        if cfg.reg_learnable:
+            if cfg.reg_loss == 'RegLoss_LogNormal':
+                reg = reg - (t1['reg_loc_prior'] + t2['reg_loc_prior']) / 2.0
+                reg = reg - ops.normal_log_pdf(ch.log_scale, *cfg.reg_scale_prior).sum()
+            else:
+                reg = reg - (t1['w_reg_prior'] + t2['w_reg_prior']) / 2.0
+        entropy = (t1['entropy'] + t2['entropy']) / 2.0 + entropy_terms(None, None, vp['log_var'], vp['u']).sum()
+        loss = data + reg - entropy
+        params = [vp['mu'], vp['log_var'], vp['u']]
+        n_q = len(params)
+        if ch.adam_reg is not None:
+            params += [p for g in ch.adam_reg.groups for p in g['params']]
+        grads = torch.autograd.grad(loss, params)
+        if ch.adam_reg is not None:
+            ch.adam_reg.step(list(grads[n_q:]))
+        self.adam.step(list(grads[:n_q]))
+        return {'data': float(data), 'reg': float(reg), 'entropy': float(entropy), 'loss': float(loss), 'alpha': out['alpha'],
+                'displacement': out['displacement']}

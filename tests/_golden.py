@@ -12,7 +12,8 @@ from oracle import OracleConfig
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-def golden_names(prefix=''):
+def golden_names(prefix='n'):
+    """transition fixtures are named n<size>_...; the VI fixtures vi_... have their own loader (tests/test_vi.py)"""
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + '*.npz')))
 
 
