@@ -122,6 +122,20 @@ bool predicted_below(const irs_ctx* c, int k, float bound) {
 }
 
 bool predicted_small(const irs_ctx* c, int k) { return predicted_below(c, k, 0.75f); }
+
+// Layouts of the INTERNAL fields of the fused path (exp_kernels.hip: Lay3; bits 1 displacement in, 2 gradient in, 4 out):
+// d_1 .. d_{n-1} and the gradients handed from one adjoint step to the next are interleaved ([V][3]); everything that crosses
+// into another kernel family -- the velocity in, d_n into the warp, the gradient into the first and out of the last adjoint
+// step -- stays planar like the reference's tensors.  The staged (z-slab) and stateless entry points are planar throughout.
+bool aos_enabled() { return use_lds_exp() && env_int("IRS_AOS", 1) != 0; }
+int fwd_lay(const irs_ctx* c, int k) {
+    if (!aos_enabled()) return 0;
+    return (k > 0 ? 1 : 0) | (k < c->cfg.no_steps - 1 ? 4 : 0);
+}
+int bwd_lay(const irs_ctx* c, int k) {
+    if (!aos_enabled()) return 0;
+    return (k > 0 ? 1 : 0) | (k < c->cfg.no_steps - 1 ? 2 : 0) | (k > 0 ? 4 : 0);
+}
 }  // namespace
 
 extern "C" {
@@ -185,7 +199,7 @@ int irs_svf_exp_fwd(const float* v, float* steps, float* transformation, float* 
     const int64_t field = (int64_t)C * 3 * vol.V;
     for (int k = 0; k < no_steps; ++k) {
         const float* in = k == 0 ? v : steps + (int64_t)(k - 1) * field;
-        if (use_lds_exp()) launch_exp_step_fwd_march(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, nullptr, nullptr, false, st);
+        if (use_lds_exp()) launch_exp_step_fwd_march(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, nullptr, nullptr, false, 0, st);
         else launch_exp_step_fwd(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, st);
     }
     if (transformation || displacement)
@@ -211,8 +225,8 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
         if (lds) {
             launch_field_absmax(dk, k == 0, no_steps, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, C, vol, st);
             const int rad = env_int("IRS_EXP_GATHER", 2);
-            if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, false, nullptr, nullptr, st);
-            launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, rad, nullptr, st);
+            if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, false, nullptr, 0, nullptr, st);
+            launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, rad, nullptr, 0, st);
         } else {
             HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
             launch_exp_step_bwd(G, dk, out, k == 0, no_steps, C, vol, lin, st);
@@ -672,7 +686,7 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
         float* out = c->steps + (int64_t)k * field;
         if (lds)
             launch_exp_step_fwd_march(in, out, k == 0, cfg.no_steps, C, c->vol, lin, c->dmax + (int64_t)k * c->C * 4,
-                                      c->dmax + (int64_t)(k + 1) * c->C * 4, predicted_small(c, k), st);
+                                      c->dmax + (int64_t)(k + 1) * c->C * 4, predicted_small(c, k), fwd_lay(c, k), st);
         else launch_exp_step_fwd(in, out, k == 0, cfg.no_steps, C, c->vol, lin, st);
     }
     if (timed) HIP_TRY(hipEventRecord(c->ev[2], st));
@@ -776,9 +790,10 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
                 // 2 voxels; otherwise the (rarely selected) radius-2 kernel owns everything above one voxel -- through its
                 // generic in-kernel fallback if the bound exceeds its ring after all
                 const bool skip_any = rad >= 2 && predicted_below(c, k, 1.5f);
-                if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, skip_any, gscale,
+                const int lay = bwd_lay(c, k);
+                if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, skip_any, gscale, lay,
                                                    timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
-                if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, gscale, st);
+                if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, gscale, lay, st);
             }
             else launch_exp_step_bwd(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, st);
             if (timed && !(lds && env_int("IRS_EXP_GATHER", 2))) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k + 1], st));
@@ -884,7 +899,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
         case IRS_ST_EXP_FWD: {
             const float* in = k == 0 ? vs : c->steps + (int64_t)(k - 1) * field;
             launch_exp_step_fwd_march(in, c->steps + (int64_t)k * field, k == 0, cfg.no_steps, C, w, lin, c->dmax + (int64_t)k * C * 4,
-                                      c->dmax + (int64_t)(k + 1) * C * 4, false, st);
+                                      c->dmax + (int64_t)(k + 1) * C * 4, false, 0, st);
             break;
         }
         case IRS_ST_OUTPUTS:
@@ -929,8 +944,8 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
             float* out = ob == IRS_BUF_GRAD_A ? c->gA : c->gB;
             const float* dk = k == 0 ? vs : c->steps + (int64_t)(k - 1) * field;
             const unsigned* dm = c->dmax + (int64_t)k * C * 4;
-            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, false, nullptr, nullptr, st);
-            launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, 2, nullptr, st);
+            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, false, nullptr, 0, nullptr, st);
+            launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, 2, nullptr, 0, st);
             break;
         }
         case IRS_ST_UPDATE: {

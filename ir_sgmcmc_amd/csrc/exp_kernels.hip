@@ -32,6 +32,17 @@ __device__ __forceinline__ float ldp(const float* __restrict__ p, int64_t i, flo
     return PRESCALE ? prescale(v, nm1, inv_pow) : v;
 }
 
+// Layout of the squaring-step working fields: planar ([3][V], the reference's tensors) or interleaved ([V][3]).  The fused
+// transition keeps its INTERNAL fields (d_1 .. d_{n-1}, the gradients between adjoint steps) interleaved: a halo row of an
+// interleaved field is one contiguous 12 (W + 2) byte segment, and the staging rate of a marching kernel grows with the
+// length of the segments it reads (tools/bw_probe.hip: 3.9 -> 4.9 TB/s for the 32x8 skeleton).  Element (c, i) of a chain's
+// field lives at base[c * cs + i * em]; `lay` bits: 1 displacement input, 2 gradient input, 4 output.
+struct Lay3 {
+    int64_t cs;
+    int em;
+};
+__host__ __device__ __forceinline__ Lay3 lay3(int aos, int64_t V) { return aos ? Lay3{1, 3} : Lay3{V, 1}; }
+
 __device__ __forceinline__ void atomic_max_nonneg(unsigned* addr, float v) {
     // non-negative floats order like their bit patterns
     atomicMax(addr, __float_as_uint(v));
@@ -52,17 +63,17 @@ struct ExpBox {
 
 // stage d (3 channels, optionally prescaled) over tile +/- H into LDS; coordinates are clamped to the volume
 template <bool PRESCALE, int H>
-__device__ __forceinline__ void stage_field(const float* __restrict__ c0, float* __restrict__ lds, int ox, int oy, int oz,
-                                            const Vol vol, const Scale3L sc) {
+__device__ __forceinline__ void stage_field(const float* __restrict__ c0, const Lay3 LD, float* __restrict__ lds, int ox, int oy,
+                                            int oz, const Vol vol, const Scale3L sc) {
     using B = ExpBox<H>;
     for (int i = threadIdx.x; i < B::SN; i += kExpBlock) {
         const int lx = i % B::SX, ly = (i / B::SX) % B::SY, lz = i / (B::SX * B::SY);
         const int gx = min(max(ox - H + lx, 0), vol.W - 1), gy = min(max(oy - H + ly, 0), vol.H - 1),
                   gz = min(max(oz - H + lz, 0), vol.D - 1);
         const int64_t g = ((int64_t)gz * vol.H + gy) * vol.W + gx;
-        lds[i] = ldp<PRESCALE>(c0, g, sc.nm1[0], sc.inv_pow);
-        lds[B::SN + i] = ldp<PRESCALE>(c0 + vol.V, g, sc.nm1[1], sc.inv_pow);
-        lds[2 * B::SN + i] = ldp<PRESCALE>(c0 + 2 * vol.V, g, sc.nm1[2], sc.inv_pow);
+        lds[i] = ldp<PRESCALE>(c0, g * LD.em, sc.nm1[0], sc.inv_pow);
+        lds[B::SN + i] = ldp<PRESCALE>(c0 + LD.cs, g * LD.em, sc.nm1[1], sc.inv_pow);
+        lds[2 * B::SN + i] = ldp<PRESCALE>(c0 + 2 * LD.cs, g * LD.em, sc.nm1[2], sc.inv_pow);
     }
 }
 
@@ -91,11 +102,10 @@ static dim3 exp_grid(Vol vol, int C, TileGrid* tg) {
 template <bool PRESCALE, int H>
 __device__ __forceinline__ void adjoint_source(const int x, const int y, const int z, const float d0, const float d1,
                                                const float d2, const int ox, const int oy, const int oz,
-                                               const float* __restrict__ Gc, const float* __restrict__ gs_,
-                                               const float* __restrict__ c0, const float* __restrict__ lds,
+                                               const float* __restrict__ Gc, const Lay3 LG, const float* __restrict__ gs_,
+                                               const float* __restrict__ c0, const Lay3 LD, const float* __restrict__ lds,
                                                float* __restrict__ acc, const Vol vol, const Lin lin, const Scale3L sc) {
     using B = ExpBox<H>;
-    const int64_t V = vol.V;
     const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
     const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
     const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
@@ -106,7 +116,7 @@ __device__ __forceinline__ void adjoint_source(const int x, const int y, const i
     if (!any && !self_in) return;
     const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
     const float gsc = gs_ ? gs_[g] : 1.0f;  // optional scalar factor of the incoming gradient (fused backward warp)
-    const float G0 = Gc[g] * gsc, G1 = Gc[V + g] * gsc, G2 = Gc[2 * V + g] * gsc;
+    const float G0 = Gc[g * LG.em] * gsc, G1 = Gc[LG.cs + g * LG.em] * gsc, G2 = Gc[2 * LG.cs + g * LG.em] * gsc;
     if (any) {
         // per-axis weights with out-of-tile corners zeroed: the scatter becomes 8 unconditional-weight products
         const float wx0 = (unsigned)ax0 < (unsigned)ETX ? tx.w0 : 0.0f, wx1 = (unsigned)ax1 < (unsigned)ETX ? tx.w1 : 0.0f;
@@ -154,9 +164,9 @@ __device__ __forceinline__ void adjoint_source(const int x, const int y, const i
                         v2 = lds[2 * B::SN + idx];
                     } else {
                         const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
-                        v0 = ldp<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow);
-                        v1 = ldp<PRESCALE>(c0 + V, idx, sc.nm1[1], sc.inv_pow);
-                        v2 = ldp<PRESCALE>(c0 + 2 * V, idx, sc.nm1[2], sc.inv_pow);
+                        v0 = ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.inv_pow);
+                        v1 = ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.inv_pow);
+                        v2 = ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.inv_pow);
                     }
                     const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
                     const float dot = v0 * G0 + v1 * G1 + v2 * G2;
@@ -175,8 +185,9 @@ template <bool PRESCALE, int H>
 __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __restrict__ G, const float* __restrict__ dk,
                                                                 float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
                                                                 const unsigned* __restrict__ dmax, TileGrid tg,
-                                                                int gather_radius, const float* __restrict__ gscale) {
+                                                                int gather_radius, const float* __restrict__ gscale, int lay) {
     using B = ExpBox<H>;
+    const Lay3 LD = lay3(lay & 1, vol.V), LG = lay3(lay & 2, vol.V), LO = lay3(lay & 4, vol.V);
     __shared__ float lds[3 * B::SN];
     __shared__ float acc[3 * ETN];
     {   // nothing to do for any chain (the usual case): leave before walking the tile list
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
     const float* Gc = G + cb;
     const float* gsc_ = gscale ? gscale + (int64_t)chain * V : nullptr;
 
-    stage_field<PRESCALE, H>(c0, lds, ox, oy, oz, vol, sc);
+    stage_field<PRESCALE, H>(c0, LD, lds, ox, oy, oz, vol, sc);
     for (int i = threadIdx.x; i < 3 * ETN; i += kExpBlock) acc[i] = 0.0f;
 
     // source halo: a voxel at distance h from the tile can reach it iff h <= floor(max|d|) + 1 (corner = floor(x+d) + {0,1})
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
             const int lx = i % B::SX, ly = (i / B::SX) % B::SY, lz = i / (B::SX * B::SY);
             const int x = ox - H + lx, y = oy - H + ly, z = oz - H + lz;
             if ((unsigned)x >= (unsigned)vol.W || (unsigned)y >= (unsigned)vol.H || (unsigned)z >= (unsigned)vol.D) continue;
-            adjoint_source<PRESCALE, H>(x, y, z, lds[i], lds[B::SN + i], lds[2 * B::SN + i], ox, oy, oz, Gc, gsc_, c0, lds, acc,
+            adjoint_source<PRESCALE, H>(x, y, z, lds[i], lds[B::SN + i], lds[2 * B::SN + i], ox, oy, oz, Gc, LG, gsc_, c0, LD, lds, acc,
                                         vol, lin, sc);
         }
     } else {
@@ -241,11 +252,11 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
                 d2 = lds[2 * B::SN + ctr];
             } else {
                 const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-                d0 = ldp<PRESCALE>(c0, g, sc.nm1[0], sc.inv_pow);
-                d1 = ldp<PRESCALE>(c0 + V, g, sc.nm1[1], sc.inv_pow);
-                d2 = ldp<PRESCALE>(c0 + 2 * V, g, sc.nm1[2], sc.inv_pow);
+                d0 = ldp<PRESCALE>(c0, g * LD.em, sc.nm1[0], sc.inv_pow);
+                d1 = ldp<PRESCALE>(c0 + LD.cs, g * LD.em, sc.nm1[1], sc.inv_pow);
+                d2 = ldp<PRESCALE>(c0 + 2 * LD.cs, g * LD.em, sc.nm1[2], sc.inv_pow);
             }
-            adjoint_source<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, Gc, gsc_, c0, lds, acc, vol, lin, sc);
+            adjoint_source<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, Gc, LG, gsc_, c0, LD, lds, acc, vol, lin, sc);
         }
     }
     __syncthreads();
@@ -255,20 +266,20 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
         const int x = ox + lx, y = oy + ly, z = oz + lz;
         if (x >= vol.W || y >= vol.H || z >= vol.z0 + vol.nz) continue;
         const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-        o[g] = acc[i];
-        o[g + V] = acc[ETN + i];
-        o[g + 2 * V] = acc[2 * ETN + i];
+        o[g * LO.em] = acc[i];
+        o[LO.cs + g * LO.em] = acc[ETN + i];
+        o[2 * LO.cs + g * LO.em] = acc[2 * ETN + i];
     }
     __syncthreads();
   }
 }
 
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
-                             Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, hipStream_t st) {
+                             Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, int lay, hipStream_t st) {
     TileGrid tz;
     const dim3 grid = exp_grid(vol, C, &tz);
     const Scale3L sc = make_scale_l(vol, no_steps);
-#define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale)
+#define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay)
     if (prescale_in) {
         if (halo <= 1) IRS_BWD(true, 1); else IRS_BWD(true, 2);
     } else {
@@ -312,6 +323,17 @@ __device__ __forceinline__ float rel_hat(float r, int c);
 __device__ __forceinline__ float ld_off(const float* __restrict__ base, unsigned byte_off) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+typedef float F3 __attribute__((ext_vector_type(3)));
+// one 12-byte access per lane for an interleaved field (global_load / store_dwordx3; 4-byte alignment suffices)
+__device__ __forceinline__ F3 ld3_off(const float* __restrict__ base, unsigned byte_off) {
+    F3 v;
+    __builtin_memcpy(&v, reinterpret_cast<const char*>(base) + byte_off, 12);
+    return v;
+}
+__device__ __forceinline__ void st3_off(float* __restrict__ base, unsigned byte_off, float a, float b, float c) {
+    const F3 v = {a, b, c};
+    __builtin_memcpy(reinterpret_cast<char*>(base) + byte_off, &v, 12);
+}
 __device__ __forceinline__ void st_off(float* __restrict__ base, unsigned byte_off, float v) {
     *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
@@ -336,11 +358,10 @@ struct March {
 // any-radius LDS-scatter kernel for this step (it predicts the displacement bound from earlier transitions, see api.hip) and
 // the bound then turned out larger than 2 voxels -- a transient that costs time, never parity.
 template <bool PRESCALE>
-__device__ __forceinline__ void exp_bwd_generic_column(const float* __restrict__ Gc, const float* __restrict__ gsc,
-                                                       const float* __restrict__ c0, float* __restrict__ oc, const Vol vol,
-                                                       const Lin lin, const Scale3L sc, const int x, const int y, const int z0,
-                                                       const int z1, const int hs) {
-    const int64_t V = vol.V;
+__device__ __forceinline__ void exp_bwd_generic_column(const float* __restrict__ Gc, const Lay3 LG, const float* __restrict__ gsc,
+                                                       const float* __restrict__ c0, const Lay3 LD, float* __restrict__ oc,
+                                                       const Lay3 LO, const Vol vol, const Lin lin, const Scale3L sc, const int x,
+                                                       const int y, const int z0, const int z1, const int hs) {
     const float nxm = (float)(vol.W - 1), nym = (float)(vol.H - 1), nzm = (float)(vol.D - 1);
     for (int zo = z0; zo < z1; ++zo) {
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
@@ -348,42 +369,43 @@ __device__ __forceinline__ void exp_bwd_generic_column(const float* __restrict__
             for (int sy = max(y - hs, 0); sy <= min(y + hs, vol.H - 1); ++sy)
                 for (int sx = max(x - hs, 0); sx <= min(x + hs, vol.W - 1); ++sx) {
                     const int64_t idx = ((int64_t)sz * vol.H + sy) * vol.W + sx;
-                    const float d0 = ldp<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow), d1 = ldp<PRESCALE>(c0 + V, idx, sc.nm1[1], sc.inv_pow),
-                                d2 = ldp<PRESCALE>(c0 + 2 * V, idx, sc.nm1[2], sc.inv_pow);
+                    const float d0 = ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.inv_pow),
+                                d1 = ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.inv_pow),
+                                d2 = ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.inv_pow);
                     const float px = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.x[sx], d0), 1.0f), 0.5f), nxm), 0.0f, nxm);
                     const float py = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.y[sy], d1), 1.0f), 0.5f), nym), 0.0f, nym);
                     const float pz = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.z[sz], d2), 1.0f), 0.5f), nzm), 0.0f, nzm);
                     const float w = hat01(px - (float)x) * hat01(py - (float)y) * hat01(pz - (float)zo);
                     if (w > 0.0f) {
                         const float gm = gsc ? gsc[idx] : 1.0f;
-                        a0 = fmaf(w, Gc[idx] * gm, a0);
-                        a1 = fmaf(w, Gc[idx + V] * gm, a1);
-                        a2 = fmaf(w, Gc[idx + 2 * V] * gm, a2);
+                        a0 = fmaf(w, Gc[idx * LG.em] * gm, a0);
+                        a1 = fmaf(w, Gc[LG.cs + idx * LG.em] * gm, a1);
+                        a2 = fmaf(w, Gc[2 * LG.cs + idx * LG.em] * gm, a2);
                     }
                 }
         // grid gradient of the sample taken at this voxel
         const int64_t own = ((int64_t)zo * vol.H + y) * vol.W + x;
         const float gmo = gsc ? gsc[own] : 1.0f;
-        const float G0 = Gc[own] * gmo, G1 = Gc[own + V] * gmo, G2 = Gc[own + 2 * V] * gmo;
-        const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], ldp<PRESCALE>(c0, own, sc.nm1[0], sc.inv_pow)), vol.W);
-        const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], ldp<PRESCALE>(c0 + V, own, sc.nm1[1], sc.inv_pow)), vol.H);
-        const AxisTap tz = axis_tap(__fadd_rn(lin.z[zo], ldp<PRESCALE>(c0 + 2 * V, own, sc.nm1[2], sc.inv_pow)), vol.D);
+        const float G0 = Gc[own * LG.em] * gmo, G1 = Gc[LG.cs + own * LG.em] * gmo, G2 = Gc[2 * LG.cs + own * LG.em] * gmo;
+        const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], ldp<PRESCALE>(c0, own * LD.em, sc.nm1[0], sc.inv_pow)), vol.W);
+        const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], ldp<PRESCALE>(c0 + LD.cs, own * LD.em, sc.nm1[1], sc.inv_pow)), vol.H);
+        const AxisTap tz = axis_tap(__fadd_rn(lin.z[zo], ldp<PRESCALE>(c0 + 2 * LD.cs, own * LD.em, sc.nm1[2], sc.inv_pow)), vol.D);
         float gix = 0.0f, giy = 0.0f, giz = 0.0f;
         for (int cz = 0; cz < 2; ++cz)
             for (int cy = 0; cy < 2; ++cy)
                 for (int cx = 0; cx < 2; ++cx) {
                     const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
-                    const float dot = fmaf(ldp<PRESCALE>(c0 + 2 * V, idx, sc.nm1[2], sc.inv_pow), G2,
-                                           fmaf(ldp<PRESCALE>(c0 + V, idx, sc.nm1[1], sc.inv_pow), G1,
-                                                ldp<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow) * G0));
+                    const float dot = fmaf(ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.inv_pow), G2,
+                                           fmaf(ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.inv_pow), G1,
+                                                ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.inv_pow) * G0));
                     const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
                     gix += (cx ? dot : -dot) * (wy * wz);
                     giy += (cy ? dot : -dot) * (wx * wz);
                     giz += (cz ? dot : -dot) * (wx * wy);
                 }
-        oc[own] = (G0 + tx.gmul * gix) + a0;
-        oc[own + V] = (G1 + ty.gmul * giy) + a1;
-        oc[own + 2 * V] = (G2 + tz.gmul * giz) + a2;
+        oc[own * LO.em] = (G0 + tx.gmul * gix) + a0;
+        oc[LO.cs + own * LO.em] = (G1 + ty.gmul * giy) + a1;
+        oc[2 * LO.cs + own * LO.em] = (G2 + tz.gmul * giz) + a2;
     }
 }
 
@@ -392,7 +414,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                                                    float* __restrict__ gout, const Vol vol, const Lin lin, const Scale3L sc,
                                                    const unsigned* __restrict__ dmax, const int seg_len, const int nseg,
                                                    const int r_lo, const int own_rest, const int swz_run, const int tile_id,
-                                                   const dim3 tiles, const float* __restrict__ gscale) {
+                                                   const dim3 tiles, const float* __restrict__ gscale, const int lay) {
     using M = March<PRESCALE, R>;
     constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
     // ring slot layout (9 floats per source, 8-byte fields so that the gather needs three ds_read_b64 per candidate):
@@ -412,19 +434,20 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
+    const Lay3 LD = lay3(lay & 1, V), LG = lay3(lay & 2, V), LO = lay3(lay & 4, V);
     if (R == 2 && hs > R) {  // the any-radius kernel was not launched for this step and the bound outgrew the ring
         const int gx = ox + (int)(threadIdx.x % MTX), gy = oy + (int)(threadIdx.x / MTX);
         if (gx < vol.W && gy < vol.H)
-            exp_bwd_generic_column<PRESCALE>(G + cb, gscale ? gscale + (int64_t)chain * V : nullptr, dk + cb, gout + cb, vol, lin, sc, gx,
-                                             gy, z0, z1, hs);
+            exp_bwd_generic_column<PRESCALE>(G + cb, LG, gscale ? gscale + (int64_t)chain * V : nullptr, dk + cb, LD, gout + cb, LO, vol,
+                                             lin, sc, gx, gy, z0, z1, hs);
         return;
     }
     const float* __restrict__ dx_ = dk + cb;
-    const float* __restrict__ dy_ = dx_ + V;
-    const float* __restrict__ dz_ = dy_ + V;
+    const float* __restrict__ dy_ = dx_ + LD.cs;
+    const float* __restrict__ dz_ = dy_ + LD.cs;
     const float* __restrict__ Gx_ = G + cb;
-    const float* __restrict__ Gy_ = Gx_ + V;
-    const float* __restrict__ Gz_ = Gy_ + V;
+    const float* __restrict__ Gy_ = Gx_ + LG.cs;
+    const float* __restrict__ Gz_ = Gy_ + LG.cs;
     const float* __restrict__ gs_ = gscale ? gscale + (int64_t)chain * V : nullptr;  // fused backward warp: G *= gs
     float* __restrict__ o = gout + cb;
 
@@ -454,22 +477,36 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     auto prefetch = [&](int s) {
         if (s < 0 || s >= vol.D) return;
         const int64_t zo = (int64_t)s * vol.H * vol.W;
-        const float* __restrict__ p0_ = dx_ + zo;  // uniform plane bases + 32-bit lane offsets
-        const float* __restrict__ p1_ = dy_ + zo;
-        const float* __restrict__ p2_ = dz_ + zo;
-        const float* __restrict__ p3_ = Gx_ + zo;
-        const float* __restrict__ p4_ = Gy_ + zo;
-        const float* __restrict__ p5_ = Gz_ + zo;
+        const float* __restrict__ p0_ = dx_ + zo * LD.em;  // uniform plane bases + 32-bit lane offsets
+        const float* __restrict__ p1_ = dy_ + zo * LD.em;
+        const float* __restrict__ p2_ = dz_ + zo * LD.em;
+        const float* __restrict__ p3_ = Gx_ + zo * LG.em;
+        const float* __restrict__ p4_ = Gy_ + zo * LG.em;
+        const float* __restrict__ p5_ = Gz_ + zo * LG.em;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
-            const unsigned g = (unsigned)sxy[it] * 4u;
-            pre[it][0] = ld_off(p0_, g);
-            pre[it][1] = ld_off(p1_, g);
-            pre[it][2] = ld_off(p2_, g);
-            pre[it][3] = ld_off(p3_, g);
-            pre[it][4] = ld_off(p4_, g);
-            pre[it][5] = ld_off(p5_, g);
+            const unsigned g = (unsigned)sxy[it] * 4u, gd = g * (unsigned)LD.em, gg = g * (unsigned)LG.em;
+            if (LD.em == 3) {
+                const F3 v = ld3_off(p0_, gd);
+                pre[it][0] = v.x;
+                pre[it][1] = v.y;
+                pre[it][2] = v.z;
+            } else {
+                pre[it][0] = ld_off(p0_, gd);
+                pre[it][1] = ld_off(p1_, gd);
+                pre[it][2] = ld_off(p2_, gd);
+            }
+            if (LG.em == 3) {
+                const F3 v = ld3_off(p3_, gg);
+                pre[it][3] = v.x;
+                pre[it][4] = v.y;
+                pre[it][5] = v.z;
+            } else {
+                pre[it][3] = ld_off(p3_, gg);
+                pre[it][4] = ld_off(p4_, gg);
+                pre[it][5] = ld_off(p5_, gg);
+            }
             if (gs_) pgs[it] = ld_off(gs_ + zo, g);
         }
     };
@@ -601,7 +638,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                             for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
                                 for (int cx = 0; cx < 2; ++cx) {
-                                    const int64_t idx = ((int64_t)min(iz0 + cz, vol.D - 1) * vol.H + min(iy0 + cy, vol.H - 1)) * vol.W + min(ix0 + cx, vol.W - 1);
+                                    const int64_t idx = (((int64_t)min(iz0 + cz, vol.D - 1) * vol.H + min(iy0 + cy, vol.H - 1)) * vol.W + min(ix0 + cx, vol.W - 1)) * LD.em;
                                     dot[cz][cy][cx] = fmaf(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.inv_pow), G2,
                                                            fmaf(ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.inv_pow), G1,
                                                                 ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.inv_pow) * G0));
@@ -620,11 +657,16 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                             giy = fmaf(wxz[u][w], dot[u][1][w] - dot[u][0][w], giy);
                             giz = fmaf(wxy[u][w], dot[1][u][w] - dot[0][u][w], giz);
                         }
-                    const int64_t pl = (int64_t)zo * vol.H * vol.W;
-                    const unsigned g = (unsigned)(y * vol.W + x) * 4u;
-                    st_off(o + pl, g, (G0 + gmx * gix) + acc01[a].x);
-                    st_off(o + V + pl, g, (G1 + gmy * giy) + acc01[a].y);
-                    st_off(o + 2 * V + pl, g, (G2 + gmz * giz) + acc2[a]);
+                    const int64_t pl = (int64_t)zo * vol.H * vol.W * LO.em;
+                    const unsigned g = (unsigned)(y * vol.W + x) * 4u * (unsigned)LO.em;
+                    const float o0 = (G0 + gmx * gix) + acc01[a].x, o1 = (G1 + gmy * giy) + acc01[a].y, o2 = (G2 + gmz * giz) + acc2[a];
+                    if (LO.em == 3) {
+                        st3_off(o + pl, g, o0, o1, o2);
+                    } else {
+                        st_off(o + pl, g, o0);
+                        st_off(o + LO.cs + pl, g, o1);
+                        st_off(o + 2 * LO.cs + pl, g, o2);
+                    }
                 }
                 acc01[a] = make_float2(0.0f, 0.0f);
                 acc2[a] = 0.0f;
@@ -641,16 +683,16 @@ template <bool PRESCALE, int R>
 __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp_bwd_march_kernel(
     const float* __restrict__ G, const float* __restrict__ dk, float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
     const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int own_rest, int swz_run, dim3 tiles,
-    const float* __restrict__ gscale) {
+    const float* __restrict__ gscale, int lay) {
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     for (int id = blockIdx.x; id < total; id += gridDim.x)
-        exp_bwd_march_tile<PRESCALE, R>(G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, r_lo, own_rest, swz_run, id, tiles, gscale);
+        exp_bwd_march_tile<PRESCALE, R>(G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, r_lo, own_rest, swz_run, id, tiles, gscale, lay);
 }
 
 constexpr int kRareGrid = 512;  // persistent grid of the rarely selected variants (two workgroups per CU)
 
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
-                               Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale,
+                               Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
                                hipEvent_t after_primary, hipStream_t st) {
     static const int seg_env = getenv("IRS_MARCH_SEG") ? atoi(getenv("IRS_MARCH_SEG")) : 0;
     const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * C, 8, seg_env);
@@ -660,7 +702,7 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
     const Scale3L sc = make_scale_l(vol, no_steps);
     static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;  // 0/1: no remap; default: one x-row of tiles per XCD run
-#define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale)
+#define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale, lay)
     const int rare = total < kRareGrid ? total : kRareGrid;
     // the radius-1 kernel first (the one the roofline is quoted on: `after_primary` brackets exactly its launch), then the
     // rarely selected radius-2 variant on the small persistent grid
@@ -697,7 +739,7 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                                                    const Lin lin, const Scale3L sc, const unsigned* __restrict__ dmax_in,
                                                    unsigned* __restrict__ dmax_out, const int seg_len, const int nseg,
                                                    const int h_lo, const int h_hi, const int swz_run, const int tile_id,
-                                                   const dim3 tiles) {
+                                                   const dim3 tiles, const int lay) {
     using M = MarchF<R>;
     constexpr int PX = M::PX, PN = M::PN, NIT = M::NIT;
     // ring of 2R+2 slots: one more than a sample can reach, so that the commit of the next source plane never overwrites
@@ -718,9 +760,10 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
     const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
+    const Lay3 LD = lay3(lay & 1, V), LO = lay3(lay & 4, V);
     const float* __restrict__ dx_ = din + cb;
-    const float* __restrict__ dy_ = dx_ + V;
-    const float* __restrict__ dz_ = dy_ + V;
+    const float* __restrict__ dy_ = dx_ + LD.cs;
+    const float* __restrict__ dz_ = dy_ + LD.cs;
     float* __restrict__ o = dout + cb;
     const int lx = threadIdx.x % FTX, ly0 = threadIdx.x / FTX;  // outputs (lx, ly0 + j * FTY / FROWS), j < FROWS
     const int x = ox + lx;
@@ -737,17 +780,24 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
     float pre[NIT][3];
     auto prefetch = [&](int s) {
         const int sc_ = min(max(s, 0), vol.D - 1);  // planes outside the volume replicate the border plane
-        const int64_t zo = (int64_t)sc_ * vol.H * vol.W;
+        const int64_t zo = (int64_t)sc_ * vol.H * vol.W * LD.em;
         const float* __restrict__ px_ = dx_ + zo;  // uniform plane bases + 32-bit lane offsets
         const float* __restrict__ py_ = dy_ + zo;
         const float* __restrict__ pz_ = dz_ + zo;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
-            const unsigned g = (unsigned)sxy[it] * 4u;
-            pre[it][0] = ld_off(px_, g);
-            pre[it][1] = ld_off(py_, g);
-            pre[it][2] = ld_off(pz_, g);
+            const unsigned g = (unsigned)sxy[it] * 4u * (unsigned)LD.em;
+            if (LD.em == 3) {
+                const F3 v = ld3_off(px_, g);
+                pre[it][0] = v.x;
+                pre[it][1] = v.y;
+                pre[it][2] = v.z;
+            } else {
+                pre[it][0] = ld_off(px_, g);
+                pre[it][1] = ld_off(py_, g);
+                pre[it][2] = ld_off(pz_, g);
+            }
         }
     };
     auto commit = [&](int slot) {
@@ -826,18 +876,22 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
 #pragma unroll
                             for (int cx = 0; cx < 2; ++cx) {
                                 const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
-                                const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
+                                const int64_t idx = (((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0)) * LD.em;
                                 a0 = __fadd_rn(a0, __fmul_rn(ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.inv_pow), w));
                                 a1 = __fadd_rn(a1, __fmul_rn(ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.inv_pow), w));
                                 a2 = __fadd_rn(a2, __fmul_rn(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.inv_pow), w));
                             }
                 }
-                const int64_t pl = (int64_t)zo * vol.H * vol.W;
-                const unsigned g = (unsigned)(y * vol.W + x) * 4u;
+                const int64_t pl = (int64_t)zo * vol.H * vol.W * LO.em;
+                const unsigned g = (unsigned)(y * vol.W + x) * 4u * (unsigned)LO.em;
                 const float r0 = __fadd_rn(d0, a0), r1 = __fadd_rn(d1, a1), r2 = __fadd_rn(d2, a2);
-                st_off(o + pl, g, r0);
-                st_off(o + V + pl, g, r1);
-                st_off(o + 2 * V + pl, g, r2);
+                if (LO.em == 3) {
+                    st3_off(o + pl, g, r0, r1, r2);
+                } else {
+                    st_off(o + pl, g, r0);
+                    st_off(o + LO.cs + pl, g, r1);
+                    st_off(o + 2 * LO.cs + pl, g, r2);
+                }
                 m0 = fmaxf(m0, fabsf(r0));
                 m1 = fmaxf(m1, fabsf(r1));
                 m2 = fmaxf(m2, fabsf(r2));
@@ -877,16 +931,16 @@ __global__ __launch_bounds__(kFwdBlock) void exp_fwd_march_kernel(const float* _
                                                                   Vol vol, Lin lin, Scale3L sc,
                                                                   const unsigned* __restrict__ dmax_in,
                                                                   unsigned* __restrict__ dmax_out, int seg_len, int nseg,
-                                                                  int h_lo, int h_hi, int swz_run, dim3 tiles) {
+                                                                  int h_lo, int h_hi, int swz_run, dim3 tiles, int lay) {
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     for (int id = blockIdx.x; id < total; id += gridDim.x) {
-        exp_fwd_march_tile<PRESCALE, R>(din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, h_lo, h_hi, swz_run, id, tiles);
+        exp_fwd_march_tile<PRESCALE, R>(din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, h_lo, h_hi, swz_run, id, tiles, lay);
         __syncthreads();  // the ring and the reduction scratch are reused by the next tile
     }
 }
 
 void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
-                               const unsigned* dmax_in, unsigned* dmax_out, bool only_r1, hipStream_t st) {
+                               const unsigned* dmax_in, unsigned* dmax_out, bool only_r1, int lay, hipStream_t st) {
     static const int seg_env = getenv("IRS_MARCH_SEG_FWD") ? atoi(getenv("IRS_MARCH_SEG_FWD")) : 0;
     const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + FTX - 1) / FTX) * ((vol.H + FTY - 1) / FTY) * C, 8, seg_env);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
@@ -895,7 +949,7 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     const Scale3L sc = make_scale_l(vol, no_steps);
     static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;
-#define IRS_FWM(P, RR, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), dim3(GRID), dim3(kFwdBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles)
+#define IRS_FWM(P, RR, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), dim3(GRID), dim3(kFwdBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
     const int rare = total < kRareGrid ? total : kRareGrid;
     if (!dmax_in || only_r1) {  // no bound / predicted small: the radius-1 ring is correct for any displacement (far taps go to global memory)
         if (prescale_in) IRS_FWM(true, 1, -1, 1 << 30, total); else IRS_FWM(false, 1, -1, 1 << 30, total);

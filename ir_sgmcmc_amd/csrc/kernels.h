@@ -53,14 +53,14 @@ void launch_scale_channels(const float* in, float* out, float s0, float s1, floa
 // ---- exp_kernels.hip (z-marching squaring step + owner-computes gather adjoint, LDS-scatter fallback)
 // dmax_in: published bound of the input field (nullptr = unknown), dmax_out: receives the bound of the output field
 void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale, int no_steps, int C, Vol vol, Lin lin,
-                               const unsigned* dmax_in, unsigned* dmax_out, bool only_r1, hipStream_t st);
+                               const unsigned* dmax_in, unsigned* dmax_out, bool only_r1, int lay, hipStream_t st);
 // the adjoint is launched as a set: gather radius 1, gather radius 2 and the scatter fallback; exactly one of them does
 // the work, chosen on the device from the bound max|d_k|
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
-                               Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale,
+                               Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
                                hipEvent_t after_primary, hipStream_t st);
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
-                             Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, hipStream_t st);
+                             Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, int lay, hipStream_t st);
 void launch_field_absmax(const float* d, bool prescale, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st);
 
 // ---- data_kernels.hip

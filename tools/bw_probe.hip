@@ -207,6 +207,62 @@ __global__ __launch_bounds__(TX * TY) void march_shape(const float* __restrict__
     }
 }
 
+
+// array-of-structures variant of the marching skeleton: one 16-byte (float4: x, y, z, pad) or 12-byte (3 floats) record per
+// voxel instead of three planar dwords.  Rates are quoted on the 12 useful bytes per voxel and direction.
+template <int TX, int TY, int NF>
+__global__ __launch_bounds__(TX * TY) void march_aos(const float* __restrict__ a, float* __restrict__ b, int N) {
+    constexpr int halo = 1, PX = TX + 2, PY = TY + 2, PN = PX * PY, NT = TX * TY, NIT = (PN + NT - 1) / NT;
+    __shared__ float lds[NF * PN];
+    const int ox = blockIdx.x * TX, oy = blockIdx.y * TY, z0 = blockIdx.z * 32;
+    const int64_t HW = (int64_t)N * N;
+    const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
+    unsigned off[NIT];
+    bool val[NIT];
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * NT;
+        const int px = i % PX, py = i / PX;
+        const int cx = min(max(ox - halo + px, 0), N - 1), cy = min(max(oy - halo + py, 0), N - 1);
+        val[it] = i < PN;
+        off[it] = (unsigned)(cy * N + cx);
+    }
+    float pre[NIT][NF];
+    auto load = [&](int z) {
+        const float* p = a + (int64_t)min(z, N - 1) * HW * NF;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (val[it]) {
+                if (NF == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)off[it] * 4);
+                    pre[it][0] = v.x; pre[it][1] = v.y; pre[it][2] = v.z; pre[it][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NF; ++c) pre[it][c] = p[(size_t)off[it] * NF + c];
+                }
+            }
+    };
+    load(z0);
+    for (int z = z0; z < z0 + 32; ++z) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (val[it]) {
+                const int i = threadIdx.x + it * NT;
+#pragma unroll
+                for (int c = 0; c < NF; ++c) lds[c * PN + i] = pre[it][c];
+            }
+        load(z + 1);
+        __syncthreads();
+        const int ci = (ly + halo) * PX + lx + halo;
+        float* q = b + ((int64_t)z * HW + (oy + ly) * N + ox + lx) * NF;
+        if (NF == 4) *reinterpret_cast<float4*>(q) = make_float4(lds[ci], lds[PN + ci], lds[2 * PN + ci], lds[3 * PN + ci]);
+        else {
+#pragma unroll
+            for (int c = 0; c < NF; ++c) q[c] = lds[c * PN + ci];
+        }
+        __syncthreads();
+    }
+}
+
 int main() {
     const int N = 256;
     const int64_t V = (int64_t)N * N * N;
@@ -251,6 +307,15 @@ int main() {
     time("march_shape<256,4,seg 64,swz 1>", [&] { hipLaunchKernelGGL((march_shape<256, 4, 64, true>), dim3(N / 256, N / 4, N / 64), dim3(1024), 0, 0, a, b, N); }, bytes);
     time("march_shape<256,2,seg 32,swz 1>", [&] { hipLaunchKernelGGL((march_shape<256, 2, 32, true>), dim3(N / 256, N / 2, N / 32), dim3(512), 0, 0, a, b, N); }, bytes);
     time("march_shape<64,16,seg 64,swz 1>", [&] { hipLaunchKernelGGL((march_shape<64, 16, 64, true>), dim3(N / 64, N / 16, N / 64), dim3(1024), 0, 0, a, b, N); }, bytes);
+    float *a4, *b4;
+    hipMalloc(&a4, 4 * V * 4);
+    hipMalloc(&b4, 4 * V * 4);
+    hipMemset(a4, 0, 4 * V * 4);
+    time("march_aos<32,8,float4>", [&] { hipLaunchKernelGGL((march_aos<32, 8, 4>), dim3(N / 32, N / 8, N / 32), dim3(256), 0, 0, a4, b4, N); }, bytes);
+    time("march_aos<32,8,float3>", [&] { hipLaunchKernelGGL((march_aos<32, 8, 3>), dim3(N / 32, N / 8, N / 32), dim3(256), 0, 0, a4, b4, N); }, bytes);
+    time("march_aos<64,8,float4>", [&] { hipLaunchKernelGGL((march_aos<64, 8, 4>), dim3(N / 64, N / 8, N / 32), dim3(512), 0, 0, a4, b4, N); }, bytes);
+    time("march_aos<64,4,float3>", [&] { hipLaunchKernelGGL((march_aos<64, 4, 3>), dim3(N / 64, N / 4, N / 32), dim3(256), 0, 0, a4, b4, N); }, bytes);
+    time("march_aos<64,8,float3>", [&] { hipLaunchKernelGGL((march_aos<64, 8, 3>), dim3(N / 64, N / 8, N / 32), dim3(512), 0, 0, a4, b4, N); }, bytes);
     time("hipMemcpyDtoD", [&] { hipMemcpyAsync(b, a, 3 * V * 4, hipMemcpyDeviceToDevice, 0); }, bytes);
     return 0;
 }
