@@ -317,7 +317,7 @@ int irs_warp_fwd(const float* im, int Cim, const float* d_last, const float* uni
     const Vol vol = make_vol(D, H, W);
     Lin lin;
     if (cached_lin(D, H, W, st, &lin)) return fail("irs_warp_fwd: identity grid allocation failed");
-    launch_warp_fwd(im, Cim == 1 ? 0 : vol.V, d_last, unif, alpha, warped, nullptr, C, vol, lin, seed, iteration, nullptr, st);
+    launch_warp_fwd(im, Cim == 1 ? 0 : vol.V, d_last, unif, alpha, warped, nullptr, 0, C, vol, lin, seed, iteration, nullptr, st);
     LAUNCH_CHECK();
     return 0;
 }
@@ -693,7 +693,7 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     const float* d_last = c->steps + (int64_t)(cfg.no_steps - 1) * field;
     // 4. warp (+ jitter) and residual
     const float alpha = with_jitter ? cfg.uniform_alpha : 0.0f;
-    launch_warp_fwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif, alpha, warped, gradm, C, c->vol, lin,
+    launch_warp_fwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif, alpha, warped, gradm, aos_enabled() ? 1 : 0, C, c->vol, lin,
                     cfg.seed, 0, it, st);
     if (cfg.data_loss == IRS_DATA_GMM_LCC)
         launch_lcc_fwd_march(c->fhat, c->fhat_chains == 1 ? 0 : c->vol.V, warped, z, c->sigM, cfg.lcc_s, C, c->vol, st);
@@ -790,7 +790,8 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
                 // 2 voxels; otherwise the (rarely selected) radius-2 kernel owns everything above one voxel -- through its
                 // generic in-kernel fallback if the bound exceeds its ring after all
                 const bool skip_any = rad >= 2 && predicted_below(c, k, 1.5f);
-                const int lay = bwd_lay(c, k);
+                // with the fused backward warp the first step's incoming gradient is the interleaved d(warped)/d(d_n)
+                const int lay = bwd_lay(c, k) | (gscale && aos_enabled() ? 2 : 0);
                 if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, skip_any, gscale, lay,
                                                    timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
                 if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, gscale, lay, st);
@@ -907,7 +908,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
             break;
         case IRS_ST_WARP:
             launch_warp_fwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif,
-                            cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f, warped, nullptr, C, w, lin, cfg.seed, 0, it, st);
+                            cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f, warped, nullptr, 0, C, w, lin, cfg.seed, 0, it, st);
             break;
         case IRS_ST_RESIDUAL:
             if (cfg.data_loss == IRS_DATA_GMM_LCC)

@@ -285,7 +285,7 @@ __device__ __forceinline__ void grid_point(const float* __restrict__ d, const fl
 __global__ __launch_bounds__(kBlock) void warp_fwd_kernel(const float* __restrict__ im, int64_t im_stride,
                                                           const float* __restrict__ d, const float* __restrict__ unif,
                                                           Jitter jt, float* __restrict__ out, float* __restrict__ gradm,
-                                                          Vol vol, Lin lin) {
+                                                          int gradm_aos, Vol vol, Lin lin) {
     IRS_VOXEL(vol, chain, x, y, z, vox);
     float g[3];
     grid_point(d, unif, jt, (int64_t)chain * 3 * vol.V, chain, vox, vol, lin, x, y, z, g);
@@ -313,9 +313,15 @@ __global__ __launch_bounds__(kBlock) void warp_fwd_kernel(const float* __restric
     out[(int64_t)chain * vol.V + vox] = acc;
     if (gradm) {
         const int64_t cb3 = (int64_t)chain * 3 * vol.V;
-        gradm[cb3 + vox] = tx.gmul * gix;
-        gradm[cb3 + vol.V + vox] = ty.gmul * giy;
-        gradm[cb3 + 2 * vol.V + vox] = tz.gmul * giz;
+        if (gradm_aos) {  // interleaved ([V][3]): the layout the fused adjoint steps read (exp_kernels.hip: Lay3)
+            typedef float f3v __attribute__((ext_vector_type(3)));
+            const f3v v = {tx.gmul * gix, ty.gmul * giy, tz.gmul * giz};
+            __builtin_memcpy(gradm + cb3 + (int64_t)vox * 3, &v, 12);
+        } else {
+            gradm[cb3 + vox] = tx.gmul * gix;
+            gradm[cb3 + vol.V + vox] = ty.gmul * giy;
+            gradm[cb3 + 2 * vol.V + vox] = tz.gmul * giz;
+        }
     }
 }
 
@@ -332,11 +338,11 @@ static Jitter make_jitter(float alpha, Vol vol, uint64_t seed, uint64_t iteratio
 }
 
 void launch_warp_fwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha, float* out,
-                     float* gradm, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
+                     float* gradm, int gradm_aos, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
                      const uint64_t* dev_iteration, hipStream_t st) {
     const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL(warp_fwd_kernel, grid, dim3(kBlock), 0, st, im, im_stride, d, unif,
-                       make_jitter(alpha, vol, seed, iteration, dev_iteration), out, gradm, vol, lin);
+                       make_jitter(alpha, vol, seed, iteration, dev_iteration), out, gradm, gradm_aos, vol, lin);
 }
 
 __global__ __launch_bounds__(kBlock) void warp_bwd_kernel(const float* __restrict__ im, int64_t im_stride,

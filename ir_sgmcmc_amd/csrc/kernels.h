@@ -35,7 +35,7 @@ void launch_exp_step_bwd(const float* G, const float* dk, float* gout, bool pres
 void launch_svf_outputs(const float* d, float* transformation, float* displacement, int C, Vol vol, Lin lin,
                         hipStream_t st);
 void launch_warp_fwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha, float* out,
-                     float* gradm, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
+                     float* gradm, int gradm_aos, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
                      const uint64_t* dev_iteration, hipStream_t st);
 void launch_warp_bwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha,
                      const float* g_warped, float* g_d, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
