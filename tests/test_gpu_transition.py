@@ -108,7 +108,7 @@ def test_transition_matches_reference_fixture(name):
             v.copy_(ref('v_new').to(DEV))
 
 
-@pytest.mark.parametrize('variant', ['ssd_l2', 'ssd_vd_lognormal', 'gmm_nosobolev_c3'])
+@pytest.mark.parametrize('variant', ['ssd_l2', 'ssd_vd_lognormal', 'gmm_nosobolev_c3', 'steps1', 'steps2', 'steps5_c2'])
 def test_transition_matches_oracle_builder_variants(variant):
     """Configurations without a reference counterpart (SSD is builder-defined) or not covered by a fixture."""
     from ir_sgmcmc_amd.data_loader import synthetic_pair
@@ -116,7 +116,9 @@ def test_transition_matches_oracle_builder_variants(variant):
     kw = dict(ssd_l2=dict(data_loss='SSD', virtual_decimation=False, ssd_sigma=0.05),
               ssd_vd_lognormal=dict(data_loss='SSD', virtual_decimation=True, reg_loss='RegLoss_LogNormal',
                                     reg_learnable=True, no_chains=2),
-              gmm_nosobolev_c3=dict(no_chains=3, sobolev_s=None, uniform_noise=None, lcc_s=2, lr=0.02))[variant]
+              gmm_nosobolev_c3=dict(no_chains=3, sobolev_s=None, uniform_noise=None, lcc_s=2, lr=0.02),
+              # few squaring steps: the first / last / only step of the chain has its own field layouts in the fused path
+              steps1=dict(no_steps=1, lr=0.05), steps2=dict(no_steps=2, lr=0.05), steps5_c2=dict(no_steps=5, no_chains=2, lr=0.05))[variant]
     oc = OracleConfig(dims=(N, N, N), **kw)
     C = oc.no_chains
     f1, m1 = synthetic_pair((N, N, N), seed=3)
