@@ -198,7 +198,11 @@ void launch_sobolev_march(const float* in, float* out, const Taps& taps, int pla
 //      -> var, sigma, output at plane pv = pin - 2S.
 // Two barriers per plane.  Tile 32 x 16, two outputs per thread.
 // ------------------------------------------------------------------------------------------------
-constexpr int LMX = 32, LMY = 16;
+#ifndef IRS_LMX
+#define IRS_LMX 32
+#define IRS_LMY 16
+#endif
+constexpr int LMX = IRS_LMX, LMY = IRS_LMY;
 
 template <int S, bool MAP>
 __global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __restrict__ fhat, int64_t fhat_stride,
