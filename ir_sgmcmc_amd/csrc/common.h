@@ -34,9 +34,10 @@ __host__ __device__ inline Vol window(Vol v, int zlo, int zhi) {
 // Segment length of the z-marching kernels.  32 planes amortise the run-in of a segment (2R .. 4S extra planes) when the
 // launch still has enough workgroups to fill 256 CUs; smaller volumes trade run-in overhead for parallelism, down to
 // `min_len`.  `forced` (> 0) is the environment override of the kernel family.
-inline int pick_seg_len(int nz, int64_t tiles_per_layer, int min_len, int forced) {
+inline int pick_seg_len(int nz, int64_t tiles_per_layer, int min_len, int forced, int64_t want_blocks = 1024) {
     if (forced > 0) return forced;
-    static const int64_t want = getenv("IRS_SEG_MIN_BLOCKS") ? atoll(getenv("IRS_SEG_MIN_BLOCKS")) : 1024;
+    static const int64_t want_env = getenv("IRS_SEG_MIN_BLOCKS") ? atoll(getenv("IRS_SEG_MIN_BLOCKS")) : 0;
+    const int64_t want = want_env > 0 ? want_env : want_blocks;
     int len = 32;
     while (len > min_len && tiles_per_layer * ((nz + len - 1) / len) < want) len >>= 1;
     return len < 1 ? 1 : len;
