@@ -127,8 +127,16 @@ __device__ __forceinline__ AxisTap axis_tap(float g, int n) {
 }
 
 // transform_coordinates (utils/util.py:418-429): (v * 2) / (n - 1), then / 2^steps (utils/transformation.py:68)
+// The division is correctly rounded at 3 instructions: the reciprocal of the (wave-uniform, loop-invariant) divisor is an
+// IEEE division the compiler hoists out of the plane loops, then quotient estimate, exact remainder and one correction
+// (Markstein) -- the full division sequence per element cost 25 us per launch in the first squaring step and its adjoint.
+__device__ __forceinline__ float div_exact(float a, float b, float rb) {
+    const float q = __fmul_rn(a, rb);
+    return __fmaf_rn(__fmaf_rn(-q, b, a), rb, q);
+}
 __device__ __forceinline__ float prescale(float v, float nm1, float inv_pow) {
-    return __fmul_rn(__fdiv_rn(__fmul_rn(v, 2.0f), nm1), inv_pow);
+    const float rc = __fdiv_rn(1.0f, nm1);
+    return __fmul_rn(div_exact(__fmul_rn(v, 2.0f), nm1, rc), inv_pow);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -184,17 +192,48 @@ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
     return c;
 }
 
-__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }  // [0, 1)
+// Philox2x32-10: half the multiplies of the 4x32 generator for 64 output bits -- three 21-bit uniforms, what the jitter of
+// one voxel needs.  96 input bits: counter = (index lo, index hi[3:0] | iteration[27:0] << 4), key = key_mix(...).
+struct U2 {
+    uint32_t x, y;
+};
+__device__ __forceinline__ U2 philox2x32_10(U2 c, uint32_t k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p = (uint64_t)0xD256D193u * c.x;
+        c = U2{(uint32_t)(p >> 32) ^ k ^ c.y, (uint32_t)p};
+        k += 0x9E3779B9u;
+    }
+    return c;
+}
+// 32-bit key from the 64-bit seed, the stream id and the iteration bits that do not fit the counter (wave-uniform: SALU)
+__device__ __forceinline__ uint32_t key_mix(uint64_t seed, uint64_t iteration, uint32_t stream) {
+    uint64_t zz = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(stream + 1u) + (iteration >> 28) * 0xD1B54A32D192ED03ull;
+    zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
+    zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
+    zz ^= zz >> 31;
+    return (uint32_t)zz ^ (uint32_t)(zz >> 32);
+}
+__device__ __forceinline__ float u01_21(uint32_t r21) { return (float)r21 * (1.0f / 2097152.0f); }  // 21 bits -> [0, 1)
 
-// two standard normals from two 32-bit words (Box-Muller)
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
-    const float u = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
-    const float v = u01(b);
-    const float r = sqrtf(-2.0f * __logf(u));
-    float s, c;
-    __sincosf(6.28318530717958647692f * v, &s, &c);
-    n0 = r * c;
-    n1 = r * s;
+// six 21-bit words from the 128 bits of one Philox4x32 call
+__device__ __forceinline__ void split21(const U4 r, uint32_t (&w)[6]) {
+    w[0] = r.x >> 11;
+    w[1] = r.y >> 11;
+    w[2] = r.z >> 11;
+    w[3] = (r.x & 0x7FFu) | ((r.w & 0x3FFu) << 11);
+    w[4] = (r.y & 0x7FFu) | (((r.w >> 10) & 0x3FFu) << 11);
+    w[5] = (r.z & 0x7FFu) | (((r.w >> 20) & 0x3FFu) << 11);
+}
+
+// two standard normals from two 21-bit words: radius from u in (0, 1] (tail cut at 5.4 sigma, 7e-8 of the mass), angle in
+// revolutions straight into v_sin / v_cos; hardware log2 / sqrt (1 ulp)
+__device__ __forceinline__ void box_muller21(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u = ((float)a + 1.0f) * (1.0f / 2097152.0f);
+    const float v = u01_21(b);
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));  // -2 ln u = -2 ln2 log2 u
+    n0 = r * __builtin_amdgcn_cosf(v);
+    n1 = r * __builtin_amdgcn_sinf(v);
 }
 
 }  // namespace irs

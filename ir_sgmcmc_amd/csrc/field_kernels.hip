@@ -10,41 +10,53 @@ namespace irs {
 
 // ------------------------------------------------------------------------------------------------
 // SGLD.forward: out = v + (amp * sigma) * eps          (utils/util.py:56-58; amp = sqrt(2 tau))
-// one thread per voxel per chain handles the three channels (one Philox call yields the 3 normals)
+// One thread handles the three channels of the voxels (x, y, 2p) and (x, y, 2p + 1): ONE Philox4x32-10 call yields the six
+// normals of the pair (3 Box-Muller pairs from 6 x 21 bits) -- with a call per voxel the kernel was VALU-bound, not
+// HBM-bound.  Pairs are aligned to absolute even z, so a z-window (slab) draws the same noise as the full volume.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void perturb_kernel(const float* __restrict__ v, const float* __restrict__ sigma,
                                                          const float* __restrict__ eps, float amp,
                                                          float* __restrict__ out, Vol vol, uint64_t seed,
-                                                         uint64_t iteration, const uint64_t* __restrict__ dev_iter) {
-    IRS_VOXEL(vol, chain, x, y, z, vox);
-    const int64_t V = vol.V;
-    const int64_t base = (int64_t)chain * 3 * V + vox;
-    float n[3];
-    if (eps) {
-        n[0] = eps[base];
-        n[1] = eps[base + V];
-        n[2] = eps[base + 2 * V];
-    } else {
+                                                         uint64_t iteration, const uint64_t* dev_iter, int npair) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int chain = blockIdx.z / npair;
+    const int za = 2 * ((vol.z0 >> 1) + (int)blockIdx.z - chain * npair);
+    if (x >= vol.W || y >= vol.H) return;
+    const int64_t V = vol.V, HW = (int64_t)vol.H * vol.W;
+    const int64_t voxa = ((int64_t)za * vol.H + y) * vol.W + x;
+    float n[2][3];
+    if (!eps) {
         const uint64_t it = dev_iter ? *dev_iter : iteration;
-        const uint64_t idx = (uint64_t)chain * (uint64_t)V + (uint64_t)vox;
+        const uint64_t idx = (uint64_t)chain * (uint64_t)V + (uint64_t)voxa;
         const U4 r = philox4x32_10(U4{(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)it, 0x5347u ^ (uint32_t)(it >> 32)},
                                    (uint32_t)seed, (uint32_t)(seed >> 32));
-        float spare;
-        box_muller(r.x, r.y, n[0], n[1]);
-        box_muller(r.z, r.w, n[2], spare);
+        uint32_t w[6];
+        split21(r, w);
+        box_muller21(w[0], w[1], n[0][0], n[0][1]);
+        box_muller21(w[2], w[3], n[0][2], n[1][0]);
+        box_muller21(w[4], w[5], n[1][1], n[1][2]);
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int64_t i = base + c * V;
-        const float sg = sigma ? sigma[i] : 1.0f;
-        out[i] = __fadd_rn(v[i], __fmul_rn(__fmul_rn(amp, sg), n[c]));
+    for (int h = 0; h < 2; ++h) {
+        const int z = za + h;
+        if (z < vol.z0 || z >= vol.z0 + vol.nz) continue;
+        const int64_t base = (int64_t)chain * 3 * V + voxa + h * HW;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int64_t i = base + c * V;
+            const float nn = eps ? eps[i] : n[h][c];
+            const float sg = sigma ? sigma[i] : 1.0f;
+            out[i] = __fadd_rn(v[i], __fmul_rn(__fmul_rn(amp, sg), nn));
+        }
     }
 }
 
 void launch_perturb(const float* v, const float* sigma, const float* eps, float amp, float* out, int C, Vol vol,
                     uint64_t seed, uint64_t iteration, const uint64_t* dev_iteration, hipStream_t st) {
-    hipLaunchKernelGGL(perturb_kernel, vox_grid(vol, C), dim3(kBlock), 0, st, v, sigma, eps, amp, out, vol, seed, iteration,
-                       dev_iteration);
+    const int npair = ((vol.z0 + vol.nz - 1) >> 1) - (vol.z0 >> 1) + 1;
+    const dim3 grid((unsigned)((vol.W + 63) / 64), (unsigned)((vol.H + 3) / 4), (unsigned)(npair * C));
+    hipLaunchKernelGGL(perturb_kernel, grid, dim3(kBlock), 0, st, v, sigma, eps, amp, out, vol, seed, iteration, dev_iteration,
+                       npair);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -245,6 +257,7 @@ void launch_svf_outputs(const float* d, float* transformation, float* displaceme
 struct Jitter {
     float alpha;       // <= 0: disabled
     float nm1[3];      // transform_coordinates scaling of the jitter (x <-> W, y <-> H, z <-> D)
+    float rnm1[3];     // correctly rounded 1 / nm1 (host): the division below stays exact at 3 instructions
     uint64_t seed, iteration;
     const uint64_t* dev_iter;
 };
@@ -263,17 +276,17 @@ __device__ __forceinline__ void grid_point(const float* __restrict__ d, const fl
             u[2] = unif[cb3 + 2 * vol.V + vox];
         } else {
             const uint64_t it = jt.dev_iter ? *jt.dev_iter : jt.iteration;
-            const uint64_t idx = (uint64_t)chain * (uint64_t)vol.V + (uint64_t)vox;
-            const U4 r = philox4x32_10(U4{(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)it, 0x554Eu ^ (uint32_t)(it >> 32)},
-                                       (uint32_t)jt.seed, (uint32_t)(jt.seed >> 32));
-            u[0] = u01(r.x);
-            u[1] = u01(r.y);
-            u[2] = u01(r.z);
+            const uint64_t idx = (uint64_t)chain * (uint64_t)vol.V + (uint64_t)vox;  // < 2^36 (dims_ok, chains)
+            const U2 r = philox2x32_10(U2{(uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)it << 4)}, key_mix(jt.seed, it, 0x554Eu));
+            u[0] = u01_21(r.x >> 11);
+            u[1] = u01_21(r.y >> 11);
+            u[2] = u01_21((r.x & 0x7FFu) | ((r.y & 0x3FFu) << 11));
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float nz = __fadd_rn(__fmul_rn(-2.0f * jt.alpha, u[c]), jt.alpha);  // -2 a u + a
-            g[c] = __fadd_rn(g[c], __fdiv_rn(__fmul_rn(nz, 2.0f), jt.nm1[c]));
+            // (nz * 2) / (n - 1), correctly rounded at 3 instructions (common.h: div_exact)
+            g[c] = __fadd_rn(g[c], div_exact(__fmul_rn(nz, 2.0f), jt.nm1[c], jt.rnm1[c]));
         }
     }
 }
@@ -292,12 +305,16 @@ __global__ __launch_bounds__(kBlock) void warp_fwd_kernel(const float* __restric
     const AxisTap tx = axis_tap(g[0], vol.W), ty = axis_tap(g[1], vol.H), tz = axis_tap(g[2], vol.D);
     const float* src = im + (int64_t)chain * im_stride;
     float acc = 0.0f, gix = 0.0f, giy = 0.0f, giz = 0.0f;
+    // 32-bit element offsets from the (uniform) image base: a chain's volume has < 2^31 voxels (dims_ok).  Two integer
+    // multiplies (quarter rate) instead of one per corner row: i1 is i0 or i0 + 1
+    const unsigned hw = (unsigned)(vol.H * vol.W);
+    const unsigned offz[2] = {(unsigned)tz.i0 * hw, (unsigned)tz.i0 * hw + (tz.i1 != tz.i0 ? hw : 0u)};
+    const unsigned offy[2] = {(unsigned)ty.i0 * (unsigned)vol.W, (unsigned)ty.i0 * (unsigned)vol.W + (ty.i1 != ty.i0 ? (unsigned)vol.W : 0u)};
 #pragma unroll
     for (int cz = 0; cz < 2; ++cz)
 #pragma unroll
         for (int cy = 0; cy < 2; ++cy) {
-            // 32-bit element offsets from the (uniform) image base: a chain's volume has < 2^31 voxels (dims_ok)
-            const unsigned rowoff = (unsigned)(((cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W);
+            const unsigned rowoff = offz[cz] + offy[cy];
 #pragma unroll
             for (int cx = 0; cx < 2; ++cx) {
                 const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
@@ -331,6 +348,14 @@ static Jitter make_jitter(float alpha, Vol vol, uint64_t seed, uint64_t iteratio
     j.nm1[0] = (float)(vol.W - 1);
     j.nm1[1] = (float)(vol.H - 1);
     j.nm1[2] = (float)(vol.D - 1);
+    for (int c = 0; c < 3; ++c) {  // the float closest to 1 / nm1: minimise |r * nm1 - 1| (exact in double) over the neighbours
+        const double n = (double)j.nm1[c];
+        float best = (float)(1.0 / (n > 0.0 ? n : 1.0));
+        const float cand[2] = {nextafterf(best, 0.0f), nextafterf(best, 2.0f)};
+        for (float r : cand)
+            if (fabs((double)r * n - 1.0) < fabs((double)best * n - 1.0)) best = r;
+        j.rnm1[c] = best;
+    }
     j.seed = seed;
     j.iteration = iteration;
     j.dev_iter = dev_iter;

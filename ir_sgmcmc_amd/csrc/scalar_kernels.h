@@ -70,7 +70,7 @@ __device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict_
             sum += t[k];
         }
     }
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);  // sum in [1, K]; 1 ulp
     e.nll = -(m + __logf(sum));
     e.x = 0.0f;
     e.gz = 0.0f;

@@ -337,10 +337,12 @@ __global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __
                 float var = 0.0f;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) var += ring2[o][t];
-                const float sigma = sqrtf(var / n + 1e-10f);
+                // 1-ulp hardware sqrt / reciprocal: relative errors of 1e-7 on sigma and z (the mean above keeps its exact division:
+                // an error there is amplified by 1 / sigma in flat regions)
+                const float sigma = __builtin_amdgcn_sqrtf(fmaf(var, 1.0f / n, 1e-10f));
                 const int yy = ly + o * (LMY / 2);
                 const float wc = LW[slot_v * BN + (yy + S) * BX + lx + S];
-                const float r = wc / sigma;
+                const float r = wc * __builtin_amdgcn_rcpf(sigma);
                 const int64_t g = (int64_t)pv * HW + (unsigned)((oy + yy) * vol.W + gx);
                 out[(int64_t)chain * vol.V + g] = MAP ? fhat[(int64_t)chain * fhat_stride + g] - r : r;
                 if (sigma_out) sigma_out[(int64_t)chain * vol.V + g] = sigma;
@@ -529,9 +531,10 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
                 }
                 const float w = pf[it] - zz;
                 const float gw = -gzv;
-                gvar = -gw * w / (2.0f * sg * sg);
-                pw = gw / sg;
-                a2 = 2.0f * w * sg / n;
+                const float isg = __builtin_amdgcn_rcpf(sg);  // 1 ulp; three IEEE divisions cost ~30 VALU per element
+                pw = gw * isg;
+                gvar = -0.5f * pw * w * isg;
+                a2 = (2.0f / n) * w * sg;
             }
             LGV[threadIdx.x + it * kStBlock] = gvar;
             if (abidx[it] >= 0) {
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
             if (r >= z0 && r < z1) {
                 const float t2 = adjoint_ring_sum<S>(ring2[o], r, vol.D);
                 const float ga = LG[slot_r2 * BN + (yy + S) * BX + lx + S];
-                g_m[(int64_t)r * HW + (unsigned)((oy + yy) * vol.W + gxo)] = ga - t2 / n;
+                g_m[(int64_t)r * HW + (unsigned)((oy + yy) * vol.W + gxo)] = fmaf(-(1.0f / n), t2, ga);
             }
         }
     }

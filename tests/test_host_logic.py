@@ -127,3 +127,18 @@ def test_svffd_config_and_control_grid(tmp_path):
     assert dl.dims_v == (35, 35, 35) and tm.cps == (4, 4, 4)   # ceil(127/4)+3, SURVEY.md section 8(a) row a4
     losses = config.init_losses()
     assert type(losses['data']['loss']).__name__ == 'SSD' and 'scale_prior' not in losses['data']
+
+
+def test_exact_division_by_markstein_correction(tmp_path):
+    """The kernels divide by (n - 1) with a reciprocal + one FMA correction instead of the full IEEE sequence (common.h
+    div_exact); results must be bit-identical to the division the reference performs (utils/util.py:418-429)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    src = os.path.join(os.path.dirname(__file__), 'csrc', 'div_exact_check.c')
+    exe = str(tmp_path / 'div_exact_check')
+    subprocess.run(['gcc', '-O2', '-ffp-contract=off', '-o', exe, src, '-lm'], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert 'mismatches 0' in out.stdout
