@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels.  CDNA4 only: 64-wide wavefronts, no portability shims.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -127,16 +128,23 @@ __device__ __forceinline__ AxisTap axis_tap(float g, int n) {
 }
 
 // transform_coordinates (utils/util.py:418-429): (v * 2) / (n - 1), then / 2^steps (utils/transformation.py:68)
-// The division is correctly rounded at 3 instructions: the reciprocal of the (wave-uniform, loop-invariant) divisor is an
-// IEEE division the compiler hoists out of the plane loops, then quotient estimate, exact remainder and one correction
-// (Markstein) -- the full division sequence per element cost 25 us per launch in the first squaring step and its adjoint.
+// a / b correctly rounded at 3 instructions, given rb = the correctly rounded reciprocal of b (host: exact_rcp, a kernel
+// argument and therefore an SGPR): quotient estimate, exact remainder, one correction (Markstein).  The IEEE division
+// sequence is ~10 instructions per element; tests/csrc/div_exact_check.c checks bit-equality with a / b.
+inline float exact_rcp(float nf) {  // the float closest to 1 / n: minimise |r n - 1| (exact in double) over the neighbours
+    const double n = (double)nf;
+    float best = (float)(1.0 / (n > 0.0 ? n : 1.0));
+    const float cand[2] = {nextafterf(best, 0.0f), nextafterf(best, 2.0f)};
+    for (float r : cand)
+        if (fabs((double)r * n - 1.0) < fabs((double)best * n - 1.0)) best = r;
+    return best;
+}
 __device__ __forceinline__ float div_exact(float a, float b, float rb) {
     const float q = __fmul_rn(a, rb);
     return __fmaf_rn(__fmaf_rn(-q, b, a), rb, q);
 }
-__device__ __forceinline__ float prescale(float v, float nm1, float inv_pow) {
-    const float rc = __fdiv_rn(1.0f, nm1);
-    return __fmul_rn(div_exact(__fmul_rn(v, 2.0f), nm1, rc), inv_pow);
+__device__ __forceinline__ float prescale(float v, float nm1, float rnm1, float inv_pow) {
+    return __fmul_rn(div_exact(__fmul_rn(v, 2.0f), nm1, rnm1), inv_pow);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -23,13 +23,14 @@ constexpr int kExpBlock = 512;
 
 struct Scale3L {
     float nm1[3];
+    float rnm1[3];  // correctly rounded 1 / nm1 (common.h: exact_rcp, div_exact)
     float inv_pow;
 };
 
 template <bool PRESCALE>
-__device__ __forceinline__ float ldp(const float* __restrict__ p, int64_t i, float nm1, float inv_pow) {
+__device__ __forceinline__ float ldp(const float* __restrict__ p, int64_t i, float nm1, float rnm1, float inv_pow) {
     const float v = p[i];
-    return PRESCALE ? prescale(v, nm1, inv_pow) : v;
+    return PRESCALE ? prescale(v, nm1, rnm1, inv_pow) : v;
 }
 
 // Layout of the squaring-step working fields: planar ([3][V], the reference's tensors) or interleaved ([V][3]).  The fused
@@ -71,9 +72,9 @@ __device__ __forceinline__ void stage_field(const float* __restrict__ c0, const 
         const int gx = min(max(ox - H + lx, 0), vol.W - 1), gy = min(max(oy - H + ly, 0), vol.H - 1),
                   gz = min(max(oz - H + lz, 0), vol.D - 1);
         const int64_t g = ((int64_t)gz * vol.H + gy) * vol.W + gx;
-        lds[i] = ldp<PRESCALE>(c0, g * LD.em, sc.nm1[0], sc.inv_pow);
-        lds[B::SN + i] = ldp<PRESCALE>(c0 + LD.cs, g * LD.em, sc.nm1[1], sc.inv_pow);
-        lds[2 * B::SN + i] = ldp<PRESCALE>(c0 + 2 * LD.cs, g * LD.em, sc.nm1[2], sc.inv_pow);
+        lds[i] = ldp<PRESCALE>(c0, g * LD.em, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
+        lds[B::SN + i] = ldp<PRESCALE>(c0 + LD.cs, g * LD.em, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
+        lds[2 * B::SN + i] = ldp<PRESCALE>(c0 + 2 * LD.cs, g * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
     }
 }
 
@@ -82,6 +83,7 @@ static Scale3L make_scale_l(Vol vol, int no_steps) {
     s.nm1[0] = (float)(vol.W - 1);
     s.nm1[1] = (float)(vol.H - 1);
     s.nm1[2] = (float)(vol.D - 1);
+    for (int c = 0; c < 3; ++c) s.rnm1[c] = exact_rcp(s.nm1[c]);
     s.inv_pow = 1.0f / (float)(1 << no_steps);
     return s;
 }
@@ -164,9 +166,9 @@ __device__ __forceinline__ void adjoint_source(const int x, const int y, const i
                         v2 = lds[2 * B::SN + idx];
                     } else {
                         const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
-                        v0 = ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.inv_pow);
-                        v1 = ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.inv_pow);
-                        v2 = ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.inv_pow);
+                        v0 = ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
+                        v1 = ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
+                        v2 = ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
                     }
                     const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
                     const float dot = v0 * G0 + v1 * G1 + v2 * G2;
@@ -252,9 +254,9 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
                 d2 = lds[2 * B::SN + ctr];
             } else {
                 const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-                d0 = ldp<PRESCALE>(c0, g * LD.em, sc.nm1[0], sc.inv_pow);
-                d1 = ldp<PRESCALE>(c0 + LD.cs, g * LD.em, sc.nm1[1], sc.inv_pow);
-                d2 = ldp<PRESCALE>(c0 + 2 * LD.cs, g * LD.em, sc.nm1[2], sc.inv_pow);
+                d0 = ldp<PRESCALE>(c0, g * LD.em, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
+                d1 = ldp<PRESCALE>(c0 + LD.cs, g * LD.em, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
+                d2 = ldp<PRESCALE>(c0 + 2 * LD.cs, g * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
             }
             adjoint_source<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, Gc, LG, gsc_, c0, LD, lds, acc, vol, lin, sc);
         }
@@ -369,9 +371,9 @@ __device__ __forceinline__ void exp_bwd_generic_column(const float* __restrict__
             for (int sy = max(y - hs, 0); sy <= min(y + hs, vol.H - 1); ++sy)
                 for (int sx = max(x - hs, 0); sx <= min(x + hs, vol.W - 1); ++sx) {
                     const int64_t idx = ((int64_t)sz * vol.H + sy) * vol.W + sx;
-                    const float d0 = ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.inv_pow),
-                                d1 = ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.inv_pow),
-                                d2 = ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.inv_pow);
+                    const float d0 = ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.rnm1[0], sc.inv_pow),
+                                d1 = ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.rnm1[1], sc.inv_pow),
+                                d2 = ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
                     const float px = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.x[sx], d0), 1.0f), 0.5f), nxm), 0.0f, nxm);
                     const float py = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.y[sy], d1), 1.0f), 0.5f), nym), 0.0f, nym);
                     const float pz = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.z[sz], d2), 1.0f), 0.5f), nzm), 0.0f, nzm);
@@ -387,17 +389,17 @@ __device__ __forceinline__ void exp_bwd_generic_column(const float* __restrict__
         const int64_t own = ((int64_t)zo * vol.H + y) * vol.W + x;
         const float gmo = gsc ? gsc[own] : 1.0f;
         const float G0 = Gc[own * LG.em] * gmo, G1 = Gc[LG.cs + own * LG.em] * gmo, G2 = Gc[2 * LG.cs + own * LG.em] * gmo;
-        const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], ldp<PRESCALE>(c0, own * LD.em, sc.nm1[0], sc.inv_pow)), vol.W);
-        const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], ldp<PRESCALE>(c0 + LD.cs, own * LD.em, sc.nm1[1], sc.inv_pow)), vol.H);
-        const AxisTap tz = axis_tap(__fadd_rn(lin.z[zo], ldp<PRESCALE>(c0 + 2 * LD.cs, own * LD.em, sc.nm1[2], sc.inv_pow)), vol.D);
+        const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], ldp<PRESCALE>(c0, own * LD.em, sc.nm1[0], sc.rnm1[0], sc.inv_pow)), vol.W);
+        const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], ldp<PRESCALE>(c0 + LD.cs, own * LD.em, sc.nm1[1], sc.rnm1[1], sc.inv_pow)), vol.H);
+        const AxisTap tz = axis_tap(__fadd_rn(lin.z[zo], ldp<PRESCALE>(c0 + 2 * LD.cs, own * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow)), vol.D);
         float gix = 0.0f, giy = 0.0f, giz = 0.0f;
         for (int cz = 0; cz < 2; ++cz)
             for (int cy = 0; cy < 2; ++cy)
                 for (int cx = 0; cx < 2; ++cx) {
                     const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
-                    const float dot = fmaf(ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.inv_pow), G2,
-                                           fmaf(ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.inv_pow), G1,
-                                                ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.inv_pow) * G0));
+                    const float dot = fmaf(ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow), G2,
+                                           fmaf(ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.rnm1[1], sc.inv_pow), G1,
+                                                ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.rnm1[0], sc.inv_pow) * G0));
                     const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
                     gix += (cx ? dot : -dot) * (wy * wz);
                     giy += (cy ? dot : -dot) * (wx * wz);
@@ -525,9 +527,9 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                 q_dz[i] = 0.0f;
                 continue;
             }
-            const float d0 = PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.inv_pow) : pre[it][0];
-            const float d1 = PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.inv_pow) : pre[it][1];
-            const float d2 = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.inv_pow) : pre[it][2];
+            const float d0 = PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.rnm1[0], sc.inv_pow) : pre[it][0];
+            const float d1 = PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.rnm1[1], sc.inv_pow) : pre[it][1];
+            const float d2 = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.rnm1[2], sc.inv_pow) : pre[it][2];
             const float qx = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(slx[it], d0), 1.0f), 0.5f), nxm);
             const float qy = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(sly[it], d1), 1.0f), 0.5f), nym);
             const float qz = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lz_, d2), 1.0f), 0.5f), nzm);
@@ -639,9 +641,9 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
 #pragma unroll
                                 for (int cx = 0; cx < 2; ++cx) {
                                     const int64_t idx = (((int64_t)min(iz0 + cz, vol.D - 1) * vol.H + min(iy0 + cy, vol.H - 1)) * vol.W + min(ix0 + cx, vol.W - 1)) * LD.em;
-                                    dot[cz][cy][cx] = fmaf(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.inv_pow), G2,
-                                                           fmaf(ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.inv_pow), G1,
-                                                                ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.inv_pow) * G0));
+                                    dot[cz][cy][cx] = fmaf(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.rnm1[2], sc.inv_pow), G2,
+                                                           fmaf(ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.rnm1[1], sc.inv_pow), G1,
+                                                                ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.rnm1[0], sc.inv_pow) * G0));
                                 }
                     }
                     // J^T G of the trilinear interpolant: differences of the corner dots along one axis, bilinear in the others
@@ -805,9 +807,9 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
             const int i = slot * PN + threadIdx.x + it * kFwdBlock;
-            r_xy[i] = make_float2(PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.inv_pow) : pre[it][0],
-                                  PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.inv_pow) : pre[it][1]);
-            r_z[i] = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.inv_pow) : pre[it][2];
+            r_xy[i] = make_float2(PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.rnm1[0], sc.inv_pow) : pre[it][0],
+                                  PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.rnm1[1], sc.inv_pow) : pre[it][1]);
+            r_z[i] = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.rnm1[2], sc.inv_pow) : pre[it][2];
         }
     };
 
@@ -877,9 +879,9 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                             for (int cx = 0; cx < 2; ++cx) {
                                 const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
                                 const int64_t idx = (((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0)) * LD.em;
-                                a0 = __fadd_rn(a0, __fmul_rn(ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.inv_pow), w));
-                                a1 = __fadd_rn(a1, __fmul_rn(ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.inv_pow), w));
-                                a2 = __fadd_rn(a2, __fmul_rn(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.inv_pow), w));
+                                a0 = __fadd_rn(a0, __fmul_rn(ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.rnm1[0], sc.inv_pow), w));
+                                a1 = __fadd_rn(a1, __fmul_rn(ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.rnm1[1], sc.inv_pow), w));
+                                a2 = __fadd_rn(a2, __fmul_rn(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.rnm1[2], sc.inv_pow), w));
                             }
                 }
                 const int64_t pl = (int64_t)zo * vol.H * vol.W * LO.em;
@@ -969,7 +971,7 @@ __global__ __launch_bounds__(kBlock) void field_absmax_kernel(const float* __res
     IRS_ROWS_BEGIN(vol, x, y, z, v)
         (void)x; (void)y; (void)z;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) m[c] = fmaxf(m[c], fabsf(ldp<PRESCALE>(c0 + c * vol.V, v, sc.nm1[c], sc.inv_pow)));
+        for (int c = 0; c < 3; ++c) m[c] = fmaxf(m[c], fabsf(ldp<PRESCALE>(c0 + c * vol.V, v, sc.nm1[c], sc.rnm1[c], sc.inv_pow)));
     IRS_ROWS_END
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

@@ -5,6 +5,7 @@
 //   cubic B-spline FFD up-sampling / adjoint (utils/transformation.py:105-153)
 // All of it is HBM/L2-bound gather/stencil work on planar fp32 fields (C,3,D,H,W); no MFMA by design.
 #include "kernels.h"
+#include "warp_device.h"
 
 namespace irs {
 
@@ -95,13 +96,14 @@ void launch_conv_axis(const float* in, float* out, const Taps& taps, int axis, i
 struct Scale3 {
     float nm1[3];   // axis length - 1 for channel c: x <-> W, y <-> H, z <-> D (the reference pairs channel c with
                     // shape[2 + c], which is the same thing for the cubic volumes it supports)
+    float rnm1[3];  // correctly rounded 1 / nm1 (common.h: exact_rcp, div_exact)
     float inv_pow;  // 1 / 2^no_steps
 };
 
 template <bool PRESCALE>
-__device__ __forceinline__ float ld(const float* p, int64_t i, float nm1, float inv_pow) {
+__device__ __forceinline__ float ld(const float* p, int64_t i, float nm1, float rnm1, float inv_pow) {
     const float v = p[i];
-    return PRESCALE ? prescale(v, nm1, inv_pow) : v;
+    return PRESCALE ? prescale(v, nm1, rnm1, inv_pow) : v;
 }
 
 template <bool PRESCALE>
@@ -113,9 +115,9 @@ __global__ __launch_bounds__(kBlock) void exp_step_fwd_kernel(const float* __res
     const float* c1 = c0 + V;
     const float* c2 = c1 + V;
 
-    const float d0 = ld<PRESCALE>(c0, vox, sc.nm1[0], sc.inv_pow);
-    const float d1 = ld<PRESCALE>(c1, vox, sc.nm1[1], sc.inv_pow);
-    const float d2 = ld<PRESCALE>(c2, vox, sc.nm1[2], sc.inv_pow);
+    const float d0 = ld<PRESCALE>(c0, vox, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
+    const float d1 = ld<PRESCALE>(c1, vox, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
+    const float d2 = ld<PRESCALE>(c2, vox, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
 
     const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
     const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
@@ -131,9 +133,9 @@ __global__ __launch_bounds__(kBlock) void exp_step_fwd_kernel(const float* __res
             for (int cx = 0; cx < 2; ++cx) {
                 const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
                 const int64_t idx = rowoff + (cx ? tx.i1 : tx.i0);
-                a0 = __fadd_rn(a0, __fmul_rn(ld<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow), w));
-                a1 = __fadd_rn(a1, __fmul_rn(ld<PRESCALE>(c1, idx, sc.nm1[1], sc.inv_pow), w));
-                a2 = __fadd_rn(a2, __fmul_rn(ld<PRESCALE>(c2, idx, sc.nm1[2], sc.inv_pow), w));
+                a0 = __fadd_rn(a0, __fmul_rn(ld<PRESCALE>(c0, idx, sc.nm1[0], sc.rnm1[0], sc.inv_pow), w));
+                a1 = __fadd_rn(a1, __fmul_rn(ld<PRESCALE>(c1, idx, sc.nm1[1], sc.rnm1[1], sc.inv_pow), w));
+                a2 = __fadd_rn(a2, __fmul_rn(ld<PRESCALE>(c2, idx, sc.nm1[2], sc.rnm1[2], sc.inv_pow), w));
             }
         }
     }
@@ -148,6 +150,7 @@ static Scale3 make_scale(Vol vol, int no_steps) {
     s.nm1[0] = (float)(vol.W - 1);
     s.nm1[1] = (float)(vol.H - 1);
     s.nm1[2] = (float)(vol.D - 1);
+    for (int c = 0; c < 3; ++c) s.rnm1[c] = exact_rcp(s.nm1[c]);
     s.inv_pow = 1.0f / (float)(1 << no_steps);
     return s;
 }
@@ -181,9 +184,9 @@ __global__ __launch_bounds__(kBlock) void exp_step_bwd_kernel(const float* __res
     float* g2 = g1 + V;
 
     const float G0 = G[cb + vox], G1 = G[cb + V + vox], G2 = G[cb + 2 * V + vox];
-    const float d0 = ld<PRESCALE>(c0, vox, sc.nm1[0], sc.inv_pow);
-    const float d1 = ld<PRESCALE>(c1, vox, sc.nm1[1], sc.inv_pow);
-    const float d2 = ld<PRESCALE>(c2, vox, sc.nm1[2], sc.inv_pow);
+    const float d0 = ld<PRESCALE>(c0, vox, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
+    const float d1 = ld<PRESCALE>(c1, vox, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
+    const float d2 = ld<PRESCALE>(c2, vox, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
 
     const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
     const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
@@ -199,9 +202,9 @@ __global__ __launch_bounds__(kBlock) void exp_step_bwd_kernel(const float* __res
             for (int cx = 0; cx < 2; ++cx) {
                 const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
                 const int64_t idx = rowoff + (cx ? tx.i1 : tx.i0);
-                const float v0 = ld<PRESCALE>(c0, idx, sc.nm1[0], sc.inv_pow);
-                const float v1 = ld<PRESCALE>(c1, idx, sc.nm1[1], sc.inv_pow);
-                const float v2 = ld<PRESCALE>(c2, idx, sc.nm1[2], sc.inv_pow);
+                const float v0 = ld<PRESCALE>(c0, idx, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
+                const float v1 = ld<PRESCALE>(c1, idx, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
+                const float v2 = ld<PRESCALE>(c2, idx, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
                 const float dot = v0 * G0 + v1 * G1 + v2 * G2;
                 gix += (cx ? dot : -dot) * (wy * wz);
                 giy += (cy ? dot : -dot) * (wx * wz);
@@ -254,118 +257,67 @@ void launch_svf_outputs(const float* d, float* transformation, float* displaceme
 // ------------------------------------------------------------------------------------------------
 // warp of the moving image at id + d (+ uniform jitter, utils/util.py:44-53) and its grid-gradient
 // ------------------------------------------------------------------------------------------------
-struct Jitter {
-    float alpha;       // <= 0: disabled
-    float nm1[3];      // transform_coordinates scaling of the jitter (x <-> W, y <-> H, z <-> D)
-    float rnm1[3];     // correctly rounded 1 / nm1 (host): the division below stays exact at 3 instructions
-    uint64_t seed, iteration;
-    const uint64_t* dev_iter;
-};
-
 __device__ __forceinline__ void grid_point(const float* __restrict__ d, const float* __restrict__ unif, const Jitter& jt,
                                            int64_t cb3, int chain, int64_t vox, Vol vol, Lin lin, int x, int y, int z,
                                            float (&g)[3]) {
     g[0] = __fadd_rn(lin.x[x], d[cb3 + vox]);
     g[1] = __fadd_rn(lin.y[y], d[cb3 + vol.V + vox]);
     g[2] = __fadd_rn(lin.z[z], d[cb3 + 2 * vol.V + vox]);
-    if (jt.alpha > 0.0f) {
-        float u[3];
-        if (unif) {
-            u[0] = unif[cb3 + vox];
-            u[1] = unif[cb3 + vol.V + vox];
-            u[2] = unif[cb3 + 2 * vol.V + vox];
-        } else {
-            const uint64_t it = jt.dev_iter ? *jt.dev_iter : jt.iteration;
-            const uint64_t idx = (uint64_t)chain * (uint64_t)vol.V + (uint64_t)vox;  // < 2^36 (dims_ok, chains)
-            const U2 r = philox2x32_10(U2{(uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)it << 4)}, key_mix(jt.seed, it, 0x554Eu));
-            u[0] = u01_21(r.x >> 11);
-            u[1] = u01_21(r.y >> 11);
-            u[2] = u01_21((r.x & 0x7FFu) | ((r.y & 0x3FFu) << 11));
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float nz = __fadd_rn(__fmul_rn(-2.0f * jt.alpha, u[c]), jt.alpha);  // -2 a u + a
-            // (nz * 2) / (n - 1), correctly rounded at 3 instructions (common.h: div_exact)
-            g[c] = __fadd_rn(g[c], div_exact(__fmul_rn(nz, 2.0f), jt.nm1[c], jt.rnm1[c]));
-        }
-    }
+    jitter_point(g, unif, jt, cb3, chain, vox, vol.V);
 }
 
 // `gradm` (optional, (C,3,D,H,W)): d(warped)/d(d_last) = the trilinear gradient of the moving image at the sampling
 // position, with the clamp mask -- exactly what warp_bwd_kernel multiplies the upstream gradient with.  The fused transition
 // lets the forward warp write it (the 8 taps are loaded anyway) and folds the product with g_warped into the staging of the
 // first adjoint squaring step, so the backward warp and its 24 B/voxel round trip disappear.
+// Each thread handles IRS_WARP_NV voxels (rows y, y + 4, ...) with all their loads issued before the first use: the kernel
+// is two dependent memory round trips (d, then the eight taps at the position d names) and nothing else, so the number of
+// independent voxels in flight per lane is what sets its rate.
+#ifndef IRS_WARP_NV
+#define IRS_WARP_NV 2
+#endif
 __global__ __launch_bounds__(kBlock) void warp_fwd_kernel(const float* __restrict__ im, int64_t im_stride,
                                                           const float* __restrict__ d, const float* __restrict__ unif,
                                                           Jitter jt, float* __restrict__ out, float* __restrict__ gradm,
                                                           int gradm_aos, Vol vol, Lin lin) {
-    IRS_VOXEL(vol, chain, x, y, z, vox);
-    float g[3];
-    grid_point(d, unif, jt, (int64_t)chain * 3 * vol.V, chain, vox, vol, lin, x, y, z, g);
-    const AxisTap tx = axis_tap(g[0], vol.W), ty = axis_tap(g[1], vol.H), tz = axis_tap(g[2], vol.D);
+    constexpr int NV = IRS_WARP_NV;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y0 = blockIdx.y * (4 * NV) + (threadIdx.x >> 6);
+    const int chain = blockIdx.z / vol.nz, z = vol.z0 + blockIdx.z - chain * vol.nz;
+    if (x >= vol.W || y0 >= vol.H) return;
+    const int64_t cb3 = (int64_t)chain * 3 * vol.V;
     const float* src = im + (int64_t)chain * im_stride;
-    float acc = 0.0f, gix = 0.0f, giy = 0.0f, giz = 0.0f;
-    // 32-bit element offsets from the (uniform) image base: a chain's volume has < 2^31 voxels (dims_ok).  Two integer
-    // multiplies (quarter rate) instead of one per corner row: i1 is i0 or i0 + 1
-    const unsigned hw = (unsigned)(vol.H * vol.W);
-    const unsigned offz[2] = {(unsigned)tz.i0 * hw, (unsigned)tz.i0 * hw + (tz.i1 != tz.i0 ? hw : 0u)};
-    const unsigned offy[2] = {(unsigned)ty.i0 * (unsigned)vol.W, (unsigned)ty.i0 * (unsigned)vol.W + (ty.i1 != ty.i0 ? (unsigned)vol.W : 0u)};
+    float g[NV][3], gm[NV][3], wv[NV];
+    int64_t vox[NV];
 #pragma unroll
-    for (int cz = 0; cz < 2; ++cz)
+    for (int h = 0; h < NV; ++h) {  // rows past the volume repeat the last one (loads stay unconditional), their stores are skipped
+        const int y = min(y0 + 4 * h, vol.H - 1);
+        vox[h] = ((int64_t)z * vol.H + y) * vol.W + x;
+        grid_point(d, unif, jt, cb3, chain, vox[h], vol, lin, x, y, z, g[h]);
+    }
 #pragma unroll
-        for (int cy = 0; cy < 2; ++cy) {
-            const unsigned rowoff = offz[cz] + offy[cy];
+    for (int h = 0; h < NV; ++h) wv[h] = gradm ? warp_sample<true>(src, g[h], vol, gm[h]) : warp_sample<false>(src, g[h], vol, gm[h]);
 #pragma unroll
-            for (int cx = 0; cx < 2; ++cx) {
-                const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
-                const float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + (size_t)((rowoff + (unsigned)(cx ? tx.i1 : tx.i0)) * 4u));
-                acc = __fadd_rn(acc, __fmul_rn(val, __fmul_rn(__fmul_rn(wx, wy), wz)));
-                if (gradm) {  // same expressions as warp_bwd_kernel
-                    gix += (cx ? val : -val) * (wy * wz);
-                    giy += (cy ? val : -val) * (wx * wz);
-                    giz += (cz ? val : -val) * (wx * wy);
-                }
+    for (int h = 0; h < NV; ++h) {
+        if (y0 + 4 * h >= vol.H) continue;
+        out[(int64_t)chain * vol.V + vox[h]] = wv[h];
+        if (gradm) {
+            if (gradm_aos) {  // interleaved ([V][3]): the layout the fused adjoint steps read (exp_kernels.hip: Lay3)
+                typedef float f3v __attribute__((ext_vector_type(3)));
+                const f3v v = {gm[h][0], gm[h][1], gm[h][2]};
+                __builtin_memcpy(gradm + cb3 + vox[h] * 3, &v, 12);
+            } else {
+                gradm[cb3 + vox[h]] = gm[h][0];
+                gradm[cb3 + vol.V + vox[h]] = gm[h][1];
+                gradm[cb3 + 2 * vol.V + vox[h]] = gm[h][2];
             }
         }
-    out[(int64_t)chain * vol.V + vox] = acc;
-    if (gradm) {
-        const int64_t cb3 = (int64_t)chain * 3 * vol.V;
-        if (gradm_aos) {  // interleaved ([V][3]): the layout the fused adjoint steps read (exp_kernels.hip: Lay3)
-            typedef float f3v __attribute__((ext_vector_type(3)));
-            const f3v v = {tx.gmul * gix, ty.gmul * giy, tz.gmul * giz};
-            __builtin_memcpy(gradm + cb3 + (int64_t)vox * 3, &v, 12);
-        } else {
-            gradm[cb3 + vox] = tx.gmul * gix;
-            gradm[cb3 + vol.V + vox] = ty.gmul * giy;
-            gradm[cb3 + 2 * vol.V + vox] = tz.gmul * giz;
-        }
     }
-}
-
-static Jitter make_jitter(float alpha, Vol vol, uint64_t seed, uint64_t iteration, const uint64_t* dev_iter) {
-    Jitter j;
-    j.alpha = alpha;
-    j.nm1[0] = (float)(vol.W - 1);
-    j.nm1[1] = (float)(vol.H - 1);
-    j.nm1[2] = (float)(vol.D - 1);
-    for (int c = 0; c < 3; ++c) {  // the float closest to 1 / nm1: minimise |r * nm1 - 1| (exact in double) over the neighbours
-        const double n = (double)j.nm1[c];
-        float best = (float)(1.0 / (n > 0.0 ? n : 1.0));
-        const float cand[2] = {nextafterf(best, 0.0f), nextafterf(best, 2.0f)};
-        for (float r : cand)
-            if (fabs((double)r * n - 1.0) < fabs((double)best * n - 1.0)) best = r;
-        j.rnm1[c] = best;
-    }
-    j.seed = seed;
-    j.iteration = iteration;
-    j.dev_iter = dev_iter;
-    return j;
 }
 
 void launch_warp_fwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha, float* out,
                      float* gradm, int gradm_aos, int C, Vol vol, Lin lin, uint64_t seed, uint64_t iteration,
                      const uint64_t* dev_iteration, hipStream_t st) {
-    const dim3 grid = vox_grid(vol, C);
+    const dim3 grid((unsigned)((vol.W + 63) / 64), (unsigned)((vol.H + 4 * IRS_WARP_NV - 1) / (4 * IRS_WARP_NV)), (unsigned)(vol.nz * C));
     hipLaunchKernelGGL(warp_fwd_kernel, grid, dim3(kBlock), 0, st, im, im_stride, d, unif,
                        make_jitter(alpha, vol, seed, iteration, dev_iteration), out, gradm, gradm_aos, vol, lin);
 }
