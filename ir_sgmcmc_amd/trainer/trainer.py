@@ -110,11 +110,11 @@ class Trainer(VIMixin, BaseTrainer):
         data_loss, reg_loss = self.losses['data']['loss'], self.losses['reg']['loss']
         if type(data_loss).__name__ == 'GMM':
             for k in range(data_loss.no_components):
-                st.gmm_log_std[k], st.gmm_logits[k] = float(data_loss.log_std[k]), float(data_loss.logits[k])
+                st.gmm_log_std[k], st.gmm_logits[k] = float(data_loss.log_std[k].detach()), float(data_loss.logits[k].detach())
         if type(reg_loss).__name__ == 'RegLoss_L2':
-            st.reg_param[0] = float(reg_loss.log_w_reg)
+            st.reg_param[0] = float(reg_loss.log_w_reg.detach())
         elif type(reg_loss).__name__ == 'RegLoss_LogNormal':
-            st.reg_param[0], st.reg_param[1] = float(reg_loss.loc), float(reg_loss.log_scale)
+            st.reg_param[0], st.reg_param[1] = float(reg_loss.loc.detach()), float(reg_loss.log_scale.detach())
         self.engine.set_state(st)
 
     def sync_parameters(self):
