@@ -730,11 +730,19 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
 #define IRS_FTY 8
 #define IRS_FROWS 2
 #endif
+#ifndef IRS_FWD_PITCH_ALIGN
+#define IRS_FWD_PITCH_ALIGN 16
+#endif
 constexpr int FTX = IRS_FTX, FTY = IRS_FTY, FROWS = IRS_FROWS, kFwdBlock = FTX * FTY / FROWS;
 template <int R>
 struct MarchF {
     static constexpr int NP = 2 * R + 1, PX = FTX + 2 * R, PY = FTY + 2 * R, PN = PX * PY;
     static constexpr int NIT = (PN + kFwdBlock - 1) / kFwdBlock;
+    // LDS row pitch: a multiple of 16 elements, so that rows and ring slots of the 8-byte (d0, d1) records start on the same
+    // bank -- lanes of a wave whose taps fall into different rows / planes (any displacement field whose sign changes inside
+    // a wave) then collide only through the x shift, not through the row they read
+    static constexpr int PITCH = (IRS_FWD_PITCH_ALIGN > 1 && R == 1) ? (PX + IRS_FWD_PITCH_ALIGN - 1) / IRS_FWD_PITCH_ALIGN * IRS_FWD_PITCH_ALIGN : PX;  // the radius-2 ring stays below 64 KB
+    static constexpr int PNP = PITCH * PY;
 };
 template <bool PRESCALE, int R>
 __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din, float* __restrict__ dout, const Vol vol,
@@ -743,12 +751,12 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                                                    const int h_lo, const int h_hi, const int swz_run, const int tile_id,
                                                    const dim3 tiles, const int lay) {
     using M = MarchF<R>;
-    constexpr int PX = M::PX, PN = M::PN, NIT = M::NIT;
+    constexpr int PX = M::PX, PN = M::PN, NIT = M::NIT, PITCH = M::PITCH, PNP = M::PNP;
     // ring of 2R+2 slots: one more than a sample can reach, so that the commit of the next source plane never overwrites
     // a plane another wavefront is still sampling -> ONE barrier per plane instead of two
     constexpr int NS = M::NP + 1;
-    __shared__ float2 r_xy[NS * PN];  // (d0, d1): one ds_read_b64 per tap
-    __shared__ float r_z[NS * PN];    // d2
+    __shared__ float2 r_xy[NS * PNP];  // (d0, d1): one ds_read_b64 per tap
+    __shared__ float r_z[NS * PNP];    // d2
     __shared__ float red[3 * (kFwdBlock / kWave)];
     const int tile_ = xcd_swizzle_runs(tile_id, (int)(tiles.x * tiles.y * tiles.z), swz_run);
     const int tbx = tile_ % tiles.x, tby = (tile_ / tiles.x) % tiles.y, tbz = tile_ / (tiles.x * tiles.y);
@@ -771,13 +779,14 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
     const int x = ox + lx;
     const float linx = x < vol.W ? lin.x[x] : 0.0f;
 
-    int sxy[NIT];
+    int sxy[NIT], sld[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = threadIdx.x + it * kFwdBlock;
         const int px = i % PX, py = i / PX;
         const int cx = min(max(ox - R + px, 0), vol.W - 1), cy = min(max(oy - R + py, 0), vol.H - 1);
         sxy[it] = i < PN ? cy * vol.W + cx : -1;
+        sld[it] = py * PITCH + px;
     }
     float pre[NIT][3];
     auto prefetch = [&](int s) {
@@ -806,7 +815,7 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
-            const int i = slot * PN + threadIdx.x + it * kFwdBlock;
+            const int i = slot * PNP + sld[it];
             r_xy[i] = make_float2(PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.rnm1[0], sc.inv_pow) : pre[it][0],
                                   PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.rnm1[1], sc.inv_pow) : pre[it][1]);
             r_z[i] = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.rnm1[2], sc.inv_pow) : pre[it][2];
@@ -833,7 +842,7 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                 if (x >= vol.W || y >= vol.H) continue;
                 const float liny = lin.y[y];
                 const int a = (PH - R + NS) % NS;  // slot of plane zo (compile-time)
-                const int ci = a * PN + (ly + R) * PX + (lx + R);
+                const int ci = a * PNP + (ly + R) * PITCH + (lx + R);
                 const float2 dxy = r_xy[ci];
                 const float d0 = dxy.x, d1 = dxy.y, d2 = r_z[ci];
                 const AxisTap tx = axis_tap(__fadd_rn(linx, d0), vol.W);
@@ -849,13 +858,13 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                     const float wxy[2][2] = {{__fmul_rn(tx.w0, ty.w0), __fmul_rn(tx.w1, ty.w0)},
                                              {__fmul_rn(tx.w0, ty.w1), __fmul_rn(tx.w1, ty.w1)}};
                     // plane zo + q sits in ring slot (a + q) mod NS; with a compile-time `a` the slots are constants picked by `rel`
-                    int sl0 = ((a - R + NS) % NS) * PN, sl1 = ((a - R + 1 + NS) % NS) * PN;
+                    int sl0 = ((a - R + NS) % NS) * PNP, sl1 = ((a - R + 1 + NS) % NS) * PNP;
 #pragma unroll
                     for (int q = -R + 1; q < R; ++q) {
-                        sl0 = rel == q ? ((a + q + NS) % NS) * PN : sl0;
-                        sl1 = rel == q ? ((a + q + 1 + NS) % NS) * PN : sl1;
+                        sl0 = rel == q ? ((a + q + NS) % NS) * PNP : sl0;
+                        sl1 = rel == q ? ((a + q + 1 + NS) % NS) * PNP : sl1;
                     }
-                    const int off = by0 * PX + bx0;
+                    const int off = by0 * PITCH + bx0;
 #pragma unroll
                     for (int cz = 0; cz < 2; ++cz) {
                         const int bs = (cz ? sl1 : sl0) + off;
@@ -864,10 +873,10 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
 #pragma unroll
                             for (int cx = 0; cx < 2; ++cx) {
                                 const float w = __fmul_rn(wxy[cy][cx], cz ? tz.w1 : tz.w0);
-                                const float2 txy = r_xy[bs + cy * PX + cx];
+                                const float2 txy = r_xy[bs + cy * PITCH + cx];
                                 a0 = __fadd_rn(a0, __fmul_rn(txy.x, w));
                                 a1 = __fadd_rn(a1, __fmul_rn(txy.y, w));
-                                a2 = __fadd_rn(a2, __fmul_rn(r_z[bs + cy * PX + cx], w));
+                                a2 = __fadd_rn(a2, __fmul_rn(r_z[bs + cy * PITCH + cx], w));
                             }
                     }
                 } else {
@@ -928,8 +937,11 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
     }
 }
 
+#ifndef IRS_FWD_WAVES
+#define IRS_FWD_WAVES 1
+#endif
 template <bool PRESCALE, int R>
-__global__ __launch_bounds__(kFwdBlock) void exp_fwd_march_kernel(const float* __restrict__ din, float* __restrict__ dout,
+__global__ __launch_bounds__(kFwdBlock, R == 1 ? IRS_FWD_WAVES : 1) void exp_fwd_march_kernel(const float* __restrict__ din, float* __restrict__ dout,
                                                                   Vol vol, Lin lin, Scale3L sc,
                                                                   const unsigned* __restrict__ dmax_in,
                                                                   unsigned* __restrict__ dmax_out, int seg_len, int nseg,
