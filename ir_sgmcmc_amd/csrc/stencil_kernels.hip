@@ -638,14 +638,21 @@ void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* s
 // pointwise version evaluated it for every neighbour again, up to 4 per voxel), the neighbours come from an LDS plane
 // (x, y) and a register (z).  partials: [gridDim.x][kStatVals], reduced by the scalar kernels in fixed order.
 // ------------------------------------------------------------------------------------------------
-constexpr int QTX = 64, QTY = 4, QPX = QTX + 1, QPN = QPX * (QTY + 1);
+#ifndef IRS_STATS_TY
+#define IRS_STATS_TY 8
+#endif
+// 64 x 8 tile, two rows per thread: the tile + halo (65 x 9) takes 3 passes of the 256 threads for 2 rows of outputs; with a
+// 64 x 4 tile it was 2 passes per row, the second one (halo column and row) on 69 lanes only.  Measured at 256^3: 64 x 8 with
+// 8-plane segments beats 64 x 4 and 64 x 16 (data stage 0.664 / 0.683 / 0.707 ms)
+constexpr int QTX = 64, QTY = 4, QPX = QTX + 1, QPN = QPX * (QTY + 1);  // reg_energy_march_kernel: one output per thread
+constexpr int TTY = IRS_STATS_TY, TPN = QPX * (TTY + 1), QROWS = kStBlock / QTX, QNOUT = TTY / QROWS;
 
 __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __restrict__ z, const uint8_t* __restrict__ mask,
                                                                const DevState* __restrict__ state, int want_vd,
                                                                double* __restrict__ partials, Vol vol, int seg_len, int nseg,
                                                                int ntx, int nty) {
-    constexpr int NIT = (QPN + kStBlock - 1) / kStBlock;
-    __shared__ float X[QPN];
+    constexpr int NIT = (TPN + kStBlock - 1) / kStBlock;
+    __shared__ float X[TPN];
     __shared__ double smem[kStatVals * (kStBlock / kWave)];
     double acc[kStatVals];
 #pragma unroll
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
     const bool gmm = state->mode == IRS_DATA_GMM_LCC;
     const int total = ntx * nty * nseg;
     for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
-        const int ox = (tile % ntx) * QTX, oy = ((tile / ntx) % nty) * QTY, seg = tile / (ntx * nty);
+        const int ox = (tile % ntx) * QTX, oy = ((tile / ntx) % nty) * TTY, seg = tile / (ntx * nty);
         const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
         unsigned off[NIT];
         bool valid[NIT], owned[NIT];
@@ -665,8 +672,8 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
             const int i = threadIdx.x + it * kStBlock;
             const int ex = i % QPX, ey = i / QPX;
             const int gx = ox + ex, gy = oy + ey;
-            valid[it] = i < QPN && gx < vol.W && gy < vol.H;
-            owned[it] = valid[it] && ex < QTX && ey < QTY;
+            valid[it] = i < TPN && gx < vol.W && gy < vol.H;
+            owned[it] = valid[it] && ex < QTX && ey < TTY;
             if (!want_vd) valid[it] = owned[it];  // no neighbour products: the halo is not needed
             off[it] = valid[it] ? (unsigned)(gy * vol.W + gx) : 0u;
         }
@@ -683,7 +690,9 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
                 }
         };
         load_plane(z0);
-        float xprev = 0.0f;
+        float xprev[QNOUT];
+#pragma unroll
+        for (int o = 0; o < QNOUT; ++o) xprev[o] = 0.0f;
         for (int zc = z0; zc < zend; ++zc) {
             const bool inseg = zc < z1;
 #pragma unroll
@@ -709,19 +718,23 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
                         xv = mix_eval<false>(pz[it], state, nullptr, nullptr).x;
                     }
                 }
-                if (i < QPN) X[i] = xv;
+                if (i < TPN) X[i] = xv;
             }
             if (zc + 1 < zend) load_plane(zc + 1);
             __syncthreads();
             if (want_vd) {
                 // lag-1 neighbours along D (reference "cov_x", dim 2), H (dim 3), W (dim 4); x = 0 off the mask / volume
-                const float own = X[ly * QPX + lx];
-                if (inseg) {
-                    acc[3] += (double)(own * X[(ly + 1) * QPX + lx]);
-                    acc[4] += (double)(own * X[ly * QPX + lx + 1]);
+#pragma unroll
+                for (int o = 0; o < QNOUT; ++o) {
+                    const int yy = ly + o * QROWS;
+                    const float own = X[yy * QPX + lx];
+                    if (inseg) {
+                        acc[3] += (double)(own * X[(yy + 1) * QPX + lx]);
+                        acc[4] += (double)(own * X[yy * QPX + lx + 1]);
+                    }
+                    if (zc > z0) acc[2] += (double)(xprev[o] * own);
+                    xprev[o] = own;
                 }
-                if (zc > z0) acc[2] += (double)(xprev * own);
-                xprev = own;
             }
             __syncthreads();
         }
@@ -735,9 +748,9 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
 void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, int blocks,
                         Vol vol, hipStream_t st) {
     static const int seg_env = getenv("IRS_STATS_SEG") ? atoi(getenv("IRS_STATS_SEG")) : 0;
-    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY), 8, seg_env);
+    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + TTY - 1) / TTY), 8, seg_env, 2048);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
-    const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + QTY - 1) / QTY;
+    const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + TTY - 1) / TTY;
     hipLaunchKernelGGL(stats_march_kernel, dim3(blocks), dim3(kStBlock), 0, st, z, mask, (const DevState*)dev_state, want_vd,
                        partials, vol, seg_len, nseg, ntx, nty);
 }
