@@ -42,7 +42,8 @@ enum { IRS_REG_L2 = 0, IRS_REG_LOGNORMAL = 1, IRS_REG_STUDENT = 2, IRS_REG_LOGNO
 /* SGLD.forward + SobolevGrad.forward: out = S * (v + sqrt(2 tau) sigma eps)
  * (utils/functions.py:76-84,98-109; utils/util.py:48-58,394-404).
  * v, out, tmp: (C,3,D,H,W).  sigma: NULL (=1) or (C,3,D,H,W).  eps: standard-normal tensor, or NULL ->
- * in-kernel Philox4x32-10 keyed by (seed, iteration).  kernel: 2s+1 host floats; s == 0 -> no smoothing.
+ * in-kernel Philox4x32-10 keyed by (seed, iteration), one call per voxel pair (z even, z + 1): six 21-bit words ->
+ * three Box-Muller pairs.  kernel: 2s+1 host floats; s == 0 -> no smoothing.
  * tau < 0 -> no noise.  `tmp` may not alias v or out; out may not alias v. */
 int irs_perturb_smooth(const float* v, const float* sigma, const float* eps, float tau, const float* kernel, int s,
                        int C, int D, int H, int W, float* tmp, float* out, uint64_t seed, uint64_t iteration,
