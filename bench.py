@@ -16,6 +16,7 @@ host cores) on a bounded sample and is a reported baseline, not a target.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -84,7 +85,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', type=int, default=256, help='volume edge N (N^3 voxels)')
     ap.add_argument('--loss', choices=['gmm', 'ssd'], default='gmm')
-    ap.add_argument('--init', choices=['identity', 'smooth'], default='identity',
+    ap.add_argument('--init', choices=['identity', 'smooth', 'wave'], default='identity',
                     help="chain start: identity (MCMC_init 'identity', sub-voxel displacements) or a smooth random velocity "
                          "field of --init-amp voxels (exercises the large-displacement kernel variants)")
     ap.add_argument('--init-amp', type=float, default=3.0)
@@ -145,6 +146,10 @@ def main():
         v = torch.nn.functional.interpolate(lo, size=dims, mode='trilinear', align_corners=True).to(dev).contiguous()
         v = perturb_smooth(v, sobolev_kernel_1d(3, 0.5)) * (args.init_amp / float(v.abs().max()))
         v = v.contiguous()
+    elif args.init == 'wave':  # one half-wave across the volume: large but smooth, like a converged registration
+        t = torch.linspace(0.0, math.pi, N, device=dev)
+        sz, sy, sx = torch.sin(t).view(N, 1, 1), torch.sin(t).view(1, N, 1), torch.sin(t).view(1, 1, N)
+        v = torch.stack([sz * sy * sx, -sz * sy * sx, 0.7 * sz * sy * sx]).unsqueeze(0).mul(args.init_amp).contiguous()
 
     def sync():
         torch.cuda.synchronize(dev)

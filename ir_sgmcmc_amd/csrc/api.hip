@@ -86,6 +86,7 @@ struct irs_ctx {
     double *stat_partials, *energy_partials, *nll_partials;
     double *stat_sum, *energy_sum, *nll_sum;  // reduced partial sums (staged / slab path)
     unsigned* dmax;  // [no_steps][C][4] max |d_k| in voxels per axis (float bits), by-product of the forward steps
+    float* cmm;      // coarse (8^3 cells) min / max of d_k for the source boxes of the any-radius adjoint (kernels.h)
     unsigned* hint = nullptr;  // pinned host copy of dmax as of the last finished transition (written by finalize_kernel, read
                      // by the host WITHOUT synchronisation: a hint that only decides which variants are launched)
     DevState* state;
@@ -216,6 +217,14 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
     int cur = 0;
     static unsigned* dmax = nullptr;  // process-wide scratch for the stateless operator: [32 steps][8 chains][4]
     if (!dmax) HIP_TRY(hipMalloc((void**)&dmax, sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32));
+    static float* cmm = nullptr;      // coarse displacement extrema for the any-radius adjoint (kernels.h), grown on demand
+    static size_t cmm_bytes = 0;
+    if (coarse_minmax_bytes(vol, C) > cmm_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (cmm) HIP_TRY(hipFree(cmm));
+        cmm_bytes = coarse_minmax_bytes(vol, C);
+        HIP_TRY(hipMalloc((void**)&cmm, cmm_bytes));
+    }
     if (C > IRS_MAX_CHAINS || no_steps > 32) return fail("irs_svf_exp_bwd: at most %d chains / 32 steps", IRS_MAX_CHAINS);
     const bool lds = use_lds_exp();
     if (lds) HIP_TRY(hipMemsetAsync(dmax, 0, sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32, st));
@@ -226,7 +235,7 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
             launch_field_absmax(dk, k == 0, no_steps, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, C, vol, st);
             const int rad = env_int("IRS_EXP_GATHER", 2);
             if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, false, nullptr, 0, nullptr, st);
-            launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, rad, nullptr, 0, st);
+            launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, rad, nullptr, 0, cmm, st);
         } else {
             HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
             launch_exp_step_bwd(G, dk, out, k == 0, no_steps, C, vol, lin, st);
@@ -515,6 +524,7 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
     const size_t o_nll = take(sizeof(double) * (size_t)c->nll_blocks * C);
     const size_t o_sums = take(sizeof(double) * (kStatVals + 2 * IRS_MAX_CHAINS));
     const size_t o_dmax = take(sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32);
+    const size_t o_cmm = take(coarse_minmax_bytes(c->vol, C));
     const size_t o_state = take(sizeof(DevState));
     c->slab_bytes = off;
     if (hipMalloc((void**)&c->slab, off) != hipSuccess) {
@@ -540,6 +550,7 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
     c->energy_sum = c->stat_sum + kStatVals;
     c->nll_sum = c->energy_sum + IRS_MAX_CHAINS;
     c->dmax = (unsigned*)(c->slab + o_dmax);
+    c->cmm = (float*)(c->slab + o_cmm);
     c->state = (DevState*)(c->slab + o_state);
 
     if (ensure_lin_tables(c->lin, D, H, W, nullptr)) {
@@ -794,7 +805,7 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
                 const int lay = bwd_lay(c, k) | (gscale && aos_enabled() ? 2 : 0);
                 if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, skip_any, gscale, lay,
                                                    timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
-                if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, gscale, lay, st);
+                if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, gscale, lay, c->cmm, st);
             }
             else launch_exp_step_bwd(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, st);
             if (timed && !(lds && env_int("IRS_EXP_GATHER", 2))) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k + 1], st));
@@ -946,7 +957,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
             const float* dk = k == 0 ? vs : c->steps + (int64_t)(k - 1) * field;
             const unsigned* dm = c->dmax + (int64_t)k * C * 4;
             launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, false, nullptr, 0, nullptr, st);
-            launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, 2, nullptr, 0, st);
+            launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, 2, nullptr, 0, c->cmm, st);
             break;
         }
         case IRS_ST_UPDATE: {

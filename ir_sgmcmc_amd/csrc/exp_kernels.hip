@@ -55,7 +55,7 @@ __device__ __forceinline__ void atomic_max_nonneg(unsigned* addr, float v) {
 struct TileGrid {
     int ntx, nty, ntz, total;  // tiles per axis, total over all chains
 };
-constexpr int kExpGridCap = 512;  // also bounds the cost of a variant that is launched but not selected
+constexpr int kExpGridCap = 1024;  // also bounds the cost of a variant that is launched but not selected
 
 template <int H>
 struct ExpBox {
@@ -97,101 +97,176 @@ static dim3 exp_grid(Vol vol, int C, TileGrid* tg) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// adjoint step (owner computes)
+// adjoint step, any displacement (owner computes): a workgroup owns a 32 x 8 x 8 tile of outputs, walks every source voxel
+// that can reach it and scatters the corner contributions into LDS accumulators.
+//
+// Accumulation is FIXED POINT: contributions w * G are scaled by a per-tile power of two, rounded to integers and added
+// with 64-bit LDS atomics.  On gfx950 ds_add_u64 retires ~10 lanes per clock and CU, ds_add_f32 0.4
+// (tools/lds_atomic_probe.hip); with float atomics 60 % of this kernel was the atomic unit.  The scale comes from the
+// largest |G| a source of the tile can carry (coarse grid below), so one contribution uses < 2^30 and 2^33 of them fit;
+// the rounding step is max|G| * 2^-30 per contribution, and integer sums do not depend on the order of the adds: the kernel
+// is deterministic, which the float version was not.
+//
+// Which sources: a source s reaches the tile iff clip(s + d(s)) lies in [lo - 1, hi + 1) per axis, i.e.
+// s in [lo - 1 - max d, hi + 1 - min d] with the extrema over any superset of the sources.  B0 = tile +- (global bound + 1);
+// two rounds over the coarse cells (8^3 voxels: min / max of d per axis, max |G|) covering the current box shrink it to
+// (tile - local displacement range) +- 1: for a smooth 12-voxel field 3x fewer sources than B0.
 // ------------------------------------------------------------------------------------------------
-// one source voxel: scatter its corner contributions that land in the owned tile; for the tile's own voxels also the
-// identity path and the grid-gradient.  d0..d2 is the source's displacement (already read).
+constexpr int kCell = 8, kCmm = 7;  // per cell: min, max of d_x, d_y, d_z (voxels), max |G|
+
+template <bool PRESCALE>
+__global__ __launch_bounds__(kWave) void coarse_minmax_kernel(const float* __restrict__ dk, const float* __restrict__ G,
+                                                              const float* __restrict__ gscale, float* __restrict__ cmm,
+                                                              Vol vol, Scale3L sc, const unsigned* __restrict__ dmax,
+                                                              int gather_radius, int ncx, int ncy, int ncz, int lay) {
+    const int chain = blockIdx.y;
+    {   // leave at once unless this chain needs the any-radius kernel (same test as exp_bwd_lds_kernel)
+        const int h = (int)floorf(fmaxf(fmaxf(__uint_as_float(dmax[chain * 4 + 0]), __uint_as_float(dmax[chain * 4 + 1])), __uint_as_float(dmax[chain * 4 + 2]))) + 1;
+        if (h <= gather_radius) return;
+    }
+    const Lay3 LD = lay3(lay & 1, vol.V), LG = lay3(lay & 2, vol.V);
+    const int cell = blockIdx.x;
+    const int cx = cell % ncx, cy = (cell / ncx) % ncy, cz = cell / (ncx * ncy);
+    const int x = cx * kCell + (int)(threadIdx.x & 7), y = cy * kCell + (int)(threadIdx.x >> 3);
+    const float* c0 = dk + (int64_t)chain * 3 * vol.V;
+    const float* Gc = G + (int64_t)chain * 3 * vol.V;
+    const float* gs_ = gscale ? gscale + (int64_t)chain * vol.V : nullptr;
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, gm = 0.0f;
+    if (x < vol.W && y < vol.H) {
+        for (int z = cz * kCell; z < min(cz * kCell + kCell, vol.D); ++z) {
+            const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
+            const float gsc = gs_ ? gs_[g] : 1.0f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = ldp<PRESCALE>(c0 + a * LD.cs, g * LD.em, sc.nm1[a], sc.rnm1[a], sc.inv_pow) * (0.5f * sc.nm1[a]);
+                mn[a] = fminf(mn[a], v);
+                mx[a] = fmaxf(mx[a], v);
+                gm = fmaxf(gm, fabsf(Gc[a * LG.cs + g * LG.em] * gsc));  // the product the scatter forms
+            }
+        }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], __shfl_down(mn[a], off, kWave));
+            mx[a] = fmaxf(mx[a], __shfl_down(mx[a], off, kWave));
+        }
+        gm = fmaxf(gm, __shfl_down(gm, off, kWave));
+    }
+    if (threadIdx.x == 0) {
+        float* o = cmm + ((int64_t)chain * ncx * ncy * ncz + cell) * kCmm;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            o[2 * a] = mn[a];
+            o[2 * a + 1] = mx[a];
+        }
+        o[6] = gm;
+    }
+}
+
+// corner contributions of one source voxel that land in the owned tile.  d0..d2: the source's displacement (already read)
 template <bool PRESCALE, int H>
-__device__ __forceinline__ void adjoint_source(const int x, const int y, const int z, const float d0, const float d1,
-                                               const float d2, const int ox, const int oy, const int oz,
-                                               const float* __restrict__ Gc, const Lay3 LG, const float* __restrict__ gs_,
-                                               const float* __restrict__ c0, const Lay3 LD, const float* __restrict__ lds,
-                                               float* __restrict__ acc, const Vol vol, const Lin lin, const Scale3L sc) {
-    using B = ExpBox<H>;
+__device__ __forceinline__ void adjoint_scatter(const int x, const int y, const int z, const float d0, const float d1,
+                                                const float d2, const int ox, const int oy, const int oz,
+                                                const float* __restrict__ Gc, const Lay3 LG, const float* __restrict__ gs_,
+                                                unsigned long long* __restrict__ acc, const float scale, const Vol vol,
+                                                const Lin lin) {
     const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
     const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
     const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
     // tile-local corner coordinates; a corner contributes iff it lies inside the owned tile
     const int ax0 = tx.i0 - ox, ax1 = tx.i1 - ox, ay0 = ty.i0 - oy, ay1 = ty.i1 - oy, az0 = tz.i0 - oz, az1 = tz.i1 - oz;
-    const bool self_in = (unsigned)(x - ox) < (unsigned)ETX && (unsigned)(y - oy) < (unsigned)ETY && (unsigned)(z - oz) < (unsigned)ETZ;
-    const bool any = ax1 >= 0 && ax0 < ETX && ay1 >= 0 && ay0 < ETY && az1 >= 0 && az0 < ETZ;
-    if (!any && !self_in) return;
+    if (!(ax1 >= 0 && ax0 < ETX && ay1 >= 0 && ay0 < ETY && az1 >= 0 && az0 < ETZ)) return;
     const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
     const float gsc = gs_ ? gs_[g] : 1.0f;  // optional scalar factor of the incoming gradient (fused backward warp)
     const float G0 = Gc[g * LG.em] * gsc, G1 = Gc[LG.cs + g * LG.em] * gsc, G2 = Gc[2 * LG.cs + g * LG.em] * gsc;
-    if (any) {
-        // per-axis weights with out-of-tile corners zeroed: the scatter becomes 8 unconditional-weight products
-        const float wx0 = (unsigned)ax0 < (unsigned)ETX ? tx.w0 : 0.0f, wx1 = (unsigned)ax1 < (unsigned)ETX ? tx.w1 : 0.0f;
-        const float wy0 = (unsigned)ay0 < (unsigned)ETY ? ty.w0 : 0.0f, wy1 = (unsigned)ay1 < (unsigned)ETY ? ty.w1 : 0.0f;
-        const float wz0 = (unsigned)az0 < (unsigned)ETZ ? tz.w0 : 0.0f, wz1 = (unsigned)az1 < (unsigned)ETZ ? tz.w1 : 0.0f;
-        const int cxa = min(max(ax0, 0), ETX - 1), cxb = min(max(ax1, 0), ETX - 1);
-        const int cya = min(max(ay0, 0), ETY - 1) * ETX, cyb = min(max(ay1, 0), ETY - 1) * ETX;
-        const int cza = min(max(az0, 0), ETZ - 1) * (ETX * ETY), czb = min(max(az1, 0), ETZ - 1) * (ETX * ETY);
+    // per-axis weights with out-of-tile corners zeroed: the scatter becomes 8 unconditional-weight products
+    const float wx0 = (unsigned)ax0 < (unsigned)ETX ? tx.w0 : 0.0f, wx1 = (unsigned)ax1 < (unsigned)ETX ? tx.w1 : 0.0f;
+    const float wy0 = (unsigned)ay0 < (unsigned)ETY ? ty.w0 : 0.0f, wy1 = (unsigned)ay1 < (unsigned)ETY ? ty.w1 : 0.0f;
+    const float wz0 = (unsigned)az0 < (unsigned)ETZ ? tz.w0 : 0.0f, wz1 = (unsigned)az1 < (unsigned)ETZ ? tz.w1 : 0.0f;
+    const int cxa = min(max(ax0, 0), ETX - 1), cxb = min(max(ax1, 0), ETX - 1);
+    const int cya = min(max(ay0, 0), ETY - 1) * ETX, cyb = min(max(ay1, 0), ETY - 1) * ETX;
+    const int cza = min(max(az0, 0), ETZ - 1) * (ETX * ETY), czb = min(max(az1, 0), ETZ - 1) * (ETX * ETY);
+    const float S0 = G0 * scale, S1 = G1 * scale, S2 = G2 * scale;  // |S| < 2^30 (scale is a power of two: exact)
 #pragma unroll
-        for (int cz = 0; cz < 2; ++cz)
+    for (int cz = 0; cz < 2; ++cz)
 #pragma unroll
-            for (int cy = 0; cy < 2; ++cy) {
-                const float wyz = (cy ? wy1 : wy0) * (cz ? wz1 : wz0);
-                if (wyz == 0.0f) continue;
-                const int row = (cz ? czb : cza) + (cy ? cyb : cya);
+        for (int cy = 0; cy < 2; ++cy) {
+            const float wyz = (cy ? wy1 : wy0) * (cz ? wz1 : wz0);
+            if (wyz == 0.0f) continue;
+            const int row = (cz ? czb : cza) + (cy ? cyb : cya);
 #pragma unroll
-                for (int cx = 0; cx < 2; ++cx) {
-                    const float w = (cx ? wx1 : wx0) * wyz;
-                    if (w == 0.0f) continue;
-                    const int t = row + (cx ? cxb : cxa);
-                    atomicAdd(&acc[t], w * G0);
-                    atomicAdd(&acc[ETN + t], w * G1);
-                    atomicAdd(&acc[2 * ETN + t], w * G2);
-                }
+            for (int cx = 0; cx < 2; ++cx) {
+                const float w = (cx ? wx1 : wx0) * wyz;
+                if (w == 0.0f) continue;
+                const int t = row + (cx ? cxb : cxa);
+                atomicAdd(&acc[t], (unsigned long long)(long long)__float2int_rn(w * S0));
+                atomicAdd(&acc[ETN + t], (unsigned long long)(long long)__float2int_rn(w * S1));
+                atomicAdd(&acc[2 * ETN + t], (unsigned long long)(long long)__float2int_rn(w * S2));
             }
-    }
-    if (self_in) {
-        // identity path + grid-gradient; the tap values come from the staged box when the position stays inside it
-        const int bx0 = tx.i0 - (ox - H), bx1 = tx.i1 - (ox - H);
-        const int by0 = ty.i0 - (oy - H), by1 = ty.i1 - (oy - H);
-        const int bz0 = tz.i0 - (oz - H), bz1 = tz.i1 - (oz - H);
-        const bool in_lds = bx0 >= 0 && bx1 < B::SX && by0 >= 0 && by1 < B::SY && bz0 >= 0 && bz1 < B::SZ;
-        float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+        }
+}
+
+// identity path + grid-gradient of an own voxel; the tap values come from the staged box when the position stays inside it
+template <bool PRESCALE, int H>
+__device__ __forceinline__ void adjoint_self(const int x, const int y, const int z, const float d0, const float d1, const float d2,
+                                             const int ox, const int oy, const int oz, const float* __restrict__ Gc, const Lay3 LG,
+                                             const float* __restrict__ gs_, const float* __restrict__ c0, const Lay3 LD,
+                                             const float* __restrict__ lds, const Vol vol, const Lin lin, const Scale3L sc,
+                                             float (&out)[3]) {
+    using B = ExpBox<H>;
+    const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
+    const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
+    const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
+    const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
+    const float gsc = gs_ ? gs_[g] : 1.0f;
+    const float G0 = Gc[g * LG.em] * gsc, G1 = Gc[LG.cs + g * LG.em] * gsc, G2 = Gc[2 * LG.cs + g * LG.em] * gsc;
+    const int bx0 = tx.i0 - (ox - H), bx1 = tx.i1 - (ox - H);
+    const int by0 = ty.i0 - (oy - H), by1 = ty.i1 - (oy - H);
+    const int bz0 = tz.i0 - (oz - H), bz1 = tz.i1 - (oz - H);
+    const bool in_lds = bx0 >= 0 && bx1 < B::SX && by0 >= 0 && by1 < B::SY && bz0 >= 0 && bz1 < B::SZ;
+    float gix = 0.0f, giy = 0.0f, giz = 0.0f;
 #pragma unroll
-        for (int cz = 0; cz < 2; ++cz)
+    for (int cz = 0; cz < 2; ++cz)
 #pragma unroll
-            for (int cy = 0; cy < 2; ++cy)
+        for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-                for (int cx = 0; cx < 2; ++cx) {
-                    float v0, v1, v2;
-                    if (in_lds) {
-                        const int idx = ((cz ? bz1 : bz0) * B::SY + (cy ? by1 : by0)) * B::SX + (cx ? bx1 : bx0);
-                        v0 = lds[idx];
-                        v1 = lds[B::SN + idx];
-                        v2 = lds[2 * B::SN + idx];
-                    } else {
-                        const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
-                        v0 = ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
-                        v1 = ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
-                        v2 = ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
-                    }
-                    const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
-                    const float dot = v0 * G0 + v1 * G1 + v2 * G2;
-                    gix += (cx ? dot : -dot) * (wy * wz);
-                    giy += (cy ? dot : -dot) * (wx * wz);
-                    giz += (cz ? dot : -dot) * (wx * wy);
+            for (int cx = 0; cx < 2; ++cx) {
+                float v0, v1, v2;
+                if (in_lds) {
+                    const int idx = ((cz ? bz1 : bz0) * B::SY + (cy ? by1 : by0)) * B::SX + (cx ? bx1 : bx0);
+                    v0 = lds[idx];
+                    v1 = lds[B::SN + idx];
+                    v2 = lds[2 * B::SN + idx];
+                } else {
+                    const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
+                    v0 = ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
+                    v1 = ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
+                    v2 = ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
                 }
-        const int t = ((z - oz) * ETY + (y - oy)) * ETX + (x - ox);
-        atomicAdd(&acc[t], G0 + tx.gmul * gix);
-        atomicAdd(&acc[ETN + t], G1 + ty.gmul * giy);
-        atomicAdd(&acc[2 * ETN + t], G2 + tz.gmul * giz);
-    }
+                const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
+                const float dot = v0 * G0 + v1 * G1 + v2 * G2;
+                gix += (cx ? dot : -dot) * (wy * wz);
+                giy += (cy ? dot : -dot) * (wx * wz);
+                giz += (cz ? dot : -dot) * (wx * wy);
+            }
+    out[0] = G0 + tx.gmul * gix;
+    out[1] = G1 + ty.gmul * giy;
+    out[2] = G2 + tz.gmul * giz;
 }
 
 template <bool PRESCALE, int H>
 __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __restrict__ G, const float* __restrict__ dk,
                                                                 float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
                                                                 const unsigned* __restrict__ dmax, TileGrid tg,
-                                                                int gather_radius, const float* __restrict__ gscale, int lay) {
+                                                                int gather_radius, const float* __restrict__ gscale, int lay,
+                                                                const float* __restrict__ cmm) {
     using B = ExpBox<H>;
     const Lay3 LD = lay3(lay & 1, vol.V), LG = lay3(lay & 2, vol.V), LO = lay3(lay & 4, vol.V);
     __shared__ float lds[3 * B::SN];
-    __shared__ float acc[3 * ETN];
+    __shared__ unsigned long long acc[3 * ETN];
+    __shared__ float bred[kCmm * (kExpBlock / kWave)];
     {   // nothing to do for any chain (the usual case): leave before walking the tile list
         const int chains = tg.total / (tg.ntx * tg.nty * tg.ntz);
         bool any = false;
@@ -207,11 +282,11 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
     t_ /= tg.nty;
     const int oz = vol.z0 + (t_ % tg.ntz) * ETZ;
     const int chain = t_ / tg.ntz;
-    {   // the gather kernel owns this launch when every source halo fits its radius
-        const int h0 = (int)floorf(__uint_as_float(dmax[chain * 4 + 0])) + 1, h1 = (int)floorf(__uint_as_float(dmax[chain * 4 + 1])) + 1,
-                  h2 = (int)floorf(__uint_as_float(dmax[chain * 4 + 2])) + 1;
-        if (h0 <= gather_radius && h1 <= gather_radius && h2 <= gather_radius) continue;
-    }
+    // source halo: a voxel at distance h from the tile can reach it iff h <= floor(max|d|) + 1 (corner = floor(x+d) + {0,1})
+    const int hx = (int)floorf(__uint_as_float(dmax[chain * 4 + 0])) + 1;
+    const int hy = (int)floorf(__uint_as_float(dmax[chain * 4 + 1])) + 1;
+    const int hz = (int)floorf(__uint_as_float(dmax[chain * 4 + 2])) + 1;
+    if (hx <= gather_radius && hy <= gather_radius && hz <= gather_radius) continue;  // a gather kernel owns this chain
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
     const float* c0 = dk + cb;
@@ -219,73 +294,153 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
     const float* gsc_ = gscale ? gscale + (int64_t)chain * V : nullptr;
 
     stage_field<PRESCALE, H>(c0, LD, lds, ox, oy, oz, vol, sc);
-    for (int i = threadIdx.x; i < 3 * ETN; i += kExpBlock) acc[i] = 0.0f;
+    for (int i = threadIdx.x; i < 3 * ETN; i += kExpBlock) acc[i] = 0ull;
 
-    // source halo: a voxel at distance h from the tile can reach it iff h <= floor(max|d|) + 1 (corner = floor(x+d) + {0,1})
-    const int hx = (int)floorf(__uint_as_float(dmax[chain * 4 + 0])) + 1;
-    const int hy = (int)floorf(__uint_as_float(dmax[chain * 4 + 1])) + 1;
-    const int hz = (int)floorf(__uint_as_float(dmax[chain * 4 + 2])) + 1;
-    __syncthreads();
-
-    if (hx <= H && hy <= H && hz <= H) {
-        // fast path: every source sits in the staged box (compile-time extents, displacement straight from LDS)
-        for (int i = threadIdx.x; i < B::SN; i += kExpBlock) {
-            const int lx = i % B::SX, ly = (i / B::SX) % B::SY, lz = i / (B::SX * B::SY);
-            const int x = ox - H + lx, y = oy - H + ly, z = oz - H + lz;
-            if ((unsigned)x >= (unsigned)vol.W || (unsigned)y >= (unsigned)vol.H || (unsigned)z >= (unsigned)vol.D) continue;
-            adjoint_source<PRESCALE, H>(x, y, z, lds[i], lds[B::SN + i], lds[2 * B::SN + i], ox, oy, oz, Gc, LG, gsc_, c0, LD, lds, acc,
-                                        vol, lin, sc);
-        }
-    } else {
-        // general path: run-time source box, displacements from global memory outside the staged box
-        const int sx0 = max(ox - hx, 0), sx1 = min(ox + ETX - 1 + hx, vol.W - 1);
-        const int sy0 = max(oy - hy, 0), sy1 = min(oy + ETY - 1 + hy, vol.H - 1);
-        const int sz0 = max(oz - hz, 0), sz1 = min(oz + ETZ - 1 + hz, vol.D - 1);
-        const int ex = sx1 - sx0 + 1, ey = sy1 - sy0 + 1, ez = sz1 - sz0 + 1;
-        const int nS = ex * ey * ez;
-        for (int i = threadIdx.x; i < nS; i += kExpBlock) {
-            const int x = sx0 + i % ex, y = sy0 + (i / ex) % ey, z = sz0 + i / (ex * ey);
-            const int bx = x - (ox - H), by = y - (oy - H), bz = z - (oz - H);
-            float d0, d1, d2;
-            if ((unsigned)bx < (unsigned)B::SX && (unsigned)by < (unsigned)B::SY && (unsigned)bz < (unsigned)B::SZ) {
-                const int ctr = (bz * B::SY + by) * B::SX + bx;
-                d0 = lds[ctr];
-                d1 = lds[B::SN + ctr];
-                d2 = lds[2 * B::SN + ctr];
-            } else {
-                const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-                d0 = ldp<PRESCALE>(c0, g * LD.em, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
-                d1 = ldp<PRESCALE>(c0 + LD.cs, g * LD.em, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
-                d2 = ldp<PRESCALE>(c0 + 2 * LD.cs, g * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
+    // ---- source box and the largest |G| inside it
+    int lo[3] = {max(ox - hx, 0), max(oy - hy, 0), max(oz - hz, 0)};
+    int hi[3] = {min(ox + ETX - 1 + hx, vol.W - 1), min(oy + ETY - 1 + hy, vol.H - 1), min(oz + ETZ - 1 + hz, vol.D - 1)};
+    float gmax = 0.0f;
+    auto block_reduce7 = [&](float (&m7)[kCmm]) {  // min over even slots < 6, max over the others; result in every thread
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1)
+#pragma unroll
+            for (int j = 0; j < kCmm; ++j) {
+                const float o = __shfl_down(m7[j], off, kWave);
+                m7[j] = (j < 6 && !(j & 1)) ? fminf(m7[j], o) : fmaxf(m7[j], o);
             }
-            adjoint_source<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, Gc, LG, gsc_, c0, LD, lds, acc, vol, lin, sc);
+        if ((threadIdx.x & (kWave - 1)) == 0)
+#pragma unroll
+            for (int j = 0; j < kCmm; ++j) bred[j * (kExpBlock / kWave) + threadIdx.x / kWave] = m7[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kCmm; ++j) {
+            float r = bred[j * (kExpBlock / kWave)];
+            for (int w = 1; w < kExpBlock / kWave; ++w) {
+                const float o = bred[j * (kExpBlock / kWave) + w];
+                r = (j < 6 && !(j & 1)) ? fminf(r, o) : fmaxf(r, o);
+            }
+            m7[j] = r;
+        }
+        __syncthreads();  // bred is reused
+    };
+    if (cmm) {
+        const int nax[3] = {vol.W, vol.H, vol.D};
+        const int tlo[3] = {ox, oy, oz};
+        const int thi[3] = {min(ox + ETX, vol.W) - 1, min(oy + ETY, vol.H) - 1, min(oz + ETZ, vol.D) - 1};
+        const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.D + kCell - 1) / kCell;
+        const float* __restrict__ cm = cmm + (int64_t)chain * ncx * ncy * ncz * kCmm;
+        for (int round = 0; round < 3; ++round) {  // the third round only collects max |G| over the final box
+            const int c0x = lo[0] / kCell, c0y = lo[1] / kCell, c0z = lo[2] / kCell;
+            const int nx_ = hi[0] / kCell - c0x + 1, ny_ = hi[1] / kCell - c0y + 1, nz_ = hi[2] / kCell - c0z + 1;
+            float m7[kCmm] = {3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 0.0f};
+            for (int i = threadIdx.x; i < nx_ * ny_ * nz_; i += kExpBlock) {
+                const int cell = ((c0z + i / (nx_ * ny_)) * ncy + c0y + (i / nx_) % ny_) * ncx + c0x + i % nx_;
+#pragma unroll
+                for (int j = 0; j < kCmm; ++j) {
+                    const float o = cm[cell * kCmm + j];
+                    m7[j] = (j < 6 && !(j & 1)) ? fminf(m7[j], o) : fmaxf(m7[j], o);
+                }
+            }
+            block_reduce7(m7);
+            gmax = m7[6];
+            if (round == 2) break;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float mn = m7[2 * a], mx = m7[2 * a + 1];
+                if (!(mn <= mx) || fabsf(mn) > 1.0e6f || fabsf(mx) > 1.0e6f) continue;  // no usable extrema: keep the box
+                // on a tile that touches the volume border the clip folds arbitrarily distant positions onto it: that side
+                // keeps B0's extent.  1e-3: the cell extrema are v (n-1)/2, the positions ((g + 1) / 2) (n-1) -- other rounding
+                if (tlo[a] - 1 > 0) lo[a] = max(lo[a], (int)floorf((float)(tlo[a] - 1) - mx - 1e-3f));
+                if (thi[a] + 1 < nax[a] - 1) hi[a] = min(hi[a], (int)ceilf((float)(thi[a] + 1) - mn + 1e-3f));
+            }
+        }
+    } else {  // no coarse grid (IRS_COARSE_BOX=0, parity runs): B0 and a pass over its sources for max |G|
+        float m7[kCmm] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        const int ex0 = hi[0] - lo[0] + 1, ey0 = hi[1] - lo[1] + 1, ez0 = hi[2] - lo[2] + 1;
+        for (int i = threadIdx.x; i < ex0 * ey0 * ez0; i += kExpBlock) {
+            const int64_t g = ((int64_t)(lo[2] + i / (ex0 * ey0)) * vol.H + lo[1] + (i / ex0) % ey0) * vol.W + lo[0] + i % ex0;
+            const float gsc = gsc_ ? gsc_[g] : 1.0f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) m7[6] = fmaxf(m7[6], fabsf(Gc[a * LG.cs + g * LG.em] * gsc));
+        }
+        block_reduce7(m7);
+        gmax = m7[6];
+    }
+    // per-tile power-of-two scale: gmax = m 2^e with m in [0.5, 1) -> |w G scale| < 2^30 for every contribution
+    int e2 = 0;
+    if (gmax > 0.0f) (void)frexpf(gmax, &e2);
+    const bool usable = gmax > 0.0f && gmax < 3.0e38f;
+    const float scale = usable ? ldexpf(1.0f, 30 - e2) : 0.0f, inv_scale = usable ? ldexpf(1.0f, e2 - 30) : 0.0f;
+    __syncthreads();  // acc zeroed, lds staged
+
+    auto disp_at = [&](int x, int y, int z, float& d0, float& d1, float& d2) {
+        const int bx = x - (ox - H), by = y - (oy - H), bz = z - (oz - H);
+        if ((unsigned)bx < (unsigned)B::SX && (unsigned)by < (unsigned)B::SY && (unsigned)bz < (unsigned)B::SZ) {
+            const int ctr = (bz * B::SY + by) * B::SX + bx;
+            d0 = lds[ctr];
+            d1 = lds[B::SN + ctr];
+            d2 = lds[2 * B::SN + ctr];
+        } else {
+            const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
+            d0 = ldp<PRESCALE>(c0, g * LD.em, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
+            d1 = ldp<PRESCALE>(c0 + LD.cs, g * LD.em, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
+            d2 = ldp<PRESCALE>(c0 + 2 * LD.cs, g * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
+        }
+    };
+    // ---- scatter: one wavefront per (y, z) row of the box, lanes along x (row coordinates are wave-uniform)
+    const int ey = max(hi[1] - lo[1] + 1, 0), ez = max(hi[2] - lo[2] + 1, 0);
+    for (int row = threadIdx.x / kWave; row < ey * ez; row += kExpBlock / kWave) {
+        const int y = lo[1] + row % ey, z = lo[2] + row / ey;
+        for (int x = lo[0] + (int)(threadIdx.x & (kWave - 1)); x <= hi[0]; x += kWave) {
+            float d0, d1, d2;
+            disp_at(x, y, z, d0, d1, d2);
+            adjoint_scatter<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, Gc, LG, gsc_, acc, scale, vol, lin);
         }
     }
     __syncthreads();
+    // ---- own voxels: identity path + grid-gradient (no atomics: one thread per output) + the scattered sum
     float* o = gout + cb;
     for (int i = threadIdx.x; i < ETN; i += kExpBlock) {
         const int lx = i % ETX, ly = (i / ETX) % ETY, lz = i / (ETX * ETY);
         const int x = ox + lx, y = oy + ly, z = oz + lz;
         if (x >= vol.W || y >= vol.H || z >= vol.z0 + vol.nz) continue;
+        float d0, d1, d2, self[3];
+        disp_at(x, y, z, d0, d1, d2);
+        adjoint_self<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, Gc, LG, gsc_, c0, LD, lds, vol, lin, sc, self);
         const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-        o[g * LO.em] = acc[i];
-        o[LO.cs + g * LO.em] = acc[ETN + i];
-        o[2 * LO.cs + g * LO.em] = acc[2 * ETN + i];
+        o[g * LO.em] = self[0] + (float)(long long)acc[i] * inv_scale;
+        o[LO.cs + g * LO.em] = self[1] + (float)(long long)acc[ETN + i] * inv_scale;
+        o[2 * LO.cs + g * LO.em] = self[2] + (float)(long long)acc[2 * ETN + i] * inv_scale;
     }
     __syncthreads();
   }
 }
 
+size_t coarse_minmax_bytes(Vol vol, int C) {
+    return sizeof(float) * kCmm * (size_t)C * ((vol.W + kCell - 1) / kCell) * ((vol.H + kCell - 1) / kCell) * ((vol.D + kCell - 1) / kCell);
+}
+
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
-                             Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, int lay, hipStream_t st) {
+                             Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, int lay,
+                             float* cmm, hipStream_t st) {
     TileGrid tz;
     const dim3 grid = exp_grid(vol, C, &tz);
     const Scale3L sc = make_scale_l(vol, no_steps);
-#define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay)
+    if (getenv("IRS_COARSE_BOX") && atoi(getenv("IRS_COARSE_BOX")) == 0) cmm = nullptr;  // parity test of the two source boxes
+    if (cmm) {  // coarse displacement extrema / gradient maxima (coarse_minmax_bytes(vol, C) of scratch)
+        const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.D + kCell - 1) / kCell;
+        const dim3 cg((unsigned)(ncx * ncy * ncz), (unsigned)C);
+        if (prescale_in) hipLaunchKernelGGL((coarse_minmax_kernel<true>), cg, dim3(kWave), 0, st, dk, G, gscale, cmm, vol, sc, dmax, gather_radius, ncx, ncy, ncz, lay);
+        else hipLaunchKernelGGL((coarse_minmax_kernel<false>), cg, dim3(kWave), 0, st, dk, G, gscale, cmm, vol, sc, dmax, gather_radius, ncx, ncy, ncz, lay);
+    }
+#define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay, cmm)
+    // With the gather variants in front (gather_radius >= 2) the staged box of d around the tile is of little use (sources
+    // and taps are far away): H = 0 stages the tile alone (74 KB instead of 111 KB of LDS -> two workgroups per CU)
+    if (gather_radius >= 2) halo = 0;
     if (prescale_in) {
-        if (halo <= 1) IRS_BWD(true, 1); else IRS_BWD(true, 2);
+        if (halo <= 0) IRS_BWD(true, 0); else if (halo <= 1) IRS_BWD(true, 1); else IRS_BWD(true, 2);
     } else {
-        if (halo <= 1) IRS_BWD(false, 1); else IRS_BWD(false, 2);
+        if (halo <= 0) IRS_BWD(false, 0); else if (halo <= 1) IRS_BWD(false, 1); else IRS_BWD(false, 2);
     }
 #undef IRS_BWD
 }

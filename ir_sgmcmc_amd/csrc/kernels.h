@@ -59,8 +59,12 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale, int
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
                                hipEvent_t after_primary, hipStream_t st);
+// cmm: scratch of coarse_minmax_bytes(vol, C) for the per-cell displacement extrema (nullptr: sources are bounded by the
+// global bound around the tile only -- correct, slow for large displacements)
+size_t coarse_minmax_bytes(Vol vol, int C);
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
-                             Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, int lay, hipStream_t st);
+                             Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, int lay,
+                             float* cmm, hipStream_t st);
 void launch_field_absmax(const float* d, bool prescale, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st);
 
 // ---- data_kernels.hip

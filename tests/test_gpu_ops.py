@@ -106,6 +106,29 @@ def test_svf_exp_backward(dims, amp, upstream):
     assert maxdiff(gv, gv_ref) < tol * float(gv_ref.abs().max())
 
 
+def test_svf_exp_backward_large_smooth_displacement(monkeypatch):
+    """8-voxel smooth field on several tiles: the last adjoint steps run in the any-radius kernel, whose source boxes are
+    shrunk with the coarse displacement extrema.  Same result with the plain boxes (LDS float atomics: summation order only),
+    with the plain global-atomic kernels, and -- except at the few voxels whose sampling position sits within rounding of a
+    cell boundary, where the CPU and the GPU forward pass pick different cells -- with autograd through the oracle."""
+    dims, amp = (40, 36, 44), 9.0
+    v = smooth_field(1, dims, amp, 2).requires_grad_(True)
+    g_last = smooth_field(1, dims, 1.0, 33)
+    _, _, steps_ref = O.svf_exp(v, 12, keep_steps=True)
+    gv_ref, = torch.autograd.grad(steps_ref[-1], v, g_last)
+    assert float(steps_ref[-2].abs().max()) * 0.5 * (min(dims) - 1) > 2.0   # d_11 beyond the radius-2 gather
+    _, _, steps = G.svf_exp_fwd(dev(v.detach()), 12, want_outputs=False)
+    gv = G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last))
+    scale = float(gv_ref.abs().max())
+    monkeypatch.setenv('IRS_COARSE_BOX', '0')
+    assert maxdiff(gv, G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last))) < 2e-6 * scale
+    monkeypatch.delenv('IRS_COARSE_BOX')
+    monkeypatch.setenv('IRS_EXP_LDS', '0')
+    assert maxdiff(gv, G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last))) < 2e-6 * scale
+    bad = ((gv.cpu() - gv_ref).abs() > GRAD_RTOL * scale).sum()
+    assert int(bad) <= 1e-3 * gv_ref.numel()
+
+
 @pytest.mark.parametrize('N,cps', [(16, 4), (16, 2), (17, 4), (20, 3)])
 def test_ffd_up_and_adjoint(N, cps):
     dims, c = (N,) * 3, (cps,) * 3
