@@ -125,37 +125,41 @@ __global__ __launch_bounds__(kWave) void coarse_minmax_kernel(const float* __res
         if (h <= gather_radius) return;
     }
     const Lay3 LD = lay3(lay & 1, vol.V), LG = lay3(lay & 2, vol.V);
-    const int cell = blockIdx.x;
-    const int cx = cell % ncx, cy = (cell / ncx) % ncy, cz = cell / (ncx * ncy);
-    const int x = cx * kCell + (int)(threadIdx.x & 7), y = cy * kCell + (int)(threadIdx.x >> 3);
+    // one wavefront per run of 8 cells along x: lane = x offset, 64 (y, z) iterations of fully coalesced row loads, then a
+    // reduction over each group of 8 lanes
+    const int nrx = (ncx + 7) / 8;
+    const int run = blockIdx.x % nrx, cy = (blockIdx.x / nrx) % ncy, cz = blockIdx.x / (nrx * ncy);
+    const int x = run * 64 + (int)threadIdx.x;
     const float* c0 = dk + (int64_t)chain * 3 * vol.V;
     const float* Gc = G + (int64_t)chain * 3 * vol.V;
     const float* gs_ = gscale ? gscale + (int64_t)chain * vol.V : nullptr;
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, gm = 0.0f;
-    if (x < vol.W && y < vol.H) {
-        for (int z = cz * kCell; z < min(cz * kCell + kCell, vol.D); ++z) {
-            const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-            const float gsc = gs_ ? gs_[g] : 1.0f;
+    if (x < vol.W) {
+        for (int z = cz * kCell; z < min(cz * kCell + kCell, vol.D); ++z)
+            for (int y = cy * kCell; y < min(cy * kCell + kCell, vol.H); ++y) {
+                const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
+                const float gsc = gs_ ? gs_[g] : 1.0f;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float v = ldp<PRESCALE>(c0 + a * LD.cs, g * LD.em, sc.nm1[a], sc.rnm1[a], sc.inv_pow) * (0.5f * sc.nm1[a]);
-                mn[a] = fminf(mn[a], v);
-                mx[a] = fmaxf(mx[a], v);
-                gm = fmaxf(gm, fabsf(Gc[a * LG.cs + g * LG.em] * gsc));  // the product the scatter forms
+                for (int a = 0; a < 3; ++a) {
+                    const float v = ldp<PRESCALE>(c0 + a * LD.cs, g * LD.em, sc.nm1[a], sc.rnm1[a], sc.inv_pow) * (0.5f * sc.nm1[a]);
+                    mn[a] = fminf(mn[a], v);
+                    mx[a] = fmaxf(mx[a], v);
+                    gm = fmaxf(gm, fabsf(Gc[a * LG.cs + g * LG.em] * gsc));  // the product the scatter forms
+                }
             }
-        }
     }
 #pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
+    for (int off = 1; off < kCell; off <<= 1) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            mn[a] = fminf(mn[a], __shfl_down(mn[a], off, kWave));
-            mx[a] = fmaxf(mx[a], __shfl_down(mx[a], off, kWave));
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, kWave));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, kWave));
         }
-        gm = fmaxf(gm, __shfl_down(gm, off, kWave));
+        gm = fmaxf(gm, __shfl_xor(gm, off, kWave));
     }
-    if (threadIdx.x == 0) {
-        float* o = cmm + ((int64_t)chain * ncx * ncy * ncz + cell) * kCmm;
+    const int cx = run * 8 + (int)(threadIdx.x >> 3);
+    if ((threadIdx.x & 7) == 0 && cx < ncx) {
+        float* o = cmm + ((int64_t)chain * ncx * ncy * ncz + ((int64_t)cz * ncy + cy) * ncx + cx) * kCmm;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             o[2 * a] = mn[a];
@@ -429,7 +433,7 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
     if (getenv("IRS_COARSE_BOX") && atoi(getenv("IRS_COARSE_BOX")) == 0) cmm = nullptr;  // parity test of the two source boxes
     if (cmm) {  // coarse displacement extrema / gradient maxima (coarse_minmax_bytes(vol, C) of scratch)
         const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.D + kCell - 1) / kCell;
-        const dim3 cg((unsigned)(ncx * ncy * ncz), (unsigned)C);
+        const dim3 cg((unsigned)(((ncx + 7) / 8) * ncy * ncz), (unsigned)C);
         if (prescale_in) hipLaunchKernelGGL((coarse_minmax_kernel<true>), cg, dim3(kWave), 0, st, dk, G, gscale, cmm, vol, sc, dmax, gather_radius, ncx, ncy, ncz, lay);
         else hipLaunchKernelGGL((coarse_minmax_kernel<false>), cg, dim3(kWave), 0, st, dk, G, gscale, cmm, vol, sc, dmax, gather_radius, ncx, ncy, ncz, lay);
     }
