@@ -119,6 +119,7 @@ def test_svf_exp_backward_large_smooth_displacement(monkeypatch):
     assert float(steps_ref[-2].abs().max()) * 0.5 * (min(dims) - 1) > 2.0   # d_11 beyond the radius-2 gather
     _, _, steps = G.svf_exp_fwd(dev(v.detach()), 12, want_outputs=False)
     gv = G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last))
+    assert torch.equal(gv, G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last)))   # integer accumulation: order-independent
     scale = float(gv_ref.abs().max())
     monkeypatch.setenv('IRS_COARSE_BOX', '0')
     assert maxdiff(gv, G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last))) < 2e-6 * scale
