@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kWave) void coarse_minmax_kernel(const float* __res
 template <bool PRESCALE, int H>
 __device__ __forceinline__ void adjoint_scatter(const int x, const int y, const int z, const float d0, const float d1,
                                                 const float d2, const int ox, const int oy, const int oz,
-                                                const float* __restrict__ Gc, const Lay3 LG, const float* __restrict__ gs_,
+                                                const float G0, const float G1, const float G2,
                                                 unsigned long long* __restrict__ acc, const float scale, const Vol vol,
                                                 const Lin lin) {
     const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
@@ -182,9 +182,6 @@ __device__ __forceinline__ void adjoint_scatter(const int x, const int y, const 
     // tile-local corner coordinates; a corner contributes iff it lies inside the owned tile
     const int ax0 = tx.i0 - ox, ax1 = tx.i1 - ox, ay0 = ty.i0 - oy, ay1 = ty.i1 - oy, az0 = tz.i0 - oz, az1 = tz.i1 - oz;
     if (!(ax1 >= 0 && ax0 < ETX && ay1 >= 0 && ay0 < ETY && az1 >= 0 && az0 < ETZ)) return;
-    const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-    const float gsc = gs_ ? gs_[g] : 1.0f;  // optional scalar factor of the incoming gradient (fused backward warp)
-    const float G0 = Gc[g * LG.em] * gsc, G1 = Gc[LG.cs + g * LG.em] * gsc, G2 = Gc[2 * LG.cs + g * LG.em] * gsc;
     // per-axis weights with out-of-tile corners zeroed: the scatter becomes 8 unconditional-weight products
     const float wx0 = (unsigned)ax0 < (unsigned)ETX ? tx.w0 : 0.0f, wx1 = (unsigned)ax1 < (unsigned)ETX ? tx.w1 : 0.0f;
     const float wy0 = (unsigned)ay0 < (unsigned)ETY ? ty.w0 : 0.0f, wy1 = (unsigned)ay1 < (unsigned)ETY ? ty.w1 : 0.0f;
@@ -229,7 +226,7 @@ __device__ __forceinline__ void adjoint_self(const int x, const int y, const int
     const int bx0 = tx.i0 - (ox - H), bx1 = tx.i1 - (ox - H);
     const int by0 = ty.i0 - (oy - H), by1 = ty.i1 - (oy - H);
     const int bz0 = tz.i0 - (oz - H), bz1 = tz.i1 - (oz - H);
-    const bool in_lds = bx0 >= 0 && bx1 < B::SX && by0 >= 0 && by1 < B::SY && bz0 >= 0 && bz1 < B::SZ;
+    const bool in_lds = H > 0 && bx0 >= 0 && bx1 < B::SX && by0 >= 0 && by1 < B::SY && bz0 >= 0 && bz1 < B::SZ;
     float gix = 0.0f, giy = 0.0f, giz = 0.0f;
 #pragma unroll
     for (int cz = 0; cz < 2; ++cz)
@@ -268,7 +265,8 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
                                                                 const float* __restrict__ cmm) {
     using B = ExpBox<H>;
     const Lay3 LD = lay3(lay & 1, vol.V), LG = lay3(lay & 2, vol.V), LO = lay3(lay & 4, vol.V);
-    __shared__ float lds[3 * B::SN];
+    constexpr bool STAGED = H > 0;  // H = 0: no staged copy of d at all (sources and taps are far from the tile anyway)
+    __shared__ float lds[STAGED ? 3 * B::SN : 1];
     __shared__ unsigned long long acc[3 * ETN];
     __shared__ float bred[kCmm * (kExpBlock / kWave)];
     {   // nothing to do for any chain (the usual case): leave before walking the tile list
@@ -297,7 +295,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
     const float* Gc = G + cb;
     const float* gsc_ = gscale ? gscale + (int64_t)chain * V : nullptr;
 
-    stage_field<PRESCALE, H>(c0, LD, lds, ox, oy, oz, vol, sc);
+    if (STAGED) stage_field<PRESCALE, H>(c0, LD, lds, ox, oy, oz, vol, sc);
     for (int i = threadIdx.x; i < 3 * ETN; i += kExpBlock) acc[i] = 0ull;
 
     // ---- source box and the largest |G| inside it
@@ -379,7 +377,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
 
     auto disp_at = [&](int x, int y, int z, float& d0, float& d1, float& d2) {
         const int bx = x - (ox - H), by = y - (oy - H), bz = z - (oz - H);
-        if ((unsigned)bx < (unsigned)B::SX && (unsigned)by < (unsigned)B::SY && (unsigned)bz < (unsigned)B::SZ) {
+        if (STAGED && (unsigned)bx < (unsigned)B::SX && (unsigned)by < (unsigned)B::SY && (unsigned)bz < (unsigned)B::SZ) {
             const int ctr = (bz * B::SY + by) * B::SX + bx;
             d0 = lds[ctr];
             d1 = lds[B::SN + ctr];
@@ -396,9 +394,14 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
     for (int row = threadIdx.x / kWave; row < ey * ez; row += kExpBlock / kWave) {
         const int y = lo[1] + row % ey, z = lo[2] + row / ey;
         for (int x = lo[0] + (int)(threadIdx.x & (kWave - 1)); x <= hi[0]; x += kWave) {
+            // d and G in one round trip (G unconditionally: about half of the box contributes, and a second dependent
+            // load per row is what this latency-bound loop cannot afford)
             float d0, d1, d2;
             disp_at(x, y, z, d0, d1, d2);
-            adjoint_scatter<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, Gc, LG, gsc_, acc, scale, vol, lin);
+            const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
+            const float gsc = gsc_ ? gsc_[g] : 1.0f;  // optional scalar factor of the incoming gradient (fused backward warp)
+            const float G0 = Gc[g * LG.em] * gsc, G1 = Gc[LG.cs + g * LG.em] * gsc, G2 = Gc[2 * LG.cs + g * LG.em] * gsc;
+            adjoint_scatter<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, G0, G1, G2, acc, scale, vol, lin);
         }
     }
     __syncthreads();
@@ -439,7 +442,7 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
     }
 #define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay, cmm)
     // With the gather variants in front (gather_radius >= 2) the staged box of d around the tile is of little use (sources
-    // and taps are far away): H = 0 stages the tile alone (74 KB instead of 111 KB of LDS -> two workgroups per CU)
+    // and taps are far away): H = 0 stages nothing (49 KB of accumulators instead of 111 KB of LDS -> three workgroups per CU)
     if (gather_radius >= 2) halo = 0;
     if (prescale_in) {
         if (halo <= 0) IRS_BWD(true, 0); else if (halo <= 1) IRS_BWD(true, 1); else IRS_BWD(true, 2);
