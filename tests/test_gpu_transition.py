@@ -156,6 +156,53 @@ def test_transition_matches_oracle_builder_variants(variant):
         v.copy_(o['v_new'].to(DEV))
 
 
+def test_transition_matches_oracle_at_128_cubed():
+    """BASELINE.json configs 2 / 3 size (128^3, GMM / LCC s = 1, virtual decimation, Sobolev, jitter): one transition of the
+    HIP path against the CPU oracle on the same injected noise, at the north-star tolerances (loss terms 1e-5 relative,
+    displacement 1e-4 voxels).  The oracle needs ~10 s of host time at this size."""
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    N = 128
+    oc = OracleConfig(dims=(N, N, N))
+    f1, m1 = synthetic_pair((N, N, N), seed=0)
+    fixed = {k: v.unsqueeze(0).contiguous() for k, v in f1.items() if k != 'seg'}
+    moving = {k: v.unsqueeze(0).contiguous() for k, v in m1.items() if k != 'seg'}
+    gen = torch.Generator().manual_seed(21)
+    from oracle import ops as O
+    # a smooth 3-voxel velocity field (low-resolution noise, upsampled): a rough field that folds the grid amplifies the
+    # rounding differences of the twelve compositions beyond any fixed tolerance (see test_svf_exp_forward, amp = 25)
+    lo = torch.randn(1, 3, N // 8, N // 8, N // 8, generator=gen)
+    v0 = torch.nn.functional.interpolate(lo, size=(N, N, N), mode='trilinear', align_corners=True)
+    v0 = (v0 * (3.0 / float(v0.abs().max()))).contiguous()
+    orc = OracleChain(oc, v0=v0)
+    orc.init_gmm(fixed, moving)
+    cfg = engine_config(oc)
+    eng = TransitionEngine(cfg, DEV)
+    fixed_d, moving_d = eng.prepare(to_dev(fixed), to_dev(moving))
+    eng.gmm_init(fixed_d, moving_d)
+    v = v0.to(DEV).contiguous()
+    out = outputs_for(cfg)
+    eps = torch.randn(1, 3, N, N, N, generator=gen)
+    unif = torch.rand(1, 3, N, N, N, generator=gen) if oc.uniform_noise is not None else None
+    o = orc.transition(fixed, moving, eps, unif)
+    eng.transition(fixed_d, moving_d, v, None, eps.to(DEV), unif.to(DEV) if unif is not None else None, out)
+    sc = eng.scalars()
+    T = 'oracle/128^3'
+    assert float(o['displacement'].abs().max()) > 1.0   # not a trivial field
+    check(T, 'alpha', sc['alpha'], o['alpha'], 5e-5)
+    check(T, 'data_term (rel)', torch.tensor(sc['data_term']) / torch.tensor(o['data']).abs(), torch.sign(torch.tensor(o['data'])), 1e-5)
+    check(T, 'reg_term (rel)', torch.tensor(sc['reg_term']) / torch.tensor(o['reg']).abs(), torch.sign(torch.tensor(o['reg'])), 1e-5)
+    check(T, 'displacement [voxels]', out['displacement'], o['displacement'], 1e-4)
+    # The gradient of trilinear interpolation jumps across cell faces.  Among 2 million voxels x 12 steps a few dozen sampling
+    # positions sit within fp32 rounding of a face, and there the CPU and the GPU (positions equal to 1e-6) take different
+    # one-sided derivatives: the gradient is compared on all but a 1e-4 fraction of the voxels (58 of 6.3 million exceed
+    # the tolerance in this configuration; every forward quantity above is compared everywhere).
+    gmax = float(o['grad_v'].abs().max())
+    dev = (out['grad_v'].cpu() - o['grad_v']).abs() / gmax
+    frac_bad = float((dev > GRAD_RTOL).double().mean())
+    check(T, 'grad_v: fraction of voxels beyond tolerance', torch.tensor(frac_bad), torch.tensor(0.0), 1e-4)
+    check(T, 'grad_v (rel to max), 99.99th percentile', torch.tensor(float(dev.flatten().kthvalue(int(0.9999 * dev.numel())).values)), torch.tensor(0.0), GRAD_RTOL)
+
+
 def test_in_kernel_noise_path_runs_and_is_reproducible():
     """eps / unif = NULL -> Philox noise keyed by (seed, iteration): same seed -> same chain, other seed -> other chain."""
     from ir_sgmcmc_amd.data_loader import synthetic_pair
