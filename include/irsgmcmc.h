@@ -266,6 +266,11 @@ enum {
 int irs_buffer(irs_ctx* ctx, int which, int index, void** ptr, size_t* bytes);
 /* which gradient buffer holds the INPUT / OUTPUT of adjoint step k (IRS_BUF_GRAD_A or IRS_BUF_GRAD_B) */
 int irs_grad_buffers(const irs_ctx* ctx, int k, int* in_buf, int* out_buf);
+/* memory layout of a staged field: 0 = planar (C,3,D,H,W) like the reference's tensors, 1 = interleaved (C,D,H,W,3) -- the
+ * layout of the fields that only the squaring-step kernels touch (a run of z-planes of one chain is then ONE contiguous
+ * block: what a ghost-plane exchange sends).  what = 0: IRS_BUF_STEP index k (output of squaring step k);
+ * what = 1: the gradient buffer that is the INPUT of adjoint step k.  -1 on bad arguments. */
+int irs_layout(const irs_ctx* ctx, int what, int k);
 
 const char* irs_last_error(void);
 const char* irs_version(void);

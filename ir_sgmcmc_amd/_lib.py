@@ -103,6 +103,7 @@ SIGNATURES = {
     'irs_stage': [_P, C.POINTER(IrsIO), _I, _I, _I, _I, _P],
     'irs_buffer': [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t)],
     'irs_grad_buffers': [_P, _I, C.POINTER(_I), C.POINTER(_I)],
+    'irs_layout': [_P, _I, _I],
     'irs_last_error': [],
     'irs_version': [],
 }

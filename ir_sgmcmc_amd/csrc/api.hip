@@ -847,6 +847,13 @@ int irs_grad_buffers(const irs_ctx* c, int k, int* in_buf, int* out_buf) {
     return 0;
 }
 
+int irs_layout(const irs_ctx* c, int what, int k) {
+    if (!c || k < 0 || k >= c->cfg.no_steps) return -1;
+    if (what == 0) return (fwd_lay(c, k) & 4) ? 1 : 0;
+    if (what == 1) return (bwd_lay(c, k) & 2) ? 1 : 0;
+    return -1;
+}
+
 int irs_buffer(irs_ctx* c, int which, int index, void** ptr, size_t* bytes) {
     if (!c || !ptr || !bytes) return fail("irs_buffer: null argument");
     const size_t fieldI = (size_t)c->C * 3 * c->vol.V * sizeof(float);
@@ -911,7 +918,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
         case IRS_ST_EXP_FWD: {
             const float* in = k == 0 ? vs : c->steps + (int64_t)(k - 1) * field;
             launch_exp_step_fwd_march(in, c->steps + (int64_t)k * field, k == 0, cfg.no_steps, C, w, lin, c->dmax + (int64_t)k * C * 4,
-                                      c->dmax + (int64_t)(k + 1) * C * 4, false, 0, st);
+                                      c->dmax + (int64_t)(k + 1) * C * 4, false, fwd_lay(c, k), st);
             break;
         }
         case IRS_ST_OUTPUTS:
@@ -956,8 +963,8 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
             float* out = ob == IRS_BUF_GRAD_A ? c->gA : c->gB;
             const float* dk = k == 0 ? vs : c->steps + (int64_t)(k - 1) * field;
             const unsigned* dm = c->dmax + (int64_t)k * C * 4;
-            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, false, nullptr, 0, nullptr, st);
-            launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, 2, nullptr, 0, c->cmm, st);
+            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, false, nullptr, bwd_lay(c, k), nullptr, st);
+            launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, 2, nullptr, bwd_lay(c, k), c->cmm, st);
             break;
         }
         case IRS_ST_UPDATE: {

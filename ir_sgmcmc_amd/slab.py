@@ -57,9 +57,15 @@ class SlabEngine(TransitionEngine):
         self.min_slab = min(slab_bounds(D, self.world, r)[1] - slab_bounds(D, self.world, r)[0] for r in range(self.world))
         C_, dims = cfg.no_chains, tuple(cfg.dims)
         self._field = lambda which, idx=0: self._view(which, idx, (C_, 3, *dims), '<f4')
+        self._field_aos = lambda which, idx=0: self._view(which, idx, (C_, *dims, 3), '<f4')
         self.noisy = self._field(BUF_NOISY)
-        self.steps = [self._field(BUF_STEP, k) for k in range(cfg.no_steps)]
-        self.grad = {BUF_GRAD_A: self._field(BUF_GRAD_A), BUF_GRAD_B: self._field(BUF_GRAD_B)}
+        # fields that only the squaring-step kernels touch are interleaved (C,D,H,W,3) (include/irsgmcmc.h: irs_layout): a
+        # run of ghost planes is then one contiguous block per chain.  (tensor view, index of the z axis) per buffer:
+        lay = lambda what, k: int(self.lib.irs_layout(self._ctx, what, k))
+        self.steps = [(self._field_aos(BUF_STEP, k), 1) if lay(0, k) == 1 else (self._field(BUF_STEP, k), 2) for k in range(cfg.no_steps)]
+        self._grad_planar = {BUF_GRAD_A: self._field(BUF_GRAD_A), BUF_GRAD_B: self._field(BUF_GRAD_B)}
+        self._grad_aos = {BUF_GRAD_A: self._field_aos(BUF_GRAD_A), BUF_GRAD_B: self._field_aos(BUF_GRAD_B)}
+        self._grad_in_aos = [lay(1, k) == 1 for k in range(cfg.no_steps)]
         self.dmax = [self._view(BUF_DMAX, k, (C_, 4), '<f4') for k in range(cfg.no_steps + 1)]
         self.stat_sum = self._view(BUF_STAT_SUM, 0, (21,), '<f8')
         self.energy_sum = self._view(BUF_ENERGY_SUM, 0, (C_,), '<f8')
@@ -87,13 +93,16 @@ class SlabEngine(TransitionEngine):
         else:
             dist.all_reduce(t, op=op)
 
-    def _halo(self, t, h):
-        """make planes [a-h, a) and [b, b+h) of `t` (C, ch, D, H, W) valid by receiving them from the neighbouring ranks"""
+    def _halo(self, t, h, zdim=2):
+        """make planes [a-h, a) and [b, b+h) of `t` valid by receiving them from the neighbouring ranks; `zdim` is the index
+        of the z axis: 2 for planar (C, ch, D, H, W) tensors, 1 for interleaved (C, D, H, W, ch) ones"""
         if not self.on or self.world == 1 or h <= 0:
             return
         if h > self.min_slab:
             raise L.IrsError(f'ghost zone of {h} planes exceeds the smallest slab ({self.min_slab} planes): '
                              f'use fewer ranks for this displacement / volume')
+        if zdim != 2:
+            t = t.movedim(zdim, 2)  # a view with z on axis 2; `.contiguous()` below copies one block per chain
         a, b, D = self.a, self.b, t.shape[2]
         ops, recvs = [], []
 
@@ -119,7 +128,7 @@ class SlabEngine(TransitionEngine):
             req.wait()
         for buf, sl in recvs:
             t[:, :, sl].copy_(buf)
-        self.exchanged_planes += 2 * h * t.shape[1]
+        self.exchanged_planes += 2 * h * (t.shape[1] if zdim == 2 else t.shape[-1])
 
     def _bound_z(self, k):
         """max |d_k| along z in voxels over all chains (after the MAX all-reduce) -- one small device read"""
@@ -170,7 +179,10 @@ class SlabEngine(TransitionEngine):
         for k in range(n - 1, -1, -1):
             ib, ob = C.c_int(), C.c_int()
             L.check(self.lib.irs_grad_buffers(self._ctx, k, C.byref(ib), C.byref(ob)))
-            self._halo(self.grad[ib.value], halo[k])
+            if self._grad_in_aos[k]:
+                self._halo(self._grad_aos[ib.value], halo[k], 1)
+            else:
+                self._halo(self._grad_planar[ib.value], halo[k])
             self._stage(io, ST_EXP_BWD, k)
         self._stage(io, ST_UPDATE)
         self._stage(io, ST_FINALIZE)
@@ -190,7 +202,7 @@ class SlabEngine(TransitionEngine):
             used = [1] + [min(p + 1, self.min_slab) for p in pred[1:]]
             for k in range(n):
                 if k > 0:
-                    self._halo(self.steps[k - 1], used[k])
+                    self._halo(self.steps[k - 1][0], used[k], self.steps[k - 1][1])
                 self._stage(io, ST_EXP_FWD, k)
             self._allreduce(dmax_all, dist.ReduceOp.MAX)
             need = [int(math.floor(x)) + 1 for x in dmax_all[:n, :, 2].max(dim=1).values.tolist()]
@@ -209,7 +221,7 @@ class SlabEngine(TransitionEngine):
                 if h > 1:
                     raise L.IrsError('|d_0| >= 1 voxel: velocity field too large for 12 squaring steps')
             else:
-                self._halo(self.steps[k - 1], h)
+                self._halo(self.steps[k - 1][0], h, self.steps[k - 1][1])
             self._stage(io, ST_EXP_FWD, k)
             self._allreduce(self.dmax[k + 1], dist.ReduceOp.MAX)
         self._halo_pred = halo
