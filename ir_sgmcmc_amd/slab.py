@@ -95,39 +95,43 @@ class SlabEngine(TransitionEngine):
 
     def _halo(self, t, h, zdim=2):
         """make planes [a-h, a) and [b, b+h) of `t` valid by receiving them from the neighbouring ranks; `zdim` is the index
-        of the z axis: 2 for planar (C, ch, D, H, W) tensors, 1 for interleaved (C, D, H, W, ch) ones"""
+        of the z axis: 2 for planar (C, ch, D, H, W) tensors, 1 for interleaved (C, D, H, W, ch) ones.
+        A run of planes that is one contiguous block (interleaved fields of a single chain) is sent from / received into the
+        field itself; otherwise it goes through a packed copy.  gloo (rehearsal on one GPU) stages through the host."""
         if not self.on or self.world == 1 or h <= 0:
             return
         if h > self.min_slab:
             raise L.IrsError(f'ghost zone of {h} planes exceeds the smallest slab ({self.min_slab} planes): '
                              f'use fewer ranks for this displacement / volume')
-        if zdim != 2:
-            t = t.movedim(zdim, 2)  # a view with z on axis 2; `.contiguous()` below copies one block per chain
-        a, b, D = self.a, self.b, t.shape[2]
-        ops, recvs = [], []
+        a, b, D = self.a, self.b, t.shape[zdim]
+        ops, unpack = [], []
 
-        def stage_out(x):
-            x = x.contiguous()
-            return x.cpu() if self.host_staging else x
+        def send(lo, hi, peer):
+            x = t.narrow(zdim, lo, hi - lo)
+            x = x if x.is_contiguous() else x.contiguous()
+            ops.append(dist.P2POp(dist.isend, x.cpu() if self.host_staging else x, peer))
+
+        def recv(lo, hi, peer):
+            if hi <= lo:
+                return
+            x = t.narrow(zdim, lo, hi - lo)
+            if x.is_contiguous() and not self.host_staging:
+                ops.append(dist.P2POp(dist.irecv, x, peer))  # straight into the field
+                return
+            buf = torch.empty(x.shape, dtype=x.dtype, device='cpu' if self.host_staging else x.device)
+            ops.append(dist.P2POp(dist.irecv, buf, peer))
+            unpack.append((buf, x))
 
         if self.rank + 1 < self.world:  # upper neighbour owns [b, ...)
-            up = self.rank + 1
-            ops.append(dist.P2POp(dist.isend, stage_out(t[:, :, b - h:b]), up))
-            hi = min(b + h, D)
-            buf = torch.empty_like(t[:, :, b:hi], device='cpu' if self.host_staging else t.device).contiguous()
-            ops.append(dist.P2POp(dist.irecv, buf, up))
-            recvs.append((buf, slice(b, hi)))
+            send(b - h, b, self.rank + 1)
+            recv(b, min(b + h, D), self.rank + 1)
         if self.rank > 0:
-            dn = self.rank - 1
-            ops.append(dist.P2POp(dist.isend, stage_out(t[:, :, a:a + h]), dn))
-            lo = max(a - h, 0)
-            buf = torch.empty_like(t[:, :, lo:a], device='cpu' if self.host_staging else t.device).contiguous()
-            ops.append(dist.P2POp(dist.irecv, buf, dn))
-            recvs.append((buf, slice(lo, a)))
+            send(a, a + h, self.rank - 1)
+            recv(max(a - h, 0), a, self.rank - 1)
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-        for buf, sl in recvs:
-            t[:, :, sl].copy_(buf)
+        for buf, x in unpack:
+            x.copy_(buf)
         self.exchanged_planes += 2 * h * (t.shape[1] if zdim == 2 else t.shape[-1])
 
     def _bound_z(self, k):
