@@ -238,7 +238,10 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'exp_bwd_march_kernel<false,1> (adjoint of one squaring step)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic_bytes(N), 'algorithmic_bytes_per_launch': BWD_STEP_BYTES_PER_VOXEL * V,
-                         'avg_launch_ms': bwd_kernel_ms},
+                         'avg_launch_ms': bwd_kernel_ms,
+                         'note': 'priced against HBM as the path prescribes; the kernel itself is bound by vector-instruction issue: '
+                                 '80.4 M wave64 VALU instructions x 4 cycles / 1024 SIMDs = 150 us of its 203 us at 256^3 '
+                                 '(profiles/r01_v8_sq_counters.json, DESIGN.md section 4)'},
             'transition_roofline': {'algorithmic_bytes': BYTES_PER_VOXEL[args.loss] * V,
                                     'frac_of_device_copy': (BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9 / extras['device_copy_GBps']) if 'device_copy_GBps' in extras else None,
                                     'achieved_GBps': BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9,
