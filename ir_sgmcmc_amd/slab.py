@@ -66,6 +66,11 @@ class SlabEngine(TransitionEngine):
         self._grad_planar = {BUF_GRAD_A: self._field(BUF_GRAD_A), BUF_GRAD_B: self._field(BUF_GRAD_B)}
         self._grad_aos = {BUF_GRAD_A: self._field_aos(BUF_GRAD_A), BUF_GRAD_B: self._field_aos(BUF_GRAD_B)}
         self._grad_in_aos = [lay(1, k) == 1 for k in range(cfg.no_steps)]
+        self._grad_in_buf = []
+        for k in range(cfg.no_steps):
+            ib, ob = C.c_int(), C.c_int()
+            L.check(self.lib.irs_grad_buffers(self._ctx, k, C.byref(ib), C.byref(ob)))
+            self._grad_in_buf.append(ib.value)
         self.dmax = [self._view(BUF_DMAX, k, (C_, 4), '<f4') for k in range(cfg.no_steps + 1)]
         self.stat_sum = self._view(BUF_STAT_SUM, 0, (21,), '<f8')
         self.energy_sum = self._view(BUF_ENERGY_SUM, 0, (C_,), '<f8')
@@ -81,7 +86,9 @@ class SlabEngine(TransitionEngine):
     def _stage(self, io, stage, k=0, lo=None, hi=None):
         lo = self.a if lo is None else lo
         hi = self.b if hi is None else hi
-        L.check(self.lib.irs_stage(self._ctx, C.byref(io), stage, k, int(lo), int(hi), L.stream_ptr()))
+        # ~60 stage calls per transition: the stream handle and the io reference are looked up once per transition
+        if self._irs_stage(self._ctx, self._io_ref, stage, k, int(lo), int(hi), self._stream):
+            L.check(1)
 
     def _allreduce(self, t, op):
         if not self.on or self.world == 1:
@@ -149,6 +156,7 @@ class SlabEngine(TransitionEngine):
             if outputs.get(key) is None:
                 outputs[key] = self._own(key, (cfg.no_chains, ch, *cfg.dims))
         io = self._io(fixed, moving, v, sigma, eps, unif, outputs)
+        self._io_ref, self._stream, self._irs_stage = C.byref(io), L.stream_ptr(), self.lib.irs_stage
         gmm = cfg.data_loss == 'GMM'
         ls = cfg.lcc_s if gmm else 0
 
@@ -181,12 +189,11 @@ class SlabEngine(TransitionEngine):
         self._allreduce(self.nll_sum, dist.ReduceOp.SUM)
         self._stage(io, ST_WARP_BWD)
         for k in range(n - 1, -1, -1):
-            ib, ob = C.c_int(), C.c_int()
-            L.check(self.lib.irs_grad_buffers(self._ctx, k, C.byref(ib), C.byref(ob)))
+            ib = self._grad_in_buf[k]
             if self._grad_in_aos[k]:
-                self._halo(self._grad_aos[ib.value], halo[k], 1)
+                self._halo(self._grad_aos[ib], halo[k], 1)
             else:
-                self._halo(self._grad_planar[ib.value], halo[k])
+                self._halo(self._grad_planar[ib], halo[k])
             self._stage(io, ST_EXP_BWD, k)
         self._stage(io, ST_UPDATE)
         self._stage(io, ST_FINALIZE)
