@@ -95,6 +95,8 @@ struct irs_ctx {
     int nll_blocks;
     hipEvent_t ev[8];
     hipEvent_t ev_bwd[64];
+    hipEvent_t ra_ev[4];     // end of the last transitions: bounds how far the host may run ahead of the device
+    uint64_t n_enqueued = 0;
 };
 
 namespace {
@@ -574,6 +576,7 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
     }
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 64 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev_bwd[i]);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ra_ev[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->hint, sizeof(unsigned) * kHintWords, hipHostMallocDefault);
     if (e == hipSuccess)
         for (int i = 0; i < kHintWords; ++i) c->hint[i] = 0x7f800000u;  // +inf: nothing known yet, launch every variant
@@ -593,6 +596,8 @@ void irs_destroy(irs_ctx* c) {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 64; ++i)
         if (c->ev_bwd[i]) (void)hipEventDestroy(c->ev_bwd[i]);
+    for (int i = 0; i < 4; ++i)
+        if (c->ra_ev[i]) (void)hipEventDestroy(c->ra_ev[i]);
     if (c->lin.dev) (void)hipFree(c->lin.dev);
     if (c->hint) (void)hipHostFree(c->hint);
     if (c->slab) (void)hipFree(c->slab);
@@ -747,6 +752,17 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     float* z = io->residuals ? io->residuals : c->z;
     const uint64_t* it = &c->state->st.iteration;
 
+    // Bounded run-ahead: the host may be at most IRS_RUN_AHEAD (default 2) transitions ahead of the device.  The variant
+    // prediction below reads bounds the device published at the end of an earlier transition; a host that has queued twenty
+    // transitions would predict from a state twenty transitions old, and while the displacement is still growing (burn-in)
+    // that mispredicts into the slow always-correct fallbacks.  Two queued transitions keep the device busy all the same.
+    {
+        const int depth = env_int("IRS_RUN_AHEAD", 2);
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (depth > 0 && depth <= 3 && cap == hipStreamCaptureStatusNone && c->n_enqueued >= (uint64_t)depth)
+            HIP_TRY(hipEventSynchronize(c->ra_ev[(c->n_enqueued - depth) % 4]));
+    }
     if (timed) HIP_TRY(hipEventRecord(c->ev[0], st));
     // fused backward warp: the forward warp also writes d(warped)/d(d_last) into gA, and the first adjoint squaring step
     // multiplies it with g_warped while staging (kernels.h: gscale); only on the LDS path, which owns every variant of it
@@ -830,6 +846,8 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
                     4 * C * (cfg.no_steps + 1), st);
     LAUNCH_CHECK();
     if (timed) HIP_TRY(hipEventRecord(c->ev[5], st));
+    HIP_TRY(hipEventRecord(c->ra_ev[c->n_enqueued % 4], st));
+    ++c->n_enqueued;
     return 0;
 }
 
