@@ -33,11 +33,11 @@ FWD_STEP_BYTES_PER_VOXEL = 24.0
 
 def pmc_traffic_bytes(n):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
-    WRITE_SIZE runs of this same command at 256^3; profiles/r01_v9_pmc_traffic.json).  Corrections as the
+    WRITE_SIZE runs of this same command at 256^3; profiles/r01_v10_pmc_traffic.json).  Corrections as the
     MI355X guide prescribes: counters are KiB; FETCH_SIZE reads exactly 1/2 of the bytes of this kernel's dword-per-lane
     loads (calibrated in the same run on perturb_kernel, whose read volume is known); WRITE_SIZE is exact.
     None for sizes that were not profiled."""
-    path = os.path.join(ROOT, 'profiles', 'r01_v9_pmc_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_v10_pmc_traffic.json')
     if n != 256 or not os.path.isfile(path):
         return None
     t = json.load(open(path))
