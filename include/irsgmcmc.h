@@ -272,6 +272,90 @@ int irs_grad_buffers(const irs_ctx* ctx, int k, int* in_buf, int* out_buf);
  * what = 1: the gradient buffer that is the INPUT of adjoint step k.  -1 on bad arguments. */
 int irs_layout(const irs_ctx* ctx, int what, int k);
 
+/* ------------------------------------------------------------------------------------------------
+ * z-slab decomposition INSIDE the library (BASELINE.json config 4): one chain, the volume split
+ * along z over the ranks of a node, one process per GPU.  What is sharded is the single-device loop body
+ * trainer/trainer.py:291-356 (the reference has no multi-device code, base/base_trainer.py:16).
+ *
+ * Rank r owns the planes [a, b) = [r D / n, (r + 1) D / n) and HOLDS [lo, hi) = [a - margin, b + margin) clipped to the
+ * volume: every array of the context and every array of irs_io -- except the moving image -- is slab-local,
+ * (C, ch, hi - lo, H, W), so memory per rank falls with the number of ranks.  The moving image is static and is given
+ * whole (67 MB at 256^3): the warp may then sample it at any displacement without traffic.
+ *
+ * irs_slab_transition runs the same kernels as irs_transition on windows of the slab and moves ghost planes between
+ * neighbouring ranks with the communicator (RCCL ncclSend / ncclRecv on a communication stream of its own; four small
+ * ncclAllReduce for the partial sums) -- no host synchronisation, no Python between the stages:
+ *   - stencil halos of fixed width (Sobolev s, LCC 4 s, update 1);
+ *   - gather halos of the squaring steps, whose width floor(max|d_k|) + 1 follows the displacement: planned on the host from
+ *     the all-reduced bounds of an earlier transition (never waited for), validated on the device afterwards
+ *     (irs_slab_status_get); the first transition measures them step by step ("exact" mode, blocking);
+ *   - forward squaring steps are grouped into communication-avoiding blocks (one exchange of up to `ghost_max` planes,
+ *     then several steps on shrinking windows); every step around an exchange is split into its interior (launched
+ *     while the exchange is in flight) and its two boundary strips (launched when the ghost planes have arrived);
+ *   - the adjoint is an owner-computes gather, so the backward pass also only RECEIVES ghost planes (of the incoming
+ *     gradient): no reverse halo accumulation.
+ * With one rank the schedule degenerates to the single-GPU launch sequence.  SVF_3D only.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct irs_comm irs_comm;
+#define IRS_COMM_ID_BYTES 128
+/* rank 0: ncclGetUniqueId; the caller distributes the bytes to the other ranks (any channel). */
+int irs_comm_unique_id(uint8_t id[IRS_COMM_ID_BYTES]);
+/* ncclCommInitRank on the CURRENT device; collective over the `world` ranks, blocking. */
+int irs_comm_create_rccl(const uint8_t id[IRS_COMM_ID_BYTES], int rank, int world, irs_comm** out);
+/* The same two transport operations as caller-supplied functions: rehearsal of the schedule with several ranks sharing ONE
+ * GPU, which RCCL refuses (tests).  A callback must leave the data in place when it returns or enqueue its work on `stream`. */
+typedef struct irs_xfer {
+    void* ptr;      /* device pointer */
+    size_t bytes;
+    int32_t peer;   /* rank */
+    int32_t recv;   /* 0 = send, 1 = receive */
+} irs_xfer;
+typedef int (*irs_exchange_fn)(void* user, const irs_xfer* xfers, int n, void* stream);
+typedef int (*irs_allreduce_fn)(void* user, void* buf, size_t count, int max_u32, void* stream); /* SUM f64 | MAX u32 */
+int irs_comm_create_callbacks(irs_exchange_fn ex, irs_allreduce_fn ar, void* user, int rank, int world, irs_comm** out);
+void irs_comm_destroy(irs_comm* comm);
+int irs_comm_rank(const irs_comm* comm);
+int irs_comm_world(const irs_comm* comm);
+/* one all-reduce of each kind and one ring exchange on scratch memory, verified on the host. blocking, collective. */
+int irs_comm_selftest(irs_comm* comm, void* stream);
+
+typedef struct irs_slab_config {
+    int32_t ghost_max;  /* widest ghost zone of one exchange, planes (0 -> 4) */
+    int32_t margin;     /* ghost planes held beyond a neighbour-facing edge (0 -> derived from the stencil widths) */
+} irs_slab_config;
+typedef struct irs_slab_layout {
+    int32_t rank, world;
+    int32_t a, b;       /* owned planes */
+    int32_t lo, hi;     /* held planes: every slab-local array is (C, ch, hi - lo, H, W) */
+    int32_t margin, ghost_max;
+} irs_slab_layout;
+/* planes a rank would own / hold, without creating anything (pure host arithmetic; what the caller cuts its arrays with) */
+int irs_slab_plan_layout(const irs_config* cfg, const irs_slab_config* scfg, int rank, int world, irs_slab_layout* out);
+/* context with slab-local workspace; `comm` may be NULL when world == 1.  The communicator is not owned. blocking. */
+int irs_slab_create(const irs_config* cfg, const irs_slab_config* scfg, irs_comm* comm, irs_ctx** out);
+int irs_slab_get_layout(const irs_ctx* ctx, irs_slab_layout* out);
+/* one transition of the slab; irs_io arrays are slab-local except moving_im (whole volume, moving_chains in {1, C}).
+ * curr_state / im_moving_warped / residuals outputs are valid on the owned planes.  asynchronous (after the first call). */
+int irs_slab_transition(irs_ctx* ctx, const irs_io* io, void* stream);
+/* Trainer.__GMM_init on the slabs (v_sample slab-local or NULL); collective, blocking. */
+int irs_slab_gmm_init(irs_ctx* ctx, const irs_io* io, const float* v_sample, int warm_up, void* stream);
+typedef struct irs_slab_status {
+    uint64_t transitions, exact_transitions; /* total / run in exact (measuring, blocking) mode */
+    uint64_t exchanges, exchanged_bytes;     /* point-to-point rounds / bytes sent by this rank */
+    uint64_t mispredictions;                 /* transitions whose planned ghost widths turned out too narrow (results invalid) */
+    int32_t last_fwd_rounds, last_bwd_rounds;/* exchange rounds of the squaring steps in the last transition */
+} irs_slab_status;
+/* blocking (waits for the enqueued transitions). A non-zero `mispredictions` is also returned as an error by the next
+ * irs_slab_transition. */
+int irs_slab_status_get(irs_ctx* ctx, irs_slab_status* out, void* stream);
+/* The schedule of the squaring steps as pure host arithmetic (tests, documentation): given the per-step ghost widths
+ * h[0..n) (= floor(max|d_k|) + 1), the widest exchange and the smallest slab, fill fwd_round[k] / bwd_round[k] with the index
+ * of the exchange round step k belongs to, and fwd_width[r] / bwd_width[r] with the planes that round exchanges (round 0 of
+ * the forward pass is fed by the widened smoothing stage and exchanges the perturbed velocity instead).  Returns the
+ * number of rounds through n_fwd / n_bwd; non-zero status if a width exceeds the limits. */
+int irs_slab_plan_rounds(const int32_t* h, int n, int ghost_max, int min_slab, int32_t* fwd_round, int32_t* fwd_width,
+                         int32_t* n_fwd, int32_t* bwd_round, int32_t* bwd_width, int32_t* n_bwd);
+
 const char* irs_last_error(void);
 const char* irs_version(void);
 

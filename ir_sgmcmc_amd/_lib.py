@@ -68,7 +68,30 @@ class IrsTimings(C.Structure):
                                          'data_ms', 'update_ms', 'exp_bwd_primary_avg_ms')]
 
 
+class IrsXfer(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('bytes', C.c_size_t), ('peer', C.c_int32), ('recv', C.c_int32)]
+
+
+class IrsSlabConfig(C.Structure):
+    _fields_ = [('ghost_max', C.c_int32), ('margin', C.c_int32)]
+
+
+class IrsSlabLayout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('rank', 'world', 'a', 'b', 'lo', 'hi', 'margin', 'ghost_max')]
+
+
+class IrsSlabStatus(C.Structure):
+    _fields_ = [('transitions', C.c_uint64), ('exact_transitions', C.c_uint64), ('exchanges', C.c_uint64),
+                ('exchanged_bytes', C.c_uint64), ('mispredictions', C.c_uint64), ('last_fwd_rounds', C.c_int32),
+                ('last_bwd_rounds', C.c_int32)]
+
+
+IRS_COMM_ID_BYTES = 128
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(IrsXfer), C.c_int, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
 _P, _I, _F, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64
+_I32P = C.POINTER(C.c_int32)
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must match include/irsgmcmc.h exactly
 SIGNATURES = {
@@ -104,10 +127,25 @@ SIGNATURES = {
     'irs_buffer': [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t)],
     'irs_grad_buffers': [_P, _I, C.POINTER(_I), C.POINTER(_I)],
     'irs_layout': [_P, _I, _I],
+    'irs_comm_unique_id': [C.POINTER(C.c_uint8 * IRS_COMM_ID_BYTES)],
+    'irs_comm_create_rccl': [C.POINTER(C.c_uint8 * IRS_COMM_ID_BYTES), _I, _I, C.POINTER(_P)],
+    'irs_comm_create_callbacks': [EXCHANGE_FN, ALLREDUCE_FN, _P, _I, _I, C.POINTER(_P)],
+    'irs_comm_destroy': [_P],
+    'irs_comm_rank': [_P],
+    'irs_comm_world': [_P],
+    'irs_comm_selftest': [_P, _P],
+    'irs_slab_plan_layout': [C.POINTER(IrsConfig), C.POINTER(IrsSlabConfig), _I, _I, C.POINTER(IrsSlabLayout)],
+    'irs_slab_create': [C.POINTER(IrsConfig), C.POINTER(IrsSlabConfig), _P, C.POINTER(_P)],
+    'irs_slab_get_layout': [_P, C.POINTER(IrsSlabLayout)],
+    'irs_slab_transition': [_P, C.POINTER(IrsIO), _P],
+    'irs_slab_gmm_init': [_P, C.POINTER(IrsIO), _P, _I, _P],
+    'irs_slab_status_get': [_P, C.POINTER(IrsSlabStatus), _P],
+    'irs_slab_plan_rounds': [_I32P, _I, _I, _I, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P],
     'irs_last_error': [],
     'irs_version': [],
 }
 _RESTYPES = {'irs_reduce_scratch_doubles': C.c_size_t, 'irs_workspace_bytes': C.c_size_t, 'irs_destroy': None,
+             'irs_comm_destroy': None,
              'irs_last_error': C.c_char_p, 'irs_version': C.c_char_p}
 
 _lib = None

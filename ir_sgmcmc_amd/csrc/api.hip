@@ -8,13 +8,11 @@
 
 #include <new>
 
-#include "kernels.h"
-#include "scalar_kernels.h"
+#include "ctx.h"
 
 using namespace irs;
 
-namespace {
-
+namespace irs {
 thread_local char g_err[512] = "";
 
 int fail(const char* fmt, ...) {
@@ -24,18 +22,9 @@ int fail(const char* fmt, ...) {
     va_end(ap);
     return 1;
 }
+}  // namespace irs
 
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));      \
-    } while (0)
-
-#define LAUNCH_CHECK()                                                                         \
-    do {                                                                                       \
-        hipError_t e_ = hipGetLastError();                                                     \
-        if (e_ != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(e_)); \
-    } while (0)
+namespace {
 
 bool dims_ok(int C, int D, int H, int W) {
     // < 2^30 voxels per volume: kernels address within a volume with 32-bit byte offsets (a 1024^3 transition would need
@@ -59,91 +48,13 @@ SplineTaps make_spline(int cps) {
     return t;
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
-bool use_lds_exp() { return env_int("IRS_EXP_LDS", 1) != 0; }
-
 int control_points(int n, int cps) { return (int)ceil((double)(n - 1) / (double)cps) + 1 + 2; }  // utils/util.py:61-69
 
 }  // namespace
 
-struct irs_ctx {
-    irs_config cfg;
-    DevCfg dcfg;
-    Vol vol, volv;
-    bool ffd;
-    int C;
-    LinTables lin;
-    Taps sob;
-    SplineTaps spl[3];
-    char* slab;
-    size_t slab_bytes;
-    // workspace views
-    float *steps, *tmpA, *tmpB, *vs, *gA, *gB, *warped, *z, *sigM, *fhat, *gM, *dense;
-    double *stat_partials, *energy_partials, *nll_partials;
-    double *stat_sum, *energy_sum, *nll_sum;  // reduced partial sums (staged / slab path)
-    unsigned* dmax;  // [no_steps][C][4] max |d_k| in voxels per axis (float bits), by-product of the forward steps
-    float* cmm;      // coarse (8^3 cells) min / max of d_k for the source boxes of the any-radius adjoint (kernels.h)
-    unsigned* hint = nullptr;  // pinned host copy of dmax as of the last finished transition (written by finalize_kernel, read
-                     // by the host WITHOUT synchronisation: a hint that only decides which variants are launched)
-    DevState* state;
-    int fhat_chains;
-    bool fixed_set;
-    int nll_blocks;
-    hipEvent_t ev[8];
-    hipEvent_t ev_bwd[64];
-    hipEvent_t ra_ev[4];     // end of the last transitions: bounds how far the host may run ahead of the device
-    uint64_t n_enqueued = 0;
-};
-
-namespace {
-constexpr int kHintWords = 4 * IRS_MAX_CHAINS * 32;  // same extent as the dmax scratch
-
-// Host-side guess of "max |d_k| stays well below one voxel" from the bounds of the last transition the host has seen
-// finish (never waited for: stale by a transition or two, and displacements move by O(lr) per transition).  Only a launch
-// decision for the FORWARD step k: when true, the radius-1 kernel is launched alone -- it is correct for any displacement
-// (taps that leave its LDS ring are read from global memory), so a wrong guess costs time, not parity.  The adjoint keeps
-// launching every variant: an in-kernel generic fallback for its radius-1 kernel was measured to cost more (7 % on
-// every launch, from the larger kernel) than the two idle launches it saves.
-bool predicted_below(const irs_ctx* c, int k, float bound) {
-    const int mode = env_int("IRS_PREDICT_VARIANTS", 1);  // 0: always launch every variant; 2: always predict small (tests)
-    if (mode == 2) return true;
-    if (!mode || !c->hint) return false;
-    const volatile unsigned* h = c->hint + (size_t)k * c->C * 4;
-    float m = 0.0f;
-    for (int i = 0; i < c->C * 4; ++i) {
-        const unsigned bits = h[i];
-        float f;
-        memcpy(&f, &bits, sizeof(f));
-        if (!(f >= 0.0f)) return false;  // NaN / garbage
-        m = f > m ? f : m;
-    }
-    return m < bound;
-}
-
-bool predicted_small(const irs_ctx* c, int k) { return predicted_below(c, k, 0.75f); }
-
-// Layouts of the INTERNAL fields of the fused path (exp_kernels.hip: Lay3; bits 1 displacement in, 2 gradient in, 4 out):
-// d_1 .. d_{n-1} and the gradients handed from one adjoint step to the next are interleaved ([V][3]); everything that crosses
-// into another kernel family -- the velocity in, d_n into the warp, the gradient into the first and out of the last adjoint
-// step -- stays planar like the reference's tensors.  The staged (z-slab) and stateless entry points are planar throughout.
-bool aos_enabled() { return use_lds_exp() && env_int("IRS_AOS", 1) != 0; }
-int fwd_lay(const irs_ctx* c, int k) {
-    if (!aos_enabled()) return 0;
-    return (k > 0 ? 1 : 0) | (k < c->cfg.no_steps - 1 ? 4 : 0);
-}
-int bwd_lay(const irs_ctx* c, int k) {
-    if (!aos_enabled()) return 0;
-    return (k > 0 ? 1 : 0) | (k < c->cfg.no_steps - 1 ? 2 : 0) | (k > 0 ? 4 : 0);
-}
-}  // namespace
-
 extern "C" {
 
-const char* irs_last_error(void) { return g_err; }
+const char* irs_last_error(void) { return irs::g_err; }
 const char* irs_version(void) { return "ir-sgmcmc-amd 0.1 (gfx950)"; }
 size_t irs_reduce_scratch_doubles(void) { return (size_t)kMaxPartialBlocks * IRS_MAX_CHAINS; }
 
@@ -247,13 +158,6 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
     }
     *result = const_cast<float*>(G);
     return 0;
-}
-
-static void prescale_factors(Vol vol, int no_steps, float s[3]) {
-    const double p = 1.0 / (double)(1 << no_steps);
-    s[0] = (float)(2.0 / (double)(vol.W - 1) * p);  // x <-> W, y <-> H, z <-> D
-    s[1] = (float)(2.0 / (double)(vol.H - 1) * p);
-    s[2] = (float)(2.0 / (double)(vol.D - 1) * p);
 }
 
 int irs_svf_exp_bwd(const float* v, const float* steps, const float* g_last, float* scratch, float* g_v, int no_steps,
@@ -441,7 +345,9 @@ int irs_log_det_jacobian(const float* transformation, float* log_det, long long*
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-int irs_create(const irs_config* cfg, irs_ctx** out) {
+}  // extern "C"
+
+int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     if (!cfg || !out) return fail("irs_create: null argument");
     const int D = cfg->dims[0], H = cfg->dims[1], W = cfg->dims[2], C = cfg->no_chains;
     if (!dims_ok(C, D, H, W) || C > IRS_MAX_CHAINS) return fail("irs_create: bad dims / chains (C <= %d)", IRS_MAX_CHAINS);
@@ -467,6 +373,10 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
     c->cfg = *cfg;
     c->C = C;
     c->vol = make_vol(D, H, W);
+    if (sl && sl->on) {  // slab-local arrays: the channel / chain stride is the number of HELD planes (common.h: Vol)
+        c->sl = *sl;
+        c->vol.V = (int64_t)(sl->hi - sl->lo) * H * W;
+    }
     c->ffd = any_cps;
     c->volv = c->ffd ? make_vol(control_points(D, cfg->cps[0]), control_points(H, cfg->cps[1]), control_points(W, cfg->cps[2]))
                      : c->vol;
@@ -533,6 +443,7 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
         delete c;
         return fail("irs_create: hipMalloc of %zu workspace bytes failed", off);
     }
+    if (c->sl.on) (void)hipMemset(c->slab, 0, off);  // ghost planes nobody has written yet must hold finite values
     c->steps = (float*)(c->slab + o_steps);
     c->tmpA = (float*)(c->slab + o_tmpA);
     c->tmpB = (float*)(c->slab + o_tmpB);
@@ -579,7 +490,7 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ra_ev[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->hint, sizeof(unsigned) * kHintWords, hipHostMallocDefault);
     if (e == hipSuccess)
-        for (int i = 0; i < kHintWords; ++i) c->hint[i] = 0x7f800000u;  // +inf: nothing known yet, launch every variant
+        for (int i = 0; i < kHintWords; ++i) c->hint[i] = i < kHintWords - 8 ? 0x7f800000u : 0u;  // +inf: nothing known yet, launch every variant; flags clear
     if (e != hipSuccess) {
         (void)hipFree(c->slab);
         delete c;
@@ -589,9 +500,14 @@ int irs_create(const irs_config* cfg, irs_ctx** out) {
     return 0;
 }
 
+extern "C" {
+
+int irs_create(const irs_config* cfg, irs_ctx** out) { return irs::create_ctx(cfg, nullptr, out); }
+
 void irs_destroy(irs_ctx* c) {
     if (!c) return;
     (void)hipDeviceSynchronize();
+    if (c->sl.on) slab_release(c);
     for (int i = 0; i < 8; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 64; ++i)
@@ -617,7 +533,14 @@ int irs_velocity_dims(const irs_ctx* c, int32_t out[3]) {
 int irs_set_fixed(irs_ctx* c, const float* fixed_im, int fixed_chains, void* stream) {
     if (!c || !fixed_im || (fixed_chains != 1 && fixed_chains != c->C)) return fail("irs_set_fixed: bad arguments");
     if (c->cfg.data_loss == IRS_DATA_GMM_LCC) {
-        launch_lcc_fwd_march(nullptr, 0, fixed_im, c->fhat, nullptr, c->cfg.lcc_s, fixed_chains, c->vol, (hipStream_t)stream);
+        Vol w = c->vol;
+        int64_t shift = 0;
+        if (c->sl.on) {  // slab-local image: normalise where the 2 s input planes either side are held (or are replicate padding)
+            const int ls = c->cfg.lcc_s;
+            w = window(c->vol, c->sl.lo + (c->sl.lo > 0 ? 2 * ls : 0), c->sl.hi - (c->sl.hi < c->vol.D ? 2 * ls : 0));
+            shift = (int64_t)c->sl.lo * c->vol.H * c->vol.W;
+        }
+        launch_lcc_fwd_march(nullptr, 0, fixed_im - shift, c->fhat - shift, nullptr, c->cfg.lcc_s, fixed_chains, w, (hipStream_t)stream);
         LAUNCH_CHECK();
     }
     c->fhat_chains = fixed_chains;
@@ -652,7 +575,9 @@ int irs_get_scalars(irs_ctx* c, irs_scalars* out, void* stream) {
 // the transition
 // ================================================================================================
 
-static int check_io(const irs_ctx* c, const irs_io* io, const char* who) {
+}  // extern "C"
+
+int irs::check_io(const irs_ctx* c, const irs_io* io, const char* who) {
     if (!c || !io) return fail("%s: null argument", who);
     if (!io->fixed_im || !io->moving_im || !io->mask) return fail("%s: fixed_im, moving_im and mask are required", who);
     auto ok = [&](int n) { return n == 1 || n == c->C; };
@@ -661,6 +586,8 @@ static int check_io(const irs_ctx* c, const irs_io* io, const char* who) {
     if (c->cfg.data_loss == IRS_DATA_GMM_LCC && !c->fixed_set) return fail("%s: call irs_set_fixed first", who);
     return 0;
 }
+
+extern "C" {
 
 // velocity (v + noise, smoothed) -> vs; dense velocity -> d_1..d_n; warp -> warped; residual -> z (+ sigM)
 static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_noise, bool with_jitter, float* vs,

@@ -1,0 +1,224 @@
+// Transport of the z-slab decomposition (include/irsgmcmc.h: irs_comm_*): ghost-plane point-to-point exchanges between
+// neighbouring ranks and the small all-reduces of the partial sums.
+//
+//   RCCL        ncclSend / ncclRecv inside one group per exchange, ncclAllReduce, all enqueued on a HIP stream (the
+//               communication stream of slab.hip) -- xGMI point-to-point between the neighbouring GPUs of one node.  librccl
+//               is bound at RUN time (dlopen): the library an application already has in its process (PyTorch ships one) is
+//               reused, and a host without RCCL can still load this library for everything that is not multi-GPU.
+//   callbacks   the same two operations handed to caller-supplied functions.  Exists so that the slab schedule can be
+//               rehearsed with several ranks SHARING one GPU (RCCL refuses two ranks on one device); tests only.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <stdio.h>
+
+#include "comm.h"
+#include "ctx.h"
+
+namespace irs {
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_rccl;
+
+int load_rccl() {
+    if (g_rccl.handle) return 0;
+    const char* names[] = {getenv("IRS_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    // an RCCL that is already in the process first (two copies of the library in one process would each own their own
+    // bootstrap / proxy threads)
+    for (const char* n : names)
+        if (n && *n && !h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    for (const char* n : names)
+        if (n && *n && !h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail("RCCL not found (librccl.so.1): %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+#define IRS_SYM(field, name)                                                      \
+    *(void**)(&a.field) = dlsym(h, name);                                         \
+    if (!a.field) return fail("librccl lacks %s", name)
+    IRS_SYM(GetUniqueId, "ncclGetUniqueId");
+    IRS_SYM(CommInitRank, "ncclCommInitRank");
+    IRS_SYM(CommDestroy, "ncclCommDestroy");
+    IRS_SYM(Send, "ncclSend");
+    IRS_SYM(Recv, "ncclRecv");
+    IRS_SYM(AllReduce, "ncclAllReduce");
+    IRS_SYM(GroupStart, "ncclGroupStart");
+    IRS_SYM(GroupEnd, "ncclGroupEnd");
+    IRS_SYM(GetErrorString, "ncclGetErrorString");
+#undef IRS_SYM
+    g_rccl = a;
+    return 0;
+}
+
+#define NCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(r_));           \
+    } while (0)
+
+}  // namespace
+
+int comm_exchange(irs_comm* cm, const irs_xfer* x, int n, hipStream_t st) {
+    if (!cm) return fail("exchange without a communicator");
+    if (n <= 0) return 0;
+    if (cm->kind == 1) {
+        if (cm->ex(cm->user, x, n, (void*)st)) return fail("exchange callback failed");
+        return 0;
+    }
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int i = 0; i < n; ++i) {
+        if (x[i].peer < 0 || x[i].peer >= cm->world || x[i].peer == cm->rank) {
+            (void)g_rccl.GroupEnd();
+            return fail("exchange: bad peer %d", x[i].peer);
+        }
+        const ncclResult_t r = x[i].recv ? g_rccl.Recv(x[i].ptr, x[i].bytes, ncclChar, x[i].peer, (ncclComm_t)cm->nccl, st)
+                                         : g_rccl.Send(x[i].ptr, x[i].bytes, ncclChar, x[i].peer, (ncclComm_t)cm->nccl, st);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            return fail("ncclSend/ncclRecv failed: %s", g_rccl.GetErrorString(r));
+        }
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    return 0;
+}
+
+int comm_allreduce(irs_comm* cm, void* buf, size_t count, int max_u32, hipStream_t st) {
+    if (!cm) return fail("all-reduce without a communicator");
+    if (cm->world == 1 || count == 0) return 0;
+    if (cm->kind == 1) {
+        if (cm->ar(cm->user, buf, count, max_u32, (void*)st)) return fail("all-reduce callback failed");
+        return 0;
+    }
+    if (max_u32) NCCL_TRY(g_rccl.AllReduce(buf, buf, count, ncclUint32, ncclMax, (ncclComm_t)cm->nccl, st));
+    else NCCL_TRY(g_rccl.AllReduce(buf, buf, count, ncclFloat64, ncclSum, (ncclComm_t)cm->nccl, st));
+    return 0;
+}
+
+}  // namespace irs
+
+using namespace irs;
+
+extern "C" {
+
+int irs_comm_unique_id(uint8_t id[IRS_COMM_ID_BYTES]) {
+    if (!id) return fail("irs_comm_unique_id: null argument");
+    if (load_rccl()) return 1;
+    static_assert(sizeof(ncclUniqueId) == IRS_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    NCCL_TRY(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+int irs_comm_create_rccl(const uint8_t id[IRS_COMM_ID_BYTES], int rank, int world, irs_comm** out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail("irs_comm_create_rccl: bad arguments");
+    if (load_rccl()) return 1;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(g_rccl.CommInitRank(&comm, world, u, rank));
+    irs_comm* c = new (std::nothrow) irs_comm();
+    if (!c) return fail("irs_comm_create_rccl: out of host memory");
+    c->kind = 0;
+    c->rank = rank;
+    c->world = world;
+    c->nccl = (void*)comm;
+    *out = c;
+    return 0;
+}
+
+int irs_comm_create_callbacks(irs_exchange_fn ex, irs_allreduce_fn ar, void* user, int rank, int world, irs_comm** out) {
+    if (!ex || !ar || !out || world < 1 || rank < 0 || rank >= world) return fail("irs_comm_create_callbacks: bad arguments");
+    irs_comm* c = new (std::nothrow) irs_comm();
+    if (!c) return fail("irs_comm_create_callbacks: out of host memory");
+    c->kind = 1;
+    c->rank = rank;
+    c->world = world;
+    c->ex = ex;
+    c->ar = ar;
+    c->user = user;
+    *out = c;
+    return 0;
+}
+
+void irs_comm_destroy(irs_comm* c) {
+    if (!c) return;
+    if (c->kind == 0 && c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->nccl);
+    delete c;
+}
+
+int irs_comm_rank(const irs_comm* c) { return c ? c->rank : -1; }
+int irs_comm_world(const irs_comm* c) { return c ? c->world : -1; }
+
+// One all-reduce (SUM of doubles, MAX of uint32) and one grouped exchange with the ring neighbours on device scratch, checked
+// on the host: the first thing a multi-GPU run executes, so that a broken transport fails here and not as a wrong chain.
+// With one rank the exchange is skipped (RCCL has no self send in a group of one) and the all-reduce is the identity.  blocking.
+int irs_comm_selftest(irs_comm* c, void* stream) {
+    if (!c) return fail("irs_comm_selftest: null communicator");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = 1024;
+    char* dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&dev, 4 * n * sizeof(double)));
+    double* d = (double*)dev;
+    unsigned* u = (unsigned*)(d + n);
+    double* sendb = d + 2 * n;
+    double* recvb = d + 3 * n;
+    double hd[n];
+    unsigned hu[n];
+    for (int i = 0; i < n; ++i) {
+        hd[i] = (double)(c->rank + 1) * (i + 1);
+        hu[i] = (unsigned)(c->rank * 7 + i);
+    }
+    int rc = 0;
+    auto done = [&](int code) {
+        (void)hipFree(dev);
+        return code;
+    };
+    if (hipMemcpyAsync(d, hd, sizeof(hd), hipMemcpyHostToDevice, st) != hipSuccess) return done(fail("selftest: copy failed"));
+    (void)hipMemcpyAsync(u, hu, sizeof(hu), hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(sendb, hd, sizeof(hd), hipMemcpyHostToDevice, st);
+    (void)hipMemsetAsync(recvb, 0, sizeof(hd), st);
+    if (c->kind == 0) {  // through RCCL even with one rank (comm_allreduce short-cuts that case): the bound entry points get used
+        if (g_rccl.AllReduce(d, d, n, ncclFloat64, ncclSum, (ncclComm_t)c->nccl, st) != ncclSuccess ||
+            g_rccl.AllReduce(u, u, n, ncclUint32, ncclMax, (ncclComm_t)c->nccl, st) != ncclSuccess)
+            return done(fail("selftest: ncclAllReduce failed"));
+    } else {
+        rc |= comm_allreduce(c, d, n, 0, st);
+        rc |= comm_allreduce(c, u, n, 1, st);
+    }
+    if (c->world > 1) {  // ring: send to rank + 1, receive from rank - 1
+        irs_xfer x[2] = {{sendb, sizeof(hd), (c->rank + 1) % c->world, 0},
+                         {recvb, sizeof(hd), (c->rank + c->world - 1) % c->world, 1}};
+        rc |= comm_exchange(c, x, 2, st);
+    }
+    if (rc) return done(1);
+    double rd[n], rr[n];
+    unsigned ru[n];
+    (void)hipMemcpyAsync(rd, d, sizeof(rd), hipMemcpyDeviceToHost, st);
+    (void)hipMemcpyAsync(ru, u, sizeof(ru), hipMemcpyDeviceToHost, st);
+    (void)hipMemcpyAsync(rr, recvb, sizeof(rr), hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) return done(fail("selftest: stream failed"));
+    const double tri = 0.5 * c->world * (c->world + 1);
+    const int prev = (c->rank + c->world - 1) % c->world;
+    for (int i = 0; i < n; ++i) {
+        if (rd[i] != tri * (i + 1)) return done(fail("selftest: all-reduce SUM wrong at %d (%g, expected %g)", i, rd[i], tri * (i + 1)));
+        if (ru[i] != (unsigned)((c->world - 1) * 7 + i)) return done(fail("selftest: all-reduce MAX wrong at %d", i));
+        if (c->world > 1 && rr[i] != (double)(prev + 1) * (i + 1)) return done(fail("selftest: exchange wrong at %d", i));
+    }
+    return done(0);
+}
+
+}  // extern "C"

@@ -13,24 +13,68 @@ constexpr int kBlock = 256;        // 4 wavefronts
 constexpr int kWave = 64;
 constexpr int kMaxPartialBlocks = 2048;  // cap for per-block partial sums (reduced in fixed order)
 
-// A volume plus the z-window [z0, z0 + nz) of OUTPUT planes a launch covers.  Indexing is always global (arrays are
-// full size, clamping uses D); the window only restricts which planes a kernel writes.  A single GPU uses the full
-// window; the z-slab decomposition (SlabEngine) launches every stage on its own slab (+ the ghost planes it recomputes).
+// A volume plus the z-window(s) of OUTPUT planes a launch covers.  Indexing is always global in z (clamping uses D); the
+// window only restricts which planes a kernel writes.  A single GPU uses the full window.  The z-slab decomposition
+// (slab.hip) launches every stage on its own slab (+ the ghost planes it recomputes) and allocates SLAB-LOCAL arrays: `V` is
+// the element stride between the channels / chains of an array (planes held * H * W), while the base pointers handed to the
+// kernels are shifted down by (first held plane) * H * W elements, so that global z indexing lands inside the allocation.
+// `Vg` = D * H * W is the voxel count of the whole volume (counter of the in-kernel Philox noise: a slab draws the noise
+// the full volume would).  The squaring-step kernels accept a second window [z0b, z0b + nzb) -- the two boundary strips
+// of a slab in one launch (slab.hip: interior / boundary split around a ghost-plane exchange).
 struct Vol {
     int D, H, W;
-    int64_t V;  // D*H*W
+    int64_t V;   // channel / chain stride in elements
     int z0, nz;
+    int z0b, nzb;
+    int64_t Vg;  // D*H*W
 };
 
-__host__ __device__ inline Vol make_vol(int D, int H, int W) { return Vol{D, H, W, (int64_t)D * H * W, 0, D}; }
+__host__ __device__ inline Vol make_vol(int D, int H, int W) {
+    return Vol{D, H, W, (int64_t)D * H * W, 0, D, 0, 0, (int64_t)D * H * W};
+}
 
 __host__ __device__ inline Vol window(Vol v, int zlo, int zhi) {
     zlo = zlo < 0 ? 0 : zlo;
     zhi = zhi > v.D ? v.D : zhi;
     v.z0 = zlo;
     v.nz = zhi > zlo ? zhi - zlo : 0;
+    v.z0b = 0;
+    v.nzb = 0;
     return v;
 }
+
+// two disjoint windows [lo0, hi0) and [lo1, hi1), lo1 >= hi0 (an empty first window is replaced by the second)
+__host__ __device__ inline Vol window2(Vol v, int lo0, int hi0, int lo1, int hi1) {
+    v = window(v, lo0, hi0);
+    lo1 = lo1 < 0 ? 0 : lo1;
+    hi1 = hi1 > v.D ? v.D : hi1;
+    const int n1 = hi1 > lo1 ? hi1 - lo1 : 0;
+    if (v.nz == 0) {
+        v.z0 = lo1;
+        v.nz = n1;
+    } else {
+        v.z0b = lo1;
+        v.nzb = n1;
+    }
+    return v;
+}
+
+// z-segments of a (two-window) marching launch: segments never straddle the two windows
+__host__ __device__ inline int vol_nseg(const Vol& v, int seg_len) {
+    return (v.nz + seg_len - 1) / seg_len + (v.nzb + seg_len - 1) / seg_len;
+}
+__device__ __forceinline__ void seg_range(const Vol& v, int seg, int seg_len, int& z0, int& z1) {
+    const int na = (v.nz + seg_len - 1) / seg_len;
+    if (seg < na) {
+        z0 = v.z0 + seg * seg_len;
+        z1 = min(z0 + seg_len, v.z0 + v.nz);
+    } else {
+        z0 = v.z0b + (seg - na) * seg_len;
+        z1 = min(z0 + seg_len, v.z0b + v.nzb);
+    }
+}
+// voxels a launch writes (sizes the partial-sum grids)
+__host__ __device__ inline int64_t win_voxels(const Vol& v) { return (int64_t)(v.nz + v.nzb) * v.H * v.W; }
 
 // Segment length of the z-marching kernels.  32 planes amortise the run-in of a segment (2R .. 4S extra planes) when the
 // launch still has enough workgroups to fill 256 CUs; smaller volumes trade run-in overhead for parallelism, down to

@@ -1,0 +1,141 @@
+// The context behind include/irsgmcmc.h (shared by api.hip and slab.hip): workspace views, variant prediction, error plumbing.
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+
+#include "kernels.h"
+#include "scalar_kernels.h"
+
+struct irs_comm;
+
+namespace irs {
+
+int fail(const char* fmt, ...);  // formats irs_last_error(), returns 1 (api.hip)
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return irs::fail("%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+#define LAUNCH_CHECK()                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = hipGetLastError();                                                          \
+        if (e_ != hipSuccess) return irs::fail("kernel launch failed: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+inline int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+inline bool use_lds_exp() { return env_int("IRS_EXP_LDS", 1) != 0; }
+
+// z-slab decomposition (slab.hip): this rank owns the planes [a, b) of the volume and HOLDS the planes [lo, hi) (its slab
+// plus a ghost margin) of every array; everything else about the context is the single-GPU one.
+struct SlabInfo {
+    bool on = false;
+    int rank = 0, world = 1;
+    int a = 0, b = 0;    // owned planes
+    int lo = 0, hi = 0;  // held planes
+    int margin = 0;      // ghost planes held beyond a neighbour-facing edge
+    int gmax = 4;        // widest ghost zone one exchange may carry (communication-avoiding blocks of squaring steps)
+    int min_slab = 0;    // smallest slab of any rank: a rank cannot send more planes than it owns
+    bool has_lo = false, has_hi = false;  // neighbours below / above
+};
+
+}  // namespace irs
+
+struct irs_ctx {
+    irs_config cfg;
+    irs::DevCfg dcfg;
+    irs::Vol vol, volv;
+    bool ffd;
+    int C;
+    irs::LinTables lin;
+    irs::Taps sob;
+    irs::SplineTaps spl[3];
+    char* slab;
+    size_t slab_bytes;
+    // workspace views (slab mode: UNSHIFTED bases of slab-local arrays; slab.hip applies the plane shift)
+    float *steps, *tmpA, *tmpB, *vs, *gA, *gB, *warped, *z, *sigM, *fhat, *gM, *dense;
+    double *stat_partials, *energy_partials, *nll_partials;
+    double *stat_sum, *energy_sum, *nll_sum;  // reduced partial sums (staged / slab path)
+    unsigned* dmax;  // [no_steps + 1][C][4] max |d_k| in voxels per axis (float bits), by-product of the forward steps
+    float* cmm;      // coarse (8^3 cells) min / max of d_k for the source boxes of the any-radius adjoint (kernels.h)
+    unsigned* hint = nullptr;  // pinned host copy of dmax as of the last finished transition (written by finalize_kernel, read
+                     // by the host WITHOUT synchronisation: a hint that only decides which variants are launched)
+    irs::DevState* state;
+    int fhat_chains;
+    bool fixed_set;
+    int nll_blocks;
+    hipEvent_t ev[8];
+    hipEvent_t ev_bwd[64];
+    hipEvent_t ra_ev[4];     // end of the last transitions: bounds how far the host may run ahead of the device
+    uint64_t n_enqueued = 0;
+    // ---- z-slab decomposition (slab.hip)
+    irs::SlabInfo sl;
+    irs_comm* comm = nullptr;      // not owned
+    hipStream_t cs = nullptr;      // communication stream (owned)
+    hipEvent_t sev[24];            // 0..15 rotating producer / receive events of the exchanges, 16.. pairs of the all-reduces
+    unsigned* used_dev = nullptr;  // [no_steps] ghost widths the current transition was planned with (device copy for validation)
+    double* hsum = nullptr;        // pinned: host copy of small reductions in exact mode
+    int pred[32];                  // host: ghost-width plan source (bounds of the last exact transition); -1 = none
+    bool have_pred = false;
+    uint64_t slab_exchanged_bytes = 0;  // bookkeeping for tests / reports
+    uint64_t slab_exchanges = 0;
+    uint64_t slab_exact = 0;           // transitions run in measuring mode
+    int last_nf = 0, last_nb = 0;      // exchange rounds of the last transition
+};
+
+namespace irs {
+
+constexpr int kHintWords = 4 * IRS_MAX_CHAINS * 32 + 8;  // dmax scratch + [flags] (slab.hip: misprediction flag)
+
+// Host-side guess of "max |d_k| stays well below `bound`" from the bounds of the last transition the host has seen
+// finish (never waited for: stale by a transition or two, and displacements move by O(lr) per transition).  Only a launch
+// decision: the kernels that remain are correct for any displacement, so a wrong guess costs time, not parity.
+inline bool predicted_below(const irs_ctx* c, int k, float bound) {
+    const int mode = env_int("IRS_PREDICT_VARIANTS", 1);  // 0: always launch every variant; 2: always predict small (tests)
+    if (mode == 2) return true;
+    if (!mode || !c->hint) return false;
+    const volatile unsigned* h = c->hint + (size_t)k * c->C * 4;
+    float m = 0.0f;
+    for (int i = 0; i < c->C * 4; ++i) {
+        const unsigned bits = h[i];
+        float f;
+        memcpy(&f, &bits, sizeof(f));
+        if (!(f >= 0.0f)) return false;  // NaN / garbage
+        m = f > m ? f : m;
+    }
+    return m < bound;
+}
+inline bool predicted_small(const irs_ctx* c, int k) { return predicted_below(c, k, 0.75f); }
+
+// Layouts of the INTERNAL fields of the fused path (exp_kernels.hip: Lay3; bits 1 displacement in, 2 gradient in, 4 out):
+// d_1 .. d_{n-1} and the gradients handed from one adjoint step to the next are interleaved ([V][3]); everything that crosses
+// into another kernel family -- the velocity in, d_n into the warp, the gradient into the first and out of the last adjoint
+// step -- stays planar like the reference's tensors.
+inline bool aos_enabled() { return use_lds_exp() && env_int("IRS_AOS", 1) != 0; }
+inline int fwd_lay(const irs_ctx* c, int k) {
+    if (!aos_enabled()) return 0;
+    return (k > 0 ? 1 : 0) | (k < c->cfg.no_steps - 1 ? 4 : 0);
+}
+inline int bwd_lay(const irs_ctx* c, int k) {
+    if (!aos_enabled()) return 0;
+    return (k > 0 ? 1 : 0) | (k < c->cfg.no_steps - 1 ? 2 : 0) | (k > 0 ? 4 : 0);
+}
+
+inline void prescale_factors(Vol vol, int no_steps, float s[3]) {
+    const double p = 1.0 / (double)(1 << no_steps);
+    s[0] = (float)(2.0 / (double)(vol.W - 1) * p);  // x <-> W, y <-> H, z <-> D
+    s[1] = (float)(2.0 / (double)(vol.H - 1) * p);
+    s[2] = (float)(2.0 / (double)(vol.D - 1) * p);
+}
+
+// shared by irs_create and irs_slab_create (api.hip)
+int create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out);
+int check_io(const irs_ctx* c, const irs_io* io, const char* who);
+void slab_release(irs_ctx* c);  // slab.hip
+
+}  // namespace irs

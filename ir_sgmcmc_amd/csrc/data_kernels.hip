@@ -54,7 +54,7 @@ void launch_data_bwd(int mode, const float* fhat_or_fixed, int64_t f_stride, con
 }
 
 int stats_blocks(Vol vol) {
-    const int64_t b = (vol.V + kBlock - 1) / kBlock;
+    const int64_t b = (win_voxels(vol) + kBlock - 1) / kBlock;
     return (int)(b < kMaxPartialBlocks ? b : kMaxPartialBlocks);
 }
 

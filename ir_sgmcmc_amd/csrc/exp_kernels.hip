@@ -430,6 +430,13 @@ size_t coarse_minmax_bytes(Vol vol, int C) {
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                              Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, int lay,
                              float* cmm, hipStream_t st) {
+    if (vol.nzb > 0) {  // two windows (slab boundary strips): this rarely selected kernel takes them one launch each
+        launch_exp_step_bwd_lds(G, dk, gout, prescale_in, no_steps, C, window(vol, vol.z0, vol.z0 + vol.nz), lin, dmax, halo,
+                                gather_radius, gscale, lay, cmm, st);
+        launch_exp_step_bwd_lds(G, dk, gout, prescale_in, no_steps, C, window(vol, vol.z0b, vol.z0b + vol.nzb), lin, dmax, halo,
+                                gather_radius, gscale, lay, cmm, st);
+        return;
+    }
     TileGrid tz;
     const dim3 grid = exp_grid(vol, C, &tz);
     const Scale3L sc = make_scale_l(vol, no_steps);
@@ -595,7 +602,8 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                        (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
     if (hs <= r_lo || (hs > R && !(R == 2 && own_rest))) return;  // another variant of this step owns the chain
     const int ox = tbx * MTX, oy = tby * MTY;
-    const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
+    int z0, z1;
+    seg_range(vol, seg, seg_len, z0, z1);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
     const Lay3 LD = lay3(lay & 1, V), LG = lay3(lay & 2, V), LO = lay3(lay & 4, V);
@@ -859,8 +867,8 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
                                Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
                                hipEvent_t after_primary, hipStream_t st) {
     static const int seg_env = getenv("IRS_MARCH_SEG") ? atoi(getenv("IRS_MARCH_SEG")) : 0;
-    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * C, 8, seg_env);
-    const int nseg = (vol.nz + seg_len - 1) / seg_len;
+    const int seg_len = pick_seg_len(vol.nz + vol.nzb, (int64_t)((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * C, 8, seg_env);
+    const int nseg = vol_nseg(vol, seg_len);  // segments of both windows
     const dim3 tiles((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     const Scale3L sc = make_scale_l(vol, no_steps);
@@ -929,7 +937,8 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
         if (need <= h_lo || need > h_hi) return;
     }
     const int ox = tbx * FTX, oy = tby * FTY;
-    const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
+    int z0, z1;
+    seg_range(vol, seg, seg_len, z0, z1);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
     const Lay3 LD = lay3(lay & 1, V), LO = lay3(lay & 4, V);
@@ -1118,8 +1127,8 @@ __global__ __launch_bounds__(kFwdBlock, R == 1 ? IRS_FWD_WAVES : 1) void exp_fwd
 void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
                                const unsigned* dmax_in, unsigned* dmax_out, bool only_r1, int lay, hipStream_t st) {
     static const int seg_env = getenv("IRS_MARCH_SEG_FWD") ? atoi(getenv("IRS_MARCH_SEG_FWD")) : 0;
-    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + FTX - 1) / FTX) * ((vol.H + FTY - 1) / FTY) * C, 8, seg_env);
-    const int nseg = (vol.nz + seg_len - 1) / seg_len;
+    const int seg_len = pick_seg_len(vol.nz + vol.nzb, (int64_t)((vol.W + FTX - 1) / FTX) * ((vol.H + FTY - 1) / FTY) * C, 8, seg_env);
+    const int nseg = vol_nseg(vol, seg_len);  // segments of both windows
     const dim3 tiles((vol.W + FTX - 1) / FTX, (vol.H + FTY - 1) / FTY, (unsigned)(nseg * C));
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     const Scale3L sc = make_scale_l(vol, no_steps);

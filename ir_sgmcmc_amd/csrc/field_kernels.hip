@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kBlock) void perturb_kernel(const float* __restrict
     float n[2][3];
     if (!eps) {
         const uint64_t it = dev_iter ? *dev_iter : iteration;
-        const uint64_t idx = (uint64_t)chain * (uint64_t)V + (uint64_t)voxa;
+        const uint64_t idx = (uint64_t)chain * (uint64_t)vol.Vg + (uint64_t)voxa;  // global voxel index: slab-independent noise
         const U4 r = philox4x32_10(U4{(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)it, 0x5347u ^ (uint32_t)(it >> 32)},
                                    (uint32_t)seed, (uint32_t)(seed >> 32));
         uint32_t w[6];
@@ -263,7 +263,7 @@ __device__ __forceinline__ void grid_point(const float* __restrict__ d, const fl
     g[0] = __fadd_rn(lin.x[x], d[cb3 + vox]);
     g[1] = __fadd_rn(lin.y[y], d[cb3 + vol.V + vox]);
     g[2] = __fadd_rn(lin.z[z], d[cb3 + 2 * vol.V + vox]);
-    jitter_point(g, unif, jt, cb3, chain, vox, vol.V);
+    jitter_point(g, unif, jt, cb3, chain, vox, vol.V, vol.Vg);
 }
 
 // `gradm` (optional, (C,3,D,H,W)): d(warped)/d(d_last) = the trilinear gradient of the moving image at the sampling

@@ -31,7 +31,7 @@ inline Jitter make_jitter(float alpha, Vol vol, uint64_t seed, uint64_t iteratio
 
 // g += transform_coordinates(U(-alpha, alpha)); `unif` (C,3,D,H,W) injected U[0,1) draws or nullptr -> Philox2x32-10
 __device__ __forceinline__ void jitter_point(float (&g)[3], const float* __restrict__ unif, const Jitter& jt, int64_t cb3,
-                                             int chain, int64_t vox, int64_t V) {
+                                             int chain, int64_t vox, int64_t V, int64_t Vg) {
     if (jt.alpha <= 0.0f) return;
     float u[3];
     if (unif) {
@@ -40,7 +40,7 @@ __device__ __forceinline__ void jitter_point(float (&g)[3], const float* __restr
         u[2] = unif[cb3 + 2 * V + vox];
     } else {
         const uint64_t it = jt.dev_iter ? *jt.dev_iter : jt.iteration;
-        const uint64_t idx = (uint64_t)chain * (uint64_t)V + (uint64_t)vox;  // < 2^36 (dims_ok, chains)
+        const uint64_t idx = (uint64_t)chain * (uint64_t)Vg + (uint64_t)vox;  // global voxel index, < 2^36 (dims_ok, chains)
         const U2 r = philox2x32_10(U2{(uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)it << 4)}, key_mix(jt.seed, it, 0x554Eu));
         u[0] = u01_21(r.x >> 11);
         u[1] = u01_21(r.y >> 11);

@@ -63,56 +63,79 @@ def lognormal_init(w_reg, dof, nu=1.0):
     return loc, math.log(4.0) + math.log(loc)
 
 
+def irs_config(cfg: EngineConfig):
+    """EngineConfig -> the C struct of include/irsgmcmc.h"""
+    c = L.IrsConfig()
+    c.dims[:] = list(cfg.dims)
+    c.cps[:] = list(cfg.cps) if cfg.cps else [0, 0, 0]
+    c.no_chains, c.no_steps = cfg.no_chains, cfg.no_steps
+    c.sobolev_s = cfg.sobolev_s or 0
+    if c.sobolev_s:
+        k = sobolev_kernel_1d(cfg.sobolev_s, cfg.sobolev_lambda)
+        for i, x in enumerate(k):
+            c.sobolev_kernel[i] = float(x)
+    c.lr = cfg.lr
+    c.uniform_alpha = cfg.uniform_noise or 0.0
+    c.virtual_decimation = int(cfg.virtual_decimation)
+    c.data_loss = L.IRS_DATA_GMM_LCC if cfg.data_loss == 'GMM' else L.IRS_DATA_SSD
+    c.lcc_s, c.gmm_components, c.ssd_sigma = cfg.lcc_s, cfg.gmm_components, cfg.ssd_sigma
+    c.gmm_lr_log_std, c.gmm_lr_logits, c.gmm_lr_decay = cfg.gmm_lr_log_std, cfg.gmm_lr_logits, cfg.gmm_lr_decay
+    c.adam_beta1, c.adam_beta2, c.adam_eps = 0.9, 0.999, 1e-8
+    c.scale_prior_loc, c.scale_prior_scale = cfg.scale_prior
+    conc = list(cfg.dirichlet_alpha)
+    if len(conc) == 1:
+        conc = conc * cfg.gmm_components
+    for i, x in enumerate(conc):
+        c.dirichlet_concentration[i] = float(x)
+    c.reg_loss = {'RegLoss_L2': L.IRS_REG_L2, 'RegLoss_LogNormal': L.IRS_REG_LOGNORMAL, 'RegLoss_Student': L.IRS_REG_STUDENT,
+                  'RegLoss_LogNormal_L2': L.IRS_REG_LOGNORMAL_L2}[cfg.reg_loss]
+    c.reg_learnable = int(cfg.reg_learnable)
+    c.w_reg, c.dof = cfg.w_reg, cfg.dof
+    c.reg_lr0, c.reg_lr1, c.reg_lr_decay = cfg.reg_lr[0], cfg.reg_lr[1], cfg.reg_lr_decay
+    c.loc_prior_nu = cfg.loc_prior_nu
+    c.loc_prior_w_reg = cfg.w_reg if cfg.loc_prior_w_reg is None else cfg.loc_prior_w_reg
+    c.reg_scale_prior_loc, c.reg_scale_prior_scale = cfg.reg_scale_prior
+    shape = 0.5 * cfg.dof  # parse_config.py:136-140
+    c.w_reg_prior_shape, c.w_reg_prior_rate = shape, 1.0 / shape
+    if cfg.reg_loss == 'RegLoss_Student':
+        c.w_reg_prior_shape, c.w_reg_prior_rate = float(cfg.student[0]), float(cfg.student[1])
+    c.seed = cfg.seed
+    return c
+
+
+def _on_device(fn):
+    """run a method with the engine's device current (launches go to the stream of THAT device)"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class TransitionEngine:
     def __init__(self, cfg: EngineConfig, device='cuda:0'):
         self.cfg = cfg
         self.device = torch.device(device)
         self.lib = L.load()
-        c = L.IrsConfig()
-        c.dims[:] = list(cfg.dims)
-        c.cps[:] = list(cfg.cps) if cfg.cps else [0, 0, 0]
-        c.no_chains, c.no_steps = cfg.no_chains, cfg.no_steps
-        c.sobolev_s = cfg.sobolev_s or 0
-        if c.sobolev_s:
-            k = sobolev_kernel_1d(cfg.sobolev_s, cfg.sobolev_lambda)
-            for i, x in enumerate(k):
-                c.sobolev_kernel[i] = float(x)
-        c.lr = cfg.lr
-        c.uniform_alpha = cfg.uniform_noise or 0.0
-        c.virtual_decimation = int(cfg.virtual_decimation)
-        c.data_loss = L.IRS_DATA_GMM_LCC if cfg.data_loss == 'GMM' else L.IRS_DATA_SSD
-        c.lcc_s, c.gmm_components, c.ssd_sigma = cfg.lcc_s, cfg.gmm_components, cfg.ssd_sigma
-        c.gmm_lr_log_std, c.gmm_lr_logits, c.gmm_lr_decay = cfg.gmm_lr_log_std, cfg.gmm_lr_logits, cfg.gmm_lr_decay
-        c.adam_beta1, c.adam_beta2, c.adam_eps = 0.9, 0.999, 1e-8
-        c.scale_prior_loc, c.scale_prior_scale = cfg.scale_prior
-        conc = list(cfg.dirichlet_alpha)
-        if len(conc) == 1:
-            conc = conc * cfg.gmm_components
-        for i, x in enumerate(conc):
-            c.dirichlet_concentration[i] = float(x)
-        c.reg_loss = {'RegLoss_L2': L.IRS_REG_L2, 'RegLoss_LogNormal': L.IRS_REG_LOGNORMAL, 'RegLoss_Student': L.IRS_REG_STUDENT,
-                      'RegLoss_LogNormal_L2': L.IRS_REG_LOGNORMAL_L2}[cfg.reg_loss]
-        c.reg_learnable = int(cfg.reg_learnable)
-        c.w_reg, c.dof = cfg.w_reg, cfg.dof
-        c.reg_lr0, c.reg_lr1, c.reg_lr_decay = cfg.reg_lr[0], cfg.reg_lr[1], cfg.reg_lr_decay
-        c.loc_prior_nu = cfg.loc_prior_nu
-        c.loc_prior_w_reg = cfg.w_reg if cfg.loc_prior_w_reg is None else cfg.loc_prior_w_reg
-        c.reg_scale_prior_loc, c.reg_scale_prior_scale = cfg.reg_scale_prior
-        shape = 0.5 * cfg.dof  # parse_config.py:136-140
-        c.w_reg_prior_shape, c.w_reg_prior_rate = shape, 1.0 / shape
-        if cfg.reg_loss == 'RegLoss_Student':
-            c.w_reg_prior_shape, c.w_reg_prior_rate = float(cfg.student[0]), float(cfg.student[1])
-        c.seed = cfg.seed
-        self._c = c
-        ctx = C.c_void_p()
+        self._c = c = irs_config(cfg)
         with torch.cuda.device(self.device):
-            L.check(self.lib.irs_create(C.byref(c), C.byref(ctx)))
-        self._ctx = ctx
+            self._ctx = self._create(c)
         self._keep = {}
         if cfg.reg_loss == 'RegLoss_LogNormal':
             st = self.state()
             st.reg_param[0], st.reg_param[1] = lognormal_init(cfg.w_reg, cfg.dof)
             self.set_state(st)
+
+    def _stream(self):
+        """the engine's device's current stream (not the current device's: an engine on cuda:1 stays there)"""
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _create(self, c):
+        ctx = C.c_void_p()
+        L.check(self.lib.irs_create(C.byref(c), C.byref(ctx)))
+        return ctx
 
     def __del__(self):
         ctx, self._ctx = getattr(self, '_ctx', None), None
@@ -127,17 +150,20 @@ class TransitionEngine:
     def workspace_bytes(self):
         return int(self.lib.irs_workspace_bytes(self._ctx))
 
+    @_on_device
     def state(self):
         st = L.IrsState()
-        L.check(self.lib.irs_get_state(self._ctx, C.byref(st), L.stream_ptr()))
+        L.check(self.lib.irs_get_state(self._ctx, C.byref(st), self._stream()))
         return st
 
+    @_on_device
     def set_state(self, st):
-        L.check(self.lib.irs_set_state(self._ctx, C.byref(st), L.stream_ptr()))
+        L.check(self.lib.irs_set_state(self._ctx, C.byref(st), self._stream()))
 
+    @_on_device
     def scalars(self):
         sc = L.IrsScalars()
-        L.check(self.lib.irs_get_scalars(self._ctx, C.byref(sc), L.stream_ptr()))
+        L.check(self.lib.irs_get_scalars(self._ctx, C.byref(sc), self._stream()))
         n = self.cfg.no_chains
         return {k: [getattr(sc, k)[i] for i in range(n)] for k in ('alpha', 'data_term', 'reg_term', 'reg_energy', 'n_mask')}
 
@@ -164,27 +190,30 @@ class TransitionEngine:
             t = t[:1]
         return t.contiguous()
 
+    @_on_device
     def prepare(self, fixed, moving):
         """Normalise dict inputs (collapse expanded chains) and pre-normalise the fixed image for the LCC map."""
         fixed = {k: self._base(v) for k, v in fixed.items() if k in ('im', 'mask')}
         moving = {k: self._base(v) for k, v in moving.items() if k in ('im',)}
         self._keep['fixed'], self._keep['moving'] = fixed, moving
         L.check(self.lib.irs_set_fixed(self._ctx, L.dev_ptr(fixed['im'], torch.float32), fixed['im'].shape[0],
-                                       L.stream_ptr()))
+                                       self._stream()))
         return fixed, moving
 
+    @_on_device
     def gmm_init(self, fixed, moving, v_sample=None, warm_up=25):
         """Trainer.__GMM_init (trainer.py:529-547)."""
         io = self._io(fixed, moving, None)
         L.check(self.lib.irs_gmm_init(self._ctx, C.byref(io), L.dev_ptr(v_sample, torch.float32, allow_none=True),
-                                      warm_up, L.stream_ptr()))
+                                      warm_up, self._stream()))
 
+    @_on_device
     def transition(self, fixed, moving, v, sigma=None, eps=None, unif=None, outputs=None, timed=False):
         """One `_SGLD_transition`; updates `v` in place.  outputs: dict of preallocated tensors to fill."""
         io = self._io(fixed, moving, v, sigma, eps, unif, outputs)
         if timed:
             tm = L.IrsTimings()
-            L.check(self.lib.irs_transition_timed(self._ctx, C.byref(io), L.stream_ptr(), C.byref(tm)))
+            L.check(self.lib.irs_transition_timed(self._ctx, C.byref(io), self._stream(), C.byref(tm)))
             return {n: getattr(tm, n) for n, _ in tm._fields_}
-        L.check(self.lib.irs_transition(self._ctx, C.byref(io), L.stream_ptr()))
+        L.check(self.lib.irs_transition(self._ctx, C.byref(io), self._stream()))
         return None

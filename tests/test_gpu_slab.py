@@ -1,8 +1,12 @@
-"""z-slab decomposition (ir_sgmcmc_amd/slab.py): the staged, windowed transition must reproduce the fused one.
+"""z-slab decomposition inside the library (csrc/slab.hip, irs_slab_transition): the slab schedule must reproduce the fused
+single-GPU transition.
 
-1 rank: the stage sequence over the full window == irs_transition.
-2 ranks: two processes share cuda:0 and exchange ghost planes over gloo (host staging) -- the same code path that uses
-RCCL point-to-point on a multi-GPU node; the assembled result must match the single-engine transition."""
+1 rank      the slab context over the whole volume == irs_transition.
+2 / 3 ranks processes SHARING cuda:0 run the library's schedule -- slab-local arrays, ghost-plane exchanges in rounds,
+            interior / boundary split, all-reduces -- over the rehearsal transport (callbacks carried by gloo with host
+            staging; RCCL refuses two ranks on one device).  On a multi-GPU node the only thing that changes is the leaf
+            that moves the bytes (csrc/comm.hip).  The assembled result must match the single-engine transition.
+BASELINE.json config 4 (256^3, SSD, z-slabs) runs at its own size on two ranks."""
 import os
 import socket
 
@@ -14,50 +18,71 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+T = 3  # transitions: the first measures the ghost widths (exact mode), the second and third run from predicted widths
 
 
-def _setup(N, C, data_loss, seed=0):
+def _setup(N, C, data_loss, seed=0, vd=True, amp=9.0, reg='RegLoss_LogNormal', with_noise=True):
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from ir_sgmcmc_amd.engine import EngineConfig
     from oracle import ops as O
-    cfg = EngineConfig(dims=(N, N, N), no_chains=C, data_loss=data_loss, virtual_decimation=True, lcc_s=1,
-                       reg_loss='RegLoss_LogNormal', reg_learnable=True, seed=seed)
+    cfg = EngineConfig(dims=(N, N, N), no_chains=C, data_loss=data_loss, virtual_decimation=vd, lcc_s=1,
+                       reg_loss=reg, reg_learnable=(reg == 'RegLoss_LogNormal'), seed=seed)
     f1, m1 = synthetic_pair((N, N, N), seed=3)
-    fixed = {k: v.unsqueeze(0).to(DEV) for k, v in f1.items() if k != 'seg'}
-    moving = {k: v.unsqueeze(0).to(DEV) for k, v in m1.items() if k != 'seg'}
+    fixed = {k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'}
+    moving = {k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'}
     g = torch.Generator().manual_seed(17)
-    v0 = O.separable_conv3d_replicate(9.0 * torch.randn(C, 3, N, N, N, generator=g), O.sobolev_kernel_1d(3, 0.5)).contiguous()
-    noise = [(torch.randn(C, 3, N, N, N, generator=g), torch.rand(C, 3, N, N, N, generator=g)) for _ in range(2)]
+    v0 = O.separable_conv3d_replicate(amp * torch.randn(C, 3, N, N, N, generator=g), O.sobolev_kernel_1d(3, 0.5)).contiguous()
+    # without injected noise every rank draws the in-kernel Philox noise of ITS planes of the same field
+    noise = [(torch.randn(C, 3, N, N, N, generator=g), torch.rand(C, 3, N, N, N, generator=g)) if with_noise else (None, None)
+             for _ in range(T)]
     return cfg, fixed, moving, v0, noise
 
 
-def _run(engine_cls, cfg, fixed, moving, v0, noise):
-    eng = engine_cls(cfg, DEV)
-    fd, md = eng.prepare(fixed, moving)
+def _run_fused(cfg, fixed, moving, v0, noise):
+    from ir_sgmcmc_amd.engine import TransitionEngine
+    eng = TransitionEngine(cfg, DEV)
+    fd, md = eng.prepare({k: v.to(DEV) for k, v in fixed.items()}, {k: v.to(DEV) for k, v in moving.items()})
     eng.gmm_init(fd, md)
     v = v0.to(DEV).contiguous()
     disp = torch.zeros(cfg.no_chains, 3, *cfg.dims, device=DEV)
     scal = []
     for eps, unif in noise:
-        eng.transition(fd, md, v, None, eps.to(DEV), unif.to(DEV), {'displacement': disp})
+        eng.transition(fd, md, v, None, eps.to(DEV) if eps is not None else None, unif.to(DEV) if unif is not None else None,
+                       {'displacement': disp})
+        scal.append(eng.scalars())
+    return v.cpu(), disp.cpu(), scal, eng.state()
+
+
+def _run_slab(cfg, fixed, moving, v0, noise, comm=None, **kw):
+    from ir_sgmcmc_amd.slab import SlabEngine
+    eng = SlabEngine(cfg, DEV, comm, **kw)
+    fd, md = eng.prepare(fixed, moving)
+    eng.gmm_init(fd, md)
+    v = eng.local(v0)
+    disp = eng.new_local(3)
+    scal = []
+    for eps, unif in noise:
+        eng.transition(fd, md, v, None, eng.local(eps) if eps is not None else None, eng.local(unif) if unif is not None else None,
+                       {'displacement': disp})
         scal.append(eng.scalars())
     return eng, v, disp, scal
 
 
 @pytest.mark.parametrize('data_loss,C', [('GMM', 1), ('SSD', 2)])
 def test_slab_single_rank_equals_fused(data_loss, C):
-    from ir_sgmcmc_amd.engine import TransitionEngine
-    from ir_sgmcmc_amd.slab import SlabEngine
     cfg, fixed, moving, v0, noise = _setup(24, C, data_loss)
-    _, v_ref, d_ref, s_ref = _run(TransitionEngine, cfg, fixed, moving, v0, noise)
-    eng, v, d, s = _run(SlabEngine, cfg, fixed, moving, v0, noise)
+    v_ref, d_ref, s_ref, st_ref = _run_fused(cfg, fixed, moving, v0, noise)
+    eng, v, d, s = _run_slab(cfg, fixed, moving, v0, noise)
+    assert (eng.a, eng.b, eng.lo, eng.hi) == (0, 24, 0, 24)
     # identical kernels; only the fp64 summation order of the partial sums differs (reduce -> all-reduce -> scalar kernel)
-    assert float((v - v_ref).abs().max()) <= 1e-5 * float(v_ref.abs().max())
-    assert float((d - d_ref).abs().max()) <= 1e-5
+    assert float((v.cpu() - v_ref).abs().max()) <= 1e-5 * float(v_ref.abs().max())
+    assert float((d.cpu() - d_ref).abs().max()) <= 1e-5
     for a, b in zip(s, s_ref):
         for key in ('alpha', 'data_term', 'reg_term', 'reg_energy'):
             np.testing.assert_allclose(a[key], b[key], rtol=1e-6)
-    assert eng.state().iteration == 2
+    st = eng.status()
+    assert eng.state().iteration == T and st['transitions'] == T and st['exact_transitions'] == 1 and st['mispredictions'] == 0
+    assert st['exchanges'] == 0
 
 
 def _free_port():
@@ -68,45 +93,84 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, data_loss, C, N):
+def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from ir_sgmcmc_amd.engine import TransitionEngine
-        from ir_sgmcmc_amd.slab import SlabEngine
-        cfg, fixed, moving, v0, noise = _setup(N, C, data_loss)
-        eng, v, d, s = _run(SlabEngine, cfg, fixed, moving, v0, noise)
-        assert (eng.a, eng.b) == ((rank * N) // world, ((rank + 1) * N) // world) and eng.exchanged_planes > 0
-        assert getattr(eng, "mispredictions", 0) == 0  # second transition ran in predicted-width mode
-        v_full = eng.gather_slabs(v)
-        d_full = eng.gather_slabs(d)
+        from ir_sgmcmc_amd.slab import SlabComm
+        torch.cuda.set_device(0)
+        comm = SlabComm.rehearsal(DEV)
+        comm.selftest()
+        cfg, fixed, moving, v0, noise = _setup(N, C, data_loss, vd=vd, amp=amp, reg=reg, with_noise=N < 128)
+        eng, v, d, s = _run_slab(cfg, fixed, moving, v0, noise, comm, ghost_max=ghost_max)
+        assert (eng.a, eng.b) == ((rank * N) // world, ((rank + 1) * N) // world)
+        assert eng.hi - eng.lo < N  # slab-local arrays
+        st = eng.status()
+        assert st['exchanges'] > 0 and st['mispredictions'] == 0 and st['exact_transitions'] == 1, st
+        v_full, d_full = eng.gather(v), eng.gather(d)
         if rank == 0:
-            _, v_ref, d_ref, s_ref = _run(TransitionEngine, cfg, fixed, moving, v0, noise)
+            v_ref, d_ref, s_ref, _ = _run_fused(cfg, fixed, moving, v0, noise)
             dv = float((v_full - v_ref).abs().max()) / float(v_ref.abs().max())
             dd = float((d_full - d_ref).abs().max())
             ds = max(abs(a[k][c] - b[k][c]) / max(abs(b[k][c]), 1e-30) for a, b in zip(s, s_ref)
                      for k in ('alpha', 'data_term', 'reg_term') for c in range(C))
-            q.put((dv, dd, ds, eng.exchanged_planes))
+            q.put((dv, dd, ds, st))
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('data_loss,C,N,world', [('GMM', 1, 32, 2), ('SSD', 2, 24, 2), ('GMM', 1, 36, 3)])
-def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world):
+def _launch(world, *args):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, data_loss, C, N)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q) + args) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(300)
+        p.join(600)
         assert p.exitcode == 0
-    dv, dd, ds, planes = q.get(timeout=10)
+    return q.get(timeout=10)
+
+
+@pytest.mark.parametrize('data_loss,C,N,world,ghost_max', [('GMM', 1, 32, 2, 4), ('SSD', 2, 24, 2, 2), ('GMM', 1, 48, 3, 4),
+                                                           ('SSD', 1, 40, 2, 1)])
+def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max):
+    dv, dd, ds, st = _launch(world, data_loss, C, N, True, 9.0, 'RegLoss_LogNormal', ghost_max)
     from tests._report import check
-    T = f'slab/{data_loss}_C{C}_N{N}_ranks{world}'
-    check(T, 'v_new (rel to max)', dv, 0.0, 1e-5)
-    check(T, 'displacement [voxels]', dd, 0.0, 1e-5)
-    check(T, 'loss terms (rel)', ds, 0.0, 1e-6)
-    assert planes > 0
+    name = f'slab/{data_loss}_C{C}_N{N}_ranks{world}_g{ghost_max}'
+    check(name, 'v_new (rel to max)', dv, 0.0, 1e-5)
+    check(name, 'displacement [voxels]', dd, 0.0, 1e-5)
+    check(name, 'loss terms (rel)', ds, 0.0, 1e-6)
+    # communication-avoiding rounds: 12 squaring steps in fewer forward exchanges than steps
+    assert st['last_fwd_rounds'] < 12 or ghost_max == 1, st
+
+
+def test_config4_256_cubed_ssd_two_slabs():
+    """BASELINE.json config 4 at its own size: 256^3, SSD + RegLoss_L2, one chain in two z-slabs vs the fused engine."""
+    dv, dd, ds, st = _launch(2, 'SSD', 1, 256, False, 3.0, 'RegLoss_L2', 4)
+    from tests._report import check
+    check('slab/config4_256_ssd_ranks2', 'v_new (rel to max)', dv, 0.0, 1e-5)
+    check('slab/config4_256_ssd_ranks2', 'displacement [voxels]', dd, 0.0, 2e-5)
+    check('slab/config4_256_ssd_ranks2', 'loss terms (rel)', ds, 0.0, 1e-6)
+
+
+def test_rccl_transport_single_rank():
+    """the RCCL leaf: librccl is bound at run time, a one-rank communicator initialises on this device and carries the
+    all-reduces of a slab transition (two ranks on one device are refused by RCCL, so the multi-rank exchanges run on a node)"""
+    port = _free_port()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        from ir_sgmcmc_amd.slab import SlabComm
+        torch.cuda.set_device(0)
+        comm = SlabComm.rccl()
+        comm.selftest()
+        cfg, fixed, moving, v0, noise = _setup(24, 1, 'GMM')
+        v_ref, d_ref, s_ref, _ = _run_fused(cfg, fixed, moving, v0, noise)
+        eng, v, d, s = _run_slab(cfg, fixed, moving, v0, noise, comm)
+        assert float((v.cpu() - v_ref).abs().max()) <= 1e-5 * float(v_ref.abs().max())
+        del eng
+        comm.close()
+    finally:
+        dist.destroy_process_group()
