@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- SG-MCMC transitions/s of the HIP path on synthetic volumes (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 256] [--loss gmm|ssd]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 256] [--loss gmm|ssd] [--decomp slab|chains]
 
 A "step" is one full `_SGLD_transition` (noise + Sobolev, 12-step scaling and squaring, warp, LCC/GMM data term with
 virtual decimation, regulariser, backward, SGLD update) over one synthetic fixed/moving pair resident in HBM, with
-in-kernel Philox noise.  One process per GPU; for N > 1 the driver launches this file under torch.distributed.run and
-every rank samples its own chain of the same pair (no data-path collective: chains only share hyper-parameters in the
-reference, trainer.py:316-327) -> weak scaling in chains; value = all ranks' transitions / max-over-ranks wall time.
+in-kernel Philox noise.  One process per GPU.
+
+N > 1 (default `--decomp slab`, "scaling": "strong"): ONE chain, the volume split into N z-slabs; ghost planes travel
+between neighbouring GPUs through RCCL send / recv issued by the library on its communication stream, four small
+all-reduces per transition carry the partial sums (csrc/slab.hip).  value = transitions of that one
+chain / max-over-ranks wall time.  `--decomp chains` is the other, trivial, decomposition: independent chains per rank, no
+data-path collective (weak scaling).  Without a launcher (no WORLD_SIZE in the environment) `--gpus N` starts the N ranks
+itself, as child processes of torch.distributed.run, before anything touches a GPU.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the adjoint of one squaring step): algorithmic
 bytes per launch (36 B/voxel: read dL/dd_{k+1} 12 + read d_k 12 + write dL/dd_k 12) over its average duration measured
 with HIP events on the launch stream inside `irs_transition_timed`.  `cpu_baseline` times the CPU oracle (torch, all
-host cores) on a bounded sample and is a reported baseline, not a target.
+host cores) on a bounded sample and is a reported baseline, not a target.  `also` carries what a registration costs away
+from the headline's best case (N = 1 only): the SSD loss of config 4, a chain started from a displaced field, 128^3 with its
+own roofline fraction, and a sustained run of >= 500 transitions.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,25 +38,26 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is 
 BYTES_PER_VOXEL = {'gmm': 878.0, 'ssd': 854.0}  # algorithmic bytes / voxel / chain / transition
 BWD_STEP_BYTES_PER_VOXEL = 36.0
 FWD_STEP_BYTES_PER_VOXEL = 24.0
+TRAFFIC_PROFILE = os.path.join('profiles', 'r02_pmc_traffic.json')  # written by tools/profile_round.sh for THIS library build
 
 
-def pmc_traffic_bytes(n):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE and
-    WRITE_SIZE runs of this same command at 256^3; profiles/r01_v10_pmc_traffic.json).  Corrections as the
-    MI355X guide prescribes: counters are KiB; FETCH_SIZE reads exactly 1/2 of the bytes of this kernel's dword-per-lane
-    loads (calibrated in the same run on perturb_kernel, whose read volume is known); WRITE_SIZE is exact.
-    None for sizes that were not profiled."""
-    path = os.path.join(ROOT, 'profiles', 'r01_v10_pmc_traffic.json')
-    if n != 256 or not os.path.isfile(path):
-        return None
+def traffic_from_profile(n):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed with this round (separate
+    FETCH_SIZE / WRITE_SIZE runs of this command at 256^3).  Corrections as the MI355X guide prescribes: counters are KiB;
+    FETCH_SIZE reads exactly 1/2 of the bytes of this kernel's dword-per-lane loads (calibrated in the same run on
+    perturb_kernel, whose read volume is known); WRITE_SIZE is exact.  None when the profile is absent, of another size, or
+    a tuning build of the library (IRS_LIB) is being measured."""
+    path = os.path.join(ROOT, TRAFFIC_PROFILE)
+    if n != 256 or not os.path.isfile(path) or os.environ.get('IRS_LIB'):
+        return None, None
     t = json.load(open(path))
     for k, v in t.items():
         if 'exp_bwd_march_kernel<false, 1>' in k:
-            return (2.0 * v['FETCH_SIZE_KiB_raw'] + v['WRITE_SIZE_KiB_raw']) * 1024.0
-    return None
+            return (2.0 * v['FETCH_SIZE_KiB_raw'] + v['WRITE_SIZE_KiB_raw']) * 1024.0, TRAFFIC_PROFILE
+    return None, None
 
 
-def cpu_baseline(n_small, reps, loss):
+def cpu_baseline(n, reps, loss):
     """the CPU oracle (op-for-op the reference's ATen sequence) on a bounded sample, all host cores"""
     import torch
     from ir_sgmcmc_amd.data_loader import synthetic_pair
@@ -58,8 +68,8 @@ def cpu_baseline(n_small, reps, loss):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, int(os.environ.get('IRS_CPU_THREADS', '16'))))  # a 1-GPU box owns a 16-core share
     torch.set_num_threads(cores)
-    print(f'[bench] cpu baseline: oracle at {n_small}^3 on {cores} threads ...', file=sys.stderr, flush=True)
-    dims = (n_small,) * 3
+    print(f'[bench] cpu baseline: oracle at {n}^3 on {cores} threads ...', file=sys.stderr, flush=True)
+    dims = (n,) * 3
     cfg = OracleConfig(dims=dims, data_loss='GMM' if loss == 'gmm' else 'SSD', virtual_decimation=(loss == 'gmm'))
     f1, m1 = synthetic_pair(dims, seed=0)
     fixed = {k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'}
@@ -78,6 +88,84 @@ def cpu_baseline(n_small, reps, loss):
     return dt, cores
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of torch.distributed.run (this process
+    has not touched a GPU and never will), pass their output through and leave with their exit code."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] no launcher in the environment: starting', ' '.join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
+def initial_velocity(kind, amp, N, dev):
+    import torch
+    dims = (N, N, N)
+    if kind == 'smooth':
+        from ir_sgmcmc_amd.ops import perturb_smooth, sobolev_kernel_1d
+        g = torch.Generator(device='cpu').manual_seed(7)
+        lo = torch.randn(1, 3, N // 8, N // 8, N // 8, generator=g)
+        v = torch.nn.functional.interpolate(lo, size=dims, mode='trilinear', align_corners=True).to(dev).contiguous()
+        v = perturb_smooth(v, sobolev_kernel_1d(3, 0.5)) * (amp / float(v.abs().max()))
+        return v.contiguous()
+    if kind == 'wave':  # one half-wave across the volume: large but smooth, like a converged registration
+        t = torch.linspace(0.0, math.pi, N, device=dev)
+        sz, sy, sx = torch.sin(t).view(N, 1, 1), torch.sin(t).view(1, N, 1), torch.sin(t).view(1, 1, N)
+        return torch.stack([sz * sy * sx, -sz * sy * sx, 0.7 * sz * sy * sx]).unsqueeze(0).mul(amp).contiguous()
+    return torch.zeros(1, 3, *dims, device=dev)  # MCMC_init: identity (trainer.py:596-598)
+
+
+def engine_config(N, loss, seed):
+    from ir_sgmcmc_amd.engine import EngineConfig
+    return EngineConfig(dims=(N, N, N), no_chains=1, data_loss='GMM' if loss == 'gmm' else 'SSD', virtual_decimation=(loss == 'gmm'),
+                        reg_loss='RegLoss_L2', w_reg=1.4, seed=seed)
+
+
+def workload_name(N, loss):
+    return (f'{N}^3 synthetic pair, SVF_3D 12 steps, ' + ('GMM(K=4)/LCC(s=1) + virtual decimation' if loss == 'gmm' else 'SSD')
+            + ', RegLoss_L2 w=1.4, Sobolev s=3, uniform noise 0.1, SGLD lr 0.4, Philox noise')
+
+
+def side_run(N, loss, init, amp, steps, warmup, dev, timed_reps=0):
+    """one fused single-GPU workload outside the headline: ms per transition (+ the per-stage events when asked)"""
+    import torch
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    from ir_sgmcmc_amd.engine import TransitionEngine
+    eng = TransitionEngine(engine_config(N, loss, 1234), dev)
+    f1, m1 = synthetic_pair((N, N, N), seed=0)
+    fixed, moving = eng.prepare({k: v.unsqueeze(0).to(dev) for k, v in f1.items() if k != 'seg'},
+                                {k: v.unsqueeze(0).to(dev) for k, v in m1.items() if k != 'seg'})
+    eng.gmm_init(fixed, moving)
+    v = initial_velocity(init, amp, N, dev)
+    for _ in range(warmup):
+        eng.transition(fixed, moving, v)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.transition(fixed, moving, v)
+    torch.cuda.synchronize(dev)
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(v).all()), 'chain diverged'
+    out = {'ms_per_transition': ms, 'transitions_per_s': 1e3 / ms, 'steps': steps, 'warmup': warmup,
+           'achieved_GBps': BYTES_PER_VOXEL[loss] * N ** 3 / (ms * 1e-3) / 1e9,
+           'frac_of_8TBps': BYTES_PER_VOXEL[loss] * N ** 3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if timed_reps:
+        acc = None
+        for _ in range(timed_reps):
+            tm = eng.transition(fixed, moving, v, timed=True)
+            acc = tm if acc is None else {k: acc[k] + tm[k] for k in tm}
+        out['stage_ms'] = {k: x / timed_reps for k, x in acc.items()}
+        bk = out['stage_ms']['exp_bwd_primary_avg_ms']
+        out['dominant_kernel'] = {'avg_launch_ms': bk, 'achieved_GBps': BWD_STEP_BYTES_PER_VOXEL * N ** 3 / (bk * 1e-3) / 1e9,
+                                  'frac': BWD_STEP_BYTES_PER_VOXEL * N ** 3 / (bk * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -89,13 +177,18 @@ def main():
                     help="chain start: identity (MCMC_init 'identity', sub-voxel displacements) or a smooth random velocity "
                          "field of --init-amp voxels (exercises the large-displacement kernel variants)")
     ap.add_argument('--init-amp', type=float, default=3.0)
-    ap.add_argument('--decomp', choices=['chains', 'slab'], default='chains',
-                    help='N > 1: independent chains per rank (weak scaling, default) or ONE chain split into z-slabs with '
-                         'ghost-plane exchange (strong scaling, ir_sgmcmc_amd/slab.py)')
+    ap.add_argument('--decomp', choices=['slab', 'chains'], default='slab',
+                    help='N > 1: ONE chain split into z-slabs with ghost-plane exchange over RCCL (strong scaling, default) or '
+                         'independent chains per rank (weak scaling)')
+    ap.add_argument('--ghost-max', type=int, default=0, help='slab mode: widest ghost zone of one exchange (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-size', type=int, default=64)
-    ap.add_argument('--cpu-reps', type=int, default=5)
+    ap.add_argument('--no-extras', action='store_true', help='skip the `also` workloads (SSD, displaced start, 128^3, sustained run)')
+    ap.add_argument('--cpu-size', type=int, default=128)
+    ap.add_argument('--cpu-reps', type=int, default=2)
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -103,7 +196,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     # IRS_BENCH_DEVICE / IRS_BENCH_BACKEND exist only to rehearse the multi-rank path on a 1-GPU box (gloo, shared device)
     dev_index = int(os.environ.get('IRS_BENCH_DEVICE', local_rank))
@@ -116,40 +209,35 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
-    red_dev = dev if backend == 'nccl' else torch.device('cpu')
 
     from ir_sgmcmc_amd.data_loader import synthetic_pair
-    from ir_sgmcmc_amd.engine import EngineConfig, TransitionEngine
+    from ir_sgmcmc_amd.engine import TransitionEngine
+    from ir_sgmcmc_amd.parallel import ChainParallel
 
+    par = ChainParallel()
     N = args.size
     dims = (N, N, N)
     V = N ** 3
-    cfg = EngineConfig(dims=dims, no_chains=1, data_loss='GMM' if args.loss == 'gmm' else 'SSD',
-                       virtual_decimation=(args.loss == 'gmm'), reg_loss='RegLoss_L2', w_reg=1.4, seed=1234 + rank)
     slab = args.decomp == 'slab' and world > 1
-    if slab:
-        from ir_sgmcmc_amd.slab import SlabEngine
-        cfg.seed = 1234  # one chain: every rank must draw the same Philox noise
-        eng = SlabEngine(cfg, dev)
-    else:
-        eng = TransitionEngine(cfg, dev)
     f1, m1 = synthetic_pair(dims, seed=0)
-    fixed = {k: v.unsqueeze(0).to(dev) for k, v in f1.items() if k != 'seg'}
-    moving = {k: v.unsqueeze(0).to(dev) for k, v in m1.items() if k != 'seg'}
-    fixed, moving = eng.prepare(fixed, moving)
-    eng.gmm_init(fixed, moving)
-    v = torch.zeros(1, 3, *dims, device=dev)  # MCMC_init: identity (trainer.py:596-598)
-    if args.init == 'smooth':
-        from ir_sgmcmc_amd.ops import perturb_smooth, sobolev_kernel_1d
-        g = torch.Generator(device='cpu').manual_seed(7)
-        lo = torch.randn(1, 3, N // 8, N // 8, N // 8, generator=g)
-        v = torch.nn.functional.interpolate(lo, size=dims, mode='trilinear', align_corners=True).to(dev).contiguous()
-        v = perturb_smooth(v, sobolev_kernel_1d(3, 0.5)) * (args.init_amp / float(v.abs().max()))
-        v = v.contiguous()
-    elif args.init == 'wave':  # one half-wave across the volume: large but smooth, like a converged registration
-        t = torch.linspace(0.0, math.pi, N, device=dev)
-        sz, sy, sx = torch.sin(t).view(N, 1, 1), torch.sin(t).view(1, N, 1), torch.sin(t).view(1, 1, N)
-        v = torch.stack([sz * sy * sx, -sz * sy * sx, 0.7 * sz * sy * sx]).unsqueeze(0).mul(args.init_amp).contiguous()
+    fixed = {k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'}
+    moving = {k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'}
+    slab_status = None
+    if slab:
+        from ir_sgmcmc_amd.slab import SlabComm, SlabEngine
+        comm = SlabComm.rccl() if backend == 'nccl' else SlabComm.rehearsal(dev)
+        comm.selftest()  # one all-reduce of each kind + a ring exchange, verified: a broken transport stops here
+        cfg = engine_config(N, args.loss, 1234)  # one chain: every rank draws the Philox noise of ITS planes of the same field
+        eng = SlabEngine(cfg, dev, comm, ghost_max=args.ghost_max)
+        fixed, moving = eng.prepare(fixed, moving)   # fixed image / mask cut to the held planes; the moving image stays whole
+        eng.gmm_init(fixed, moving)
+        v = eng.local(initial_velocity(args.init, args.init_amp, N, dev))
+    else:
+        cfg = engine_config(N, args.loss, par.chain_seed(1234))
+        eng = TransitionEngine(cfg, dev)
+        fixed, moving = eng.prepare({k: v.to(dev) for k, v in fixed.items()}, {k: v.to(dev) for k, v in moving.items()})
+        eng.gmm_init(fixed, moving)
+        v = initial_velocity(args.init, args.init_amp, N, dev)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -164,16 +252,15 @@ def main():
     for _ in range(args.steps):
         eng.transition(fixed, moving, v)
     sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = par.max_over_ranks(time.perf_counter() - t0)
     assert bool(torch.isfinite(v).all()), 'chain diverged'
+    if slab:
+        slab_status = eng.status()
+        assert slab_status['mispredictions'] == 0, slab_status
 
-    # ---- side measurements on rank 0 of a single-GPU run (outside the timed region) ------------------------------------
+    # ---- side measurements on rank 0 (outside the timed region) ------------------------------------------------------------
     extras = {}
-    if world == 1 and dev.type == 'cuda':
+    if world == 1:
         # (1) the reference's own speed definition (trainer.py:467-476): every sample also warps the segmentation
         #     (nearest neighbour) with the sampled transformation
         from ir_sgmcmc_amd.ops import warp
@@ -203,62 +290,93 @@ def main():
         extras['device_copy_GBps'] = 20 * 2 * 3 * V * 4 / (time.perf_counter() - t1) / 1e9
         del a, b, outs
 
-    # per-stage HIP-event timings (outside the timed region), averaged over a few transitions
-    reps = max(3, min(10, args.steps))
-    acc = None
-    timing_eng = eng
-    if slab:  # per-stage events come from the fused path: time them on a plain engine (same kernels, full window)
-        timing_eng = TransitionEngine(cfg, dev)
-        timing_eng.prepare(fixed, moving)
-        timing_eng.gmm_init(fixed, moving)
-        v = torch.zeros(1, 3, *dims, device=dev)
-    for _ in range(reps):
-        tm = timing_eng.transition(fixed, moving, v, timed=True)
-        acc = tm if acc is None else {k: acc[k] + tm[k] for k in tm}
-    tm = {k: x / reps for k, x in acc.items()}
-    steps = cfg.no_steps
-    bwd_kernel_ms = tm['exp_bwd_primary_avg_ms']  # mean duration of exp_bwd_march_kernel<false,1> alone (HIP events)
-    fwd_kernel_ms = tm['exp_fwd_ms'] / steps
+    # per-stage HIP-event timings of the fused single-GPU launch sequence (rank 0, outside the timed region)
+    tm = None
+    if rank == 0:
+        timing_eng, tf, tmv, tv = eng, fixed, moving, v
+        if slab:  # the slab engine holds slab-local arrays: the events come from a fused engine on the whole volume
+            timing_eng = TransitionEngine(engine_config(N, args.loss, 1234), dev)
+            tf, tmv = timing_eng.prepare({k: x.unsqueeze(0).to(dev) for k, x in f1.items() if k != 'seg'},
+                                         {k: x.unsqueeze(0).to(dev) for k, x in m1.items() if k != 'seg'})
+            timing_eng.gmm_init(tf, tmv)
+            tv = torch.zeros(1, 3, *dims, device=dev)
+            for _ in range(3):
+                timing_eng.transition(tf, tmv, tv)
+        reps = max(3, min(10, args.steps))
+        acc = None
+        for _ in range(reps):
+            t = timing_eng.transition(tf, tmv, tv, timed=True)
+            acc = t if acc is None else {k: acc[k] + t[k] for k in t}
+        tm = {k: x / reps for k, x in acc.items()}
+        if slab:
+            del timing_eng
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
+        steps = cfg.no_steps
+        bwd_kernel_ms = tm['exp_bwd_primary_avg_ms']  # mean duration of exp_bwd_march_kernel<false,1> alone (HIP events)
+        fwd_kernel_ms = tm['exp_fwd_ms'] / steps
         ms_per_step = 1e3 * elapsed / args.steps
         value = (1 if slab else world) * args.steps / elapsed
         achieved = BWD_STEP_BYTES_PER_VOXEL * V / (bwd_kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = traffic_from_profile(N)
+        if slab:
+            via = 'RCCL send/recv' if backend == 'nccl' else f'{backend} with host staging (one-GPU REHEARSAL of the schedule, not a measurement)'
+            para = f'1 chain in {world} z-slabs, ghost planes over {via}, {slab_status["last_fwd_rounds"]}+{slab_status["last_bwd_rounds"]} exchange rounds for 2x12 squaring steps'
+        else:
+            para = f'{world} independent chain(s)'
         out = {
-            'metric': 'SG-MCMC transitions/sec (full _SGLD_transition, 1 chain per GPU)', 'value': value,
+            'metric': 'SG-MCMC transitions/sec (full _SGLD_transition)', 'value': value,
             'unit': 'transitions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if slab else 'weak', 'vs_baseline': None,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak' if (world > 1 and not slab) else 'strong', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{N}^3 synthetic pair, SVF_3D 12 steps, '
-                                   + ('GMM(K=4)/LCC(s=1) + virtual decimation' if args.loss == 'gmm' else 'SSD')
-                                   + ', RegLoss_L2 w=1.4, Sobolev s=3, uniform noise 0.1, SGLD lr 0.4, Philox noise',
-                       'volume': [N, N, N], 'init': args.init + (f' amp {args.init_amp}' if args.init == 'smooth' else ''),
-                       'chains_per_gpu': 1,
-                       'parallelism': (f'1 chain in {world} z-slabs, ghost-plane exchange' if slab else f'{world} independent chain(s)')},
+            'config': {'workload': workload_name(N, args.loss), 'volume': [N, N, N],
+                       'init': args.init + (f' amp {args.init_amp}' if args.init != 'identity' else ''),
+                       'chains': 1 if (slab or world == 1) else world, 'parallelism': para},
             'roofline': {'bound': 'hbm', 'kernel': 'exp_bwd_march_kernel<false,1> (adjoint of one squaring step)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': pmc_traffic_bytes(N), 'algorithmic_bytes_per_launch': BWD_STEP_BYTES_PER_VOXEL * V,
-                         'avg_launch_ms': bwd_kernel_ms,
-                         'note': 'priced against HBM as the path prescribes; the kernel itself is bound by vector-instruction issue: '
-                                 '80.4 M wave64 VALU instructions x 4 cycles / 1024 SIMDs = 150 us of its 203 us at 256^3 '
-                                 '(profiles/r01_v8_sq_counters.json, DESIGN.md section 4)'},
+                         'traffic': traffic, 'traffic_from_committed_profile': traffic_src,
+                         'algorithmic_bytes_per_launch': BWD_STEP_BYTES_PER_VOXEL * V, 'avg_launch_ms': bwd_kernel_ms,
+                         'measured_on': 'whole volume, one GPU (HIP events around the launch)'},
             'transition_roofline': {'algorithmic_bytes': BYTES_PER_VOXEL[args.loss] * V,
                                     'frac_of_device_copy': (BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9 / extras['device_copy_GBps']) if 'device_copy_GBps' in extras else None,
                                     'achieved_GBps': BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9,
-                                    'frac_of_8TBps': BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                    'frac_of_8TBps': BYTES_PER_VOXEL[args.loss] * V / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / (world if slab else 1)},
             'exp_step_fwd': {'avg_launch_ms': fwd_kernel_ms,
                              'achieved_GBps': FWD_STEP_BYTES_PER_VOXEL * V / (fwd_kernel_ms * 1e-3) / 1e9},
             'stage_ms': tm, 'workspace_GB': eng.workspace_bytes / 1e9, **extras,
         }
+        if slab:
+            st = slab_status
+            out['slab'] = {'planes_owned': eng.b - eng.a, 'planes_held': eng.hi - eng.lo, 'ghost_max': eng.ghost_max,
+                           'exchange_rounds_per_transition': st['exchanges'] / max(st['transitions'], 1),
+                           'MB_sent_per_transition_rank0': st['exchanged_bytes'] / max(st['transitions'], 1) / 1e6,
+                           'exact_transitions': st['exact_transitions'], 'mispredictions': st['mispredictions']}
+        if world == 1 and not args.no_extras:
+            also = {}
+            print('[bench] extras: SSD, displaced start, 128^3, sustained run ...', file=sys.stderr, flush=True)
+            del eng
+            torch.cuda.empty_cache()
+            other = 'ssd' if args.loss == 'gmm' else 'gmm'
+            also[f'{other}_{N}'] = dict(side_run(N, other, 'identity', 0.0, 25, 5, dev), workload=workload_name(N, other),
+                                        note='BASELINE.json config 4 names the SSD loss' if other == 'ssd' else '')
+            also['displaced_init'] = dict(side_run(N, args.loss, 'wave', 6.0, 20, 5, dev), init='wave amp 6.0 voxels',
+                                          note='last squaring steps leave the radius-1 kernels (DESIGN.md section 4)')
+            if N != 128:
+                also['size_128'] = dict(side_run(128, args.loss, 'identity', 0.0, 50, 10, dev, timed_reps=5), workload=workload_name(128, args.loss))
+            also['sustained'] = dict(side_run(N, args.loss, 'identity', 0.0, 500, 5, dev), note='500 consecutive transitions from the identity')
+            out['also'] = also
         if not args.no_cpu_baseline and world == 1:
-            n_small = min(args.cpu_size, N)
-            dt, cores = cpu_baseline(n_small, args.cpu_reps, args.loss)
-            scale = (N / n_small) ** 3
+            n_cpu = min(args.cpu_size, N)
+            dt, cores = cpu_baseline(n_cpu, args.cpu_reps, args.loss)
+            scale = (N / n_cpu) ** 3
             out['cpu_baseline'] = {'value': 1.0 / (dt * scale), 'unit': 'transitions/s', 'cores': cores, 'kind': 'port',
-                                   'sample': f'{args.cpu_reps} transitions of the torch-CPU oracle at {n_small}^3 '
-                                             f'({dt:.2f} s each, {cores} threads), scaled by voxel count x{scale:.0f} to {N}^3'}
-        print(json.dumps(out))
+                                   'sample': f'{args.cpu_reps} transitions of the torch-CPU oracle at {n_cpu}^3 '
+                                             f'({dt:.2f} s each, {cores} threads)' + (f', scaled by voxel count x{scale:.0f} to {N}^3' if scale != 1 else '')}
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

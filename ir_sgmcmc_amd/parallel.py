@@ -1,11 +1,9 @@
-"""One process per GPU over torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests).
-
-What shards in this path are the CHAINS: the reference's chains only share 2K + 2 hyper-parameter scalars, updated
-serially (trainer.py:316-327), so ranks sample their own chains of the same image pair with no data-path collective
-(weak scaling in chains).  The only exchanges are tiny: timing (max over ranks), the per-chain scalars that get
-logged, and the pooled posterior moments of the displacement at the end.  The z-slab decomposition of ONE chain
-(BASELINE.json config 4) needs displacement-wide halos for the 13 gathers per transition and is
-not part of this round.
+"""Rank bookkeeping of the multi-process runs (one process per GPU over torch.distributed; backend "nccl" == RCCL on
+ROCm, "gloo" in the CPU tests): max-over-ranks timing, whole-job rates, per-rank Philox keys, and the two exchanges the
+CHAIN decomposition has -- the per-chain scalars that get logged and the pooled posterior moments of the displacement.
+(Chains only share 2K + 2 hyper-parameter scalars in the reference, trainer.py:316-327, so ranks can sample their own
+chains with no data-path collective: `bench.py --decomp chains`.)  The z-slab decomposition of ONE chain, the default of
+`bench.py --gpus N`, lives in the library: ir_sgmcmc_amd/slab.py, csrc/slab.hip.  Used by bench.py.
 """
 import torch
 import torch.distributed as dist
