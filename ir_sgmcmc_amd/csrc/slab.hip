@@ -259,7 +259,11 @@ void fwd_step(irs_ctx* c, const Views& v, const float* vs, int k, int chains, Vo
                               c->dmax + (int64_t)(k + 1) * c->C * 4, predicted_small(c, k), fwd_lay(c, k), st);
 }
 
-void bwd_step(irs_ctx* c, const Views& v, const float* vs, int k, Vol w, hipStream_t st) {
+// `hplan`: the ghost width this transition was planned with for step k (0: unknown, launch every variant).  The plan is
+// validated against the measured bound afterwards (validate_widths_kernel: floor(max|d_k|) + 1 <= hplan, else the transition
+// is flagged invalid), so the variants that can only be selected above it need not be launched at all: hplan = 1 leaves the
+// radius-1 gather alone -- 24 idle launches less per transition than the fused path, which has no such guarantee.
+void bwd_step(irs_ctx* c, const Views& v, const float* vs, int k, int hplan, Vol w, hipStream_t st) {
     if (w.nz + w.nzb <= 0) return;
     const int lay = bwd_lay(c, k);
     float* gi = grad_raw(c, k, true);
@@ -268,8 +272,8 @@ void bwd_step(irs_ctx* c, const Views& v, const float* vs, int k, Vol w, hipStre
     float* out = (lay & 4) ? aos(go, v) : planar(go, v);
     const float* dk = k == 0 ? vs : step_buf(c, v, k - 1);
     const unsigned* dm = c->dmax + (int64_t)k * c->C * 4;
-    const bool skip_any = predicted_below(c, k, 1.5f);
-    launch_exp_step_bwd_march(G, dk, out, k == 0, c->cfg.no_steps, c->C, w, c->lin.lin(), dm, 2, skip_any, nullptr, lay, nullptr, st);
+    const bool skip_any = (hplan >= 1 && hplan <= 2) || predicted_below(c, k, 1.5f);
+    launch_exp_step_bwd_march(G, dk, out, k == 0, c->cfg.no_steps, c->C, w, c->lin.lin(), dm, hplan == 1 ? 1 : 2, skip_any, nullptr, lay, nullptr, st);
     // the any-radius kernel bounds its sources by the global bound around the tile (no coarse grid: that one spans the volume)
     if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, c->cfg.no_steps, c->C, w, c->lin.lin(), dm, 2, 2, nullptr, lay, nullptr, st);
 }
@@ -631,8 +635,10 @@ int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
     if (start_allreduce(p, c->dmax, (size_t)4 * C * (n + 1), 1, AR_DMAX, &dmax_done)) return 1;
 
     // ---- per chain, serially (trainer.py:316-327): VD factor -> GMM step -> data term with the UPDATED mixture
+    // (SSD without virtual decimation has alpha = 1 and no mixture: the statistics stage and its all-reduce drop out)
+    const bool need_stats = cfg.data_loss == IRS_DATA_GMM_LCC || cfg.virtual_decimation || exact;  // (once, for n_mask)
     for (int ch = 0; ch < C; ++ch) {
-        if (stats_for_chain(c, p, io, z, ch, cfg.virtual_decimation, 3)) return 1;
+        if (need_stats && stats_for_chain(c, p, io, z, ch, cfg.virtual_decimation, 3)) return 1;
         const uint8_t* mask = io.mask + (io.mask_chains == 1 ? 0 : (int64_t)ch * c->vol.V);
         const float* f = cfg.data_loss == IRS_DATA_GMM_LCC ? planar(c->fhat, v) + (c->fhat_chains == 1 ? 0 : (int64_t)ch * c->vol.V) : nullptr;
         double* part = c->nll_partials + (int64_t)ch * c->nll_blocks;
@@ -648,7 +654,7 @@ int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
                     planar(c->gM, v), planar(c->gA, v), C, w0, lin, cfg.seed, 0, it, st);
     LAUNCH_CHECK();
     if (dmax_done) HIP_TRY(hipStreamWaitEvent(st, dmax_done, 0));
-    auto bstep = [&](int k, Vol w) { bwd_step(c, v, vs, k, w, st); };
+    auto bstep = [&](int k, Vol w) { bwd_step(c, v, vs, k, plan.h[k], w, st); };
     for (int r = 0; r < plan.nb; ++r) {
         int ks[kMaxSteps], hs[kMaxSteps], m = 0;
         for (int k = n - 1; k >= 0; --k)

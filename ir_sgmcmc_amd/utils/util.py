@@ -80,9 +80,24 @@ def add_noise_Langevin(field, sigma, tau):
 
 def separable_conv_3D(field, *args):
     """Both branches of utils/util.py:350-406: (kernel (3,1,k), padding_sz) or (S_x, S_y, S_z, padding).
-    The same 1-D kernel is applied to the three channels (as every reference call site does)."""
-    k = args[0].reshape(args[0].shape[0], -1)[0].detach().cpu().tolist()
-    return _ops.perturb_smooth(field.contiguous(), k)
+
+    The 2-argument branch (utils/util.py:362-392) pads the last axis by replicate, flattens the volume, runs a zero-padded
+    conv1d and crops -- three times, permuting the axes in between.  The crop removes exactly the positions the zero padding
+    and the neighbouring rows reach, so it IS one (2 p + 1)-tap filter per axis with replicate padding, like the 4-argument
+    branch (verified against the imported reference to 3e-7 and pinned by tests/golden/utils_ops.npz, including per-channel
+    kernels: `groups=3` gives channel c row c of the kernel tensor)."""
+    k = args[0].reshape(args[0].shape[0], -1).detach().cpu()
+    if len(args) == 4:  # the three axis kernels of every reference call site are the same taps reshaped
+        ky, kz = (a.reshape(a.shape[0], -1).detach().cpu() for a in args[1:3])
+        if not (torch.equal(k, ky) and torch.equal(k, kz)):
+            raise NotImplementedError('separable_conv_3D: different kernels per axis')
+    f = field.contiguous()
+    if all(torch.equal(k[0], k[c]) for c in range(1, k.shape[0])):
+        return _ops.perturb_smooth(f, k[0].tolist())
+    out = torch.empty_like(f)
+    for c in range(k.shape[0]):  # a kernel of its own per channel: filter with each, keep the matching channel
+        out[:, c] = _ops.perturb_smooth(f, k[c].tolist())[:, c]
+    return out
 
 
 def calc_norm(field):
@@ -118,7 +133,7 @@ def calc_DSC_GPU(no_samples, seg_fixed, seg_moving, structures_dict):
         for j, label in enumerate(structures_dict.values()):
             num = 2.0 * ((f == label) & (m == label)).sum()
             den = (f == label).sum() + (m == label).sum()
-            DSC[idx, j] = float(num) / float(den) if int(den) > 0 else 0.0
+            DSC[idx, j] = num / den  # a label absent from both gives 0 / 0 = NaN, as in the reference (its `except` never fires)
     return DSC.numpy()
 
 

@@ -50,6 +50,9 @@ VARIANTS = {
     'n16_svf_big_displacement': dict(N=16, T=2, cfg=dict(w_reg=0.2), init='big'),
     'n16_svf_student_c1': dict(N=16, T=2, cfg=dict(reg_loss='RegLoss_Student', student=(2e-6, 0.7, 1e-6, 1e-6)), init='smooth_noise'),
     'n16_svf_lognormal_l2_c1': dict(N=16, T=2, cfg=dict(reg_loss='RegLoss_LogNormal_L2', w_reg=0.9), init='smooth_noise'),
+    # non-learnable RegLoss_LogNormal (model/loss.py:273-312): the coefficient of SURVEY.md row a13 without the hyper-prior terms
+    'n16_svf_lognormal_fixed_c1': dict(N=16, T=2, cfg=dict(reg_loss='RegLoss_LogNormal', reg_learnable=False, w_reg=1.1),
+                                       init='smooth_noise'),
     'n32_svf_l2_vd_c1': dict(N=32, T=2, cfg=dict(), init='smooth_noise'),
     'n32_svf_lognormal_learn_c2': dict(N=32, T=1, cfg=dict(no_chains=2, reg_loss='RegLoss_LogNormal',
                                                             reg_learnable=True), init='vi', sigma=0.5),
@@ -272,6 +275,74 @@ def run_variant(ref, name, spec, write):
         print(f'    wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)')
 
 
+# Free-running trajectories: T transitions of the reference loop body trainer/trainer.py:371-379 with NO
+# re-synchronisation of the state in between -- what the fixtures above cannot show is drift.  Stored: inputs, the seed of every
+# transition's noise (regenerated by the tests with the same torch CPU generator; checksums guard that), and per transition the
+# loss terms, alpha, the energy, ||v||, the mixture / regulariser parameters; the final v (sub-sampled above 16^3).
+TRAJECTORIES = {
+    'traj_n16_svf_l2_vd_c1': dict(N=16, T=10, cfg=dict(), init='smooth_noise'),
+    'traj_n32_svf_lognormal_learn_c2': dict(N=32, T=10, cfg=dict(no_chains=2, reg_loss='RegLoss_LogNormal', reg_learnable=True),
+                                            init='vi', sigma=0.5),
+}
+
+
+def run_trajectory(ref, name, spec, write):
+    N, T = spec['N'], spec['T']
+    cfg = OracleConfig(dims=(N, N, N), **spec['cfg'])
+    C = cfg.no_chains
+    fixed1, moving1 = synthetic_pair(cfg.dims, seed=0)
+    fixed = {k: v.unsqueeze(0).expand(C, *v.shape).contiguous() for k, v in fixed1.items()}
+    moving = {k: v.unsqueeze(0).expand(C, *v.shape).contiguous() for k, v in moving1.items()}
+    v0, sigma = initial_state(name, spec, cfg)
+    t, gmm, reg = build_reference(ref, cfg, fixed, moving, v0, sigma)
+    reference_gmm_init(ref, t, gmm, cfg, fixed, moving)
+    orc = OracleChain(cfg, v0=v0, sigma=torch.full_like(v0, sigma))
+    orc.init_gmm(fixed, moving)
+    store = {'config': np.frombuffer(json.dumps({**spec['cfg'], 'N': N, 'sigma': sigma}).encode(), dtype=np.uint8),
+             'gmm_log_std_init': gmm.log_std.detach().numpy().copy(), 'gmm_logits_init': gmm.logits.detach().numpy().copy(),
+             'fixed': fixed1['im'].numpy(), 'moving': moving1['im'].numpy(), 'mask': fixed1['mask'].numpy(), 'v0': v0.numpy()}
+    for i, (step, m, v) in enumerate(adam_state(t.optimizer_GMM)):
+        store[f'gmm_adam{i}_step'] = np.int64(step)
+        store[f'gmm_adam{i}_m'] = m.numpy()
+        store[f'gmm_adam{i}_v'] = v.numpy()
+    if cfg.reg_loss == 'RegLoss_LogNormal':
+        store.update(reg_loc_init=reg.loc.detach().numpy().copy(), reg_log_scale_init=reg.log_scale.detach().numpy().copy())
+    rows, worst = [], {}
+    for it in range(T):
+        seed = 9100 + 17 * it
+        torch.manual_seed(seed)
+        eps = torch.randn_like(t.SGLD_params['sigma'])
+        unif = torch.rand(C, 3, N, N, N) if cfg.uniform_noise is not None else None
+        torch.manual_seed(seed)
+        loss_terms, output, aux = t._SGLD_transition(fixed, moving, gmm, reg)
+        o = orc.transition(fixed, moving, eps, unif)
+        v_now = t.v_curr_state.detach()
+        row = [float(x) for x in loss_terms['data']] + [float(x) for x in loss_terms['reg']] + [float(a) for a in aux['alpha']] + \
+              [float(x) for x in aux['reg_energy']] + [float(v_now[c].double().norm()) for c in range(C)]
+        rows.append(row)
+        store[f't{it}_seed'] = np.int64(seed)
+        store[f't{it}_noise_checksum'] = np.array([eps.double().sum(), unif.double().sum() if unif is not None else 0.0])
+        store[f't{it}_gmm_log_std'] = gmm.log_std.detach().numpy().copy()
+        store[f't{it}_gmm_logits'] = gmm.logits.detach().numpy().copy()
+        if cfg.reg_loss == 'RegLoss_LogNormal':
+            store[f't{it}_reg_params'] = np.array([float(reg.loc), float(reg.log_scale)])
+        cmp = {'data_rel': maxdiff(row[:C], o['data']) / max(1.0, max(abs(x) for x in row[:C])),
+               'reg_rel': maxdiff(row[C:2 * C], o['reg']) / max(1.0, max(abs(x) for x in row[C:2 * C])),
+               'alpha': maxdiff(row[2 * C:3 * C], o['alpha']),
+               'v_rel': maxdiff(v_now, o['v_new']) / float(v_now.abs().max())}
+        for k, v in cmp.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    store['trajectory'] = np.array(rows)  # [T, 5 C]: data (C), reg (C), alpha (C), energy (C), ||v|| (C)
+    v_fin = t.v_curr_state.detach().numpy()
+    store['v_final'] = v_fin if N <= 16 else v_fin[:, :, ::4, ::4, ::4].copy()
+    print(f'{name:42s} oracle drift over {T} free-running transitions: ' + ' '.join(f'{k} {v:.1e}' for k, v in worst.items()))
+    assert worst['data_rel'] < 1e-4 and worst['reg_rel'] < 1e-5 and worst['alpha'] < 1e-4 and worst['v_rel'] < 1e-3, worst
+    if write:
+        path = os.path.join(HERE, name + '.npz')
+        np.savez_compressed(path, **store)
+        print(f'    wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--check-only', action='store_true', help='validate the oracle, write nothing')
@@ -282,6 +353,10 @@ def main():
         if args.only and args.only not in name:
             continue
         run_variant(ref, name, spec, write=not args.check_only)
+    for name, spec in TRAJECTORIES.items():
+        if args.only and args.only not in name:
+            continue
+        run_trajectory(ref, name, spec, write=not args.check_only)
 
 
 if __name__ == '__main__':

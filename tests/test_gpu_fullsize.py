@@ -147,3 +147,51 @@ def test_full_transition_is_reproducible_and_sane():
         del eng
     assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
     assert not torch.equal(res[0][0], res[2][0])
+
+
+def test_ssd_transition_reproducible_and_gradient_is_the_adjoint():
+    """BASELINE.json config 4's loss at its own size (256^3 SSD + RegLoss_L2, one GPU; the z-slab run of the same
+    configuration is compared with this engine in tests/test_gpu_slab.py).
+    (1) Two engines, same seed: bit-identical chains.
+    (2) The gradient the transition applies is the adjoint of its own forward map: with the regulariser switched off
+        (w_reg -> 0) and no noise, <dL/dv, u> equals the central difference of the data term along u, L(v) = the SSD
+        data term the engine reports."""
+    fixed, moving = _pair()
+    res = []
+    for seed in (3, 3):
+        eng = TransitionEngine(EngineConfig(dims=(N, N, N), data_loss='SSD', virtual_decimation=False, reg_loss='RegLoss_L2', w_reg=1.4,
+                                            seed=seed), DEV)
+        fd, md = eng.prepare(fixed, moving)
+        eng.gmm_init(fd, md)
+        v = smooth(1, 2.0, 31)
+        for _ in range(3):
+            eng.transition(fd, md, v)
+        sc = eng.scalars()
+        assert eng.state().iteration == 3 and bool(torch.isfinite(v).all()) and float(sc['alpha'][0]) == 1.0
+        res.append((v.clone(), float(sc['data_term'][0]), float(sc['reg_term'][0])))
+        del eng
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1:] == res[1][1:]
+
+    def data_term(v_in, want_grad=False):
+        # no Langevin noise (lr -> 0 keeps the perturbation and the update negligible), no jitter, no Sobolev smoothing:
+        # v_s = v, and grad_v is the data gradient plus a vanishing regulariser term
+        eng = TransitionEngine(EngineConfig(dims=(N, N, N), data_loss='SSD', virtual_decimation=False, reg_loss='RegLoss_L2', w_reg=1e-12,
+                                            sobolev_s=0, uniform_noise=0.0, lr=1e-30, seed=1), DEV)
+        fd, md = eng.prepare(fixed, moving)
+        eng.gmm_init(fd, md)
+        vv = v_in.clone()
+        g = torch.empty_like(vv) if want_grad else None
+        eng.transition(fd, md, vv, outputs={'grad_v': g} if want_grad else None)
+        d = float(eng.scalars()['data_term'][0])
+        del eng
+        return d, g
+
+    v = smooth(1, 2.0, 41)
+    u = smooth(1, 1.0, 42)
+    _, g = data_term(v, True)
+    rhs = float((g.double() * u.double()).sum())
+    eps = 0.0125
+    lp, _ = data_term(v + eps * u)
+    lm, _ = data_term(v - eps * u)
+    lhs = (lp - lm) / (2 * eps)
+    assert abs(lhs - rhs) < 1e-2 * max(abs(lhs), abs(rhs)), (lhs, rhs)

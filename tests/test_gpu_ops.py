@@ -1,12 +1,14 @@
 """Operator-level parity of the HIP kernels (through the C ABI) against the CPU oracle.  GPU only."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
 from ir_sgmcmc_amd import ops as G
 from oracle import ops as O
-from tests._report import GRAD_RTOL
+from tests._report import GRAD_RTOL, check
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -211,3 +213,32 @@ def test_reg_energy_gradient_operator_and_det_j():
     cnt, ld = G.log_det_jacobian(dev(t))
     ld_ref = O.det_jacobian(O.forward_differences(t, transformation=True)).log()
     assert int(cnt[0]) == int(torch.isnan(ld_ref).sum())
+
+
+def test_utility_operators_match_reference_fixture():
+    """separable_conv_3D (2-argument branch, utils/util.py:362-392; reference tests/test_utils.py:117-133 restated on a
+    non-constant field and asymmetric / per-channel kernels), calc_norm (utils/util.py:215-225) and calc_DSC_GPU
+    (utils/util.py:123-148) against outputs of the imported reference (tests/golden/make_golden_utils.py)."""
+    import os
+    from ir_sgmcmc_amd.utils import util as U
+    from tests._golden import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'utils_ops.npz'))
+    v = torch.from_numpy(z['field']).to(DEV)
+    for tag in ('k3', 'k5', 'sobolev', 'kc'):
+        k = torch.from_numpy(z[f'{tag}_kernel'])
+        S = (k if k.dim() == 2 else torch.stack((k, k, k), 0)).unsqueeze(1)
+        p = (S.shape[-1] - 1) // 2
+        check('utils/separable_conv_3D', f'2-arg {tag}', U.separable_conv_3D(v, S.to(DEV), p), z[f'{tag}_out_2arg'], 1e-6)
+        if k.dim() == 1:  # the 4-argument call of the same taps gives the same field
+            S4 = S.to(DEV)
+            out4 = U.separable_conv_3D(v, S4.unsqueeze(2).unsqueeze(2), S4.unsqueeze(2).unsqueeze(4), S4.unsqueeze(3).unsqueeze(4), (p,) * 6)
+            check('utils/separable_conv_3D', f'4-arg {tag}', out4, z[f'{tag}_out_2arg'], 1e-6)
+    # the reference's own known answer: all-ones 3-tap kernels on a constant field give 27 (tests/test_utils.py:117-133)
+    ones = torch.zeros(2, 3, 16, 16, 16, device=DEV)
+    ones[0, 1], ones[1, 2] = 1.0, 1.0
+    out = U.separable_conv_3D(ones, torch.ones(3, 1, 3, device=DEV), 1)
+    assert torch.allclose(out[0, 1], torch.full_like(out[0, 1], 27.0)) and float(out[0, 0].abs().max()) == 0.0
+    check('utils/calc_norm', 'norm', U.calc_norm(v), z['norm'], 1e-6)
+    labels = {str(i): int(l) for i, l in enumerate(z['dsc_labels'])}
+    dsc = U.calc_DSC_GPU(3, torch.from_numpy(z['seg_fixed']).to(DEV), torch.from_numpy(z['seg_moving']).to(DEV), labels)
+    assert np.array_equal(np.isnan(dsc), np.isnan(z['dsc'])) and np.allclose(np.nan_to_num(dsc), np.nan_to_num(z['dsc']), atol=1e-6)

@@ -156,13 +156,16 @@ def test_transition_matches_oracle_builder_variants(variant):
         v.copy_(o['v_new'].to(DEV))
 
 
-def test_transition_matches_oracle_at_128_cubed():
-    """BASELINE.json configs 2 / 3 size (128^3, GMM / LCC s = 1, virtual decimation, Sobolev, jitter): one transition of the
-    HIP path against the CPU oracle on the same injected noise, at the north-star tolerances (loss terms 1e-5 relative,
+@pytest.mark.parametrize('loss', ['gmm', 'ssd'])
+def test_transition_matches_oracle_at_128_cubed(loss):
+    """BASELINE.json configs 2 / 3 at their own size: 128^3, SSD + RegLoss_L2 (config 2; SSD is builder-defined, SURVEY.md
+    section 0) and GMM / LCC s = 1 with virtual decimation (config 3), both with Sobolev smoothing and jitter: one transition of
+    the HIP path against the CPU oracle on the same injected noise, at the north-star tolerances (loss terms 1e-5 relative,
     displacement 1e-4 voxels).  The oracle needs ~10 s of host time at this size."""
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     N = 128
-    oc = OracleConfig(dims=(N, N, N))
+    oc = OracleConfig(dims=(N, N, N)) if loss == 'gmm' else OracleConfig(dims=(N, N, N), data_loss='SSD', virtual_decimation=False,
+                                                                         reg_loss='RegLoss_L2', w_reg=1.4)
     f1, m1 = synthetic_pair((N, N, N), seed=0)
     fixed = {k: v.unsqueeze(0).contiguous() for k, v in f1.items() if k != 'seg'}
     moving = {k: v.unsqueeze(0).contiguous() for k, v in m1.items() if k != 'seg'}
@@ -186,7 +189,7 @@ def test_transition_matches_oracle_at_128_cubed():
     o = orc.transition(fixed, moving, eps, unif)
     eng.transition(fixed_d, moving_d, v, None, eps.to(DEV), unif.to(DEV) if unif is not None else None, out)
     sc = eng.scalars()
-    T = 'oracle/128^3'
+    T = 'oracle/128^3_' + loss
     assert float(o['displacement'].abs().max()) > 1.0   # not a trivial field
     check(T, 'alpha', sc['alpha'], o['alpha'], 5e-5)
     check(T, 'data_term (rel)', torch.tensor(sc['data_term']) / torch.tensor(o['data']).abs(), torch.sign(torch.tensor(o['data'])), 1e-5)
