@@ -57,7 +57,8 @@ int irs_svf_exp_fwd(const float* v, float* steps, float* transformation, float* 
 
 /* adjoint of the above w.r.t. v (what autograd does through the 12 grid_sample calls).
  * g_last: gradient w.r.t. d_no_steps (normalised units), (C,3,D,H,W).  g_v: output, gradient w.r.t. v.
- * scratch: 2 x (C,3,D,H,W).  Accumulates with float atomics (order-dependent in the last bits). */
+ * scratch: 2 x (C,3,D,H,W).  Owner-computes gather for max|d_k| < 2 voxels, fixed-point LDS accumulation above: no float
+ * atomics, bitwise reproducible. */
 int irs_svf_exp_bwd(const float* v, const float* steps, const float* g_last, float* scratch, float* g_v, int no_steps,
                     int C, int D, int H, int W, void* stream);
 
@@ -204,7 +205,10 @@ int irs_get_scalars(irs_ctx* ctx, irs_scalars* out, void* stream);
  * (NULL = zero field), then `warm_up` _step_GMM iterations.  blocking (reads one scalar back). */
 int irs_gmm_init(irs_ctx* ctx, const irs_io* io, const float* v_sample, int warm_up, void* stream);
 
-/* one SG-MCMC transition; asynchronous, graph-capturable (no allocation, no host sync) */
+/* one SG-MCMC transition.  Asynchronous: nothing is allocated and the DEVICE is never waited for; the host, however, is
+ * held back so that it runs at most two transitions ahead of the device (it waits on the end event of the transition before
+ * the previous one -- the kernel-variant prediction reads bounds no older than that).  Under stream capture that wait is
+ * skipped, so the call stays graph-capturable. */
 int irs_transition(irs_ctx* ctx, const irs_io* io, void* stream);
 
 /* timing hook for bench.py: the same transition with hipEvents recorded on `stream` around the stages; blocking.

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 
 #include "ctx.h"
@@ -128,15 +129,35 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
     const float* G = g_last;
     float* bufs[2] = {gA, gB};
     int cur = 0;
-    static unsigned* dmax = nullptr;  // process-wide scratch for the stateless operator: [32 steps][8 chains][4]
-    if (!dmax) HIP_TRY(hipMalloc((void**)&dmax, sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32));
-    static float* cmm = nullptr;      // coarse displacement extrema for the any-radius adjoint (kernels.h), grown on demand
-    static size_t cmm_bytes = 0;
-    if (coarse_minmax_bytes(vol, C) > cmm_bytes) {
-        HIP_TRY(hipStreamSynchronize(st));
-        if (cmm) HIP_TRY(hipFree(cmm));
-        cmm_bytes = coarse_minmax_bytes(vol, C);
-        HIP_TRY(hipMalloc((void**)&cmm, cmm_bytes));
+    // Scratch of the stateless operator, one set PER DEVICE (a pointer of device 0 is no use to a launch on device 1), guarded
+    // by a mutex and regrown only after the WHOLE device has drained (another stream may still be reading the old block).
+    // [32 steps][8 chains][4] bounds + the coarse displacement extrema of the any-radius adjoint (kernels.h).
+    struct Scratch {
+        unsigned* dmax = nullptr;
+        float* cmm = nullptr;
+        size_t cmm_bytes = 0;
+    };
+    static Scratch per_device[64];
+    static std::mutex mu;
+    int dev_id = 0;
+    HIP_TRY(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= 64) return fail("irs_svf_exp_bwd: device ordinal %d out of range", dev_id);
+    unsigned* dmax;
+    float* cmm;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        Scratch& sc = per_device[dev_id];
+        if (!sc.dmax) HIP_TRY(hipMalloc((void**)&sc.dmax, sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32));
+        if (coarse_minmax_bytes(vol, C) > sc.cmm_bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (sc.cmm) HIP_TRY(hipFree(sc.cmm));
+            sc.cmm = nullptr;
+            sc.cmm_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&sc.cmm, coarse_minmax_bytes(vol, C)));
+            sc.cmm_bytes = coarse_minmax_bytes(vol, C);
+        }
+        dmax = sc.dmax;
+        cmm = sc.cmm;
     }
     if (C > IRS_MAX_CHAINS || no_steps > 32) return fail("irs_svf_exp_bwd: at most %d chains / 32 steps", IRS_MAX_CHAINS);
     const bool lds = use_lds_exp();
@@ -651,10 +672,12 @@ int irs_gmm_init(irs_ctx* c, const irs_io* io, const float* v_sample, int warm_u
     if (c->cfg.data_loss != IRS_DATA_GMM_LCC) return 0;
     hipStream_t st = (hipStream_t)stream;
     // trainer.py:529-547: one velocity sample (no Langevin noise, no jitter), batch of one
+    // staged in tmpB: a velocity-grid-sized buffer the forward pass does not touch (gA is image-grid-sized, and the control
+    // grid of SVFFD with cps = 1 is LARGER than the image grid)
     const size_t bytes = (size_t)3 * c->volv.V * sizeof(float);
-    if (v_sample) HIP_TRY(hipMemcpyAsync(c->gA, v_sample, bytes, hipMemcpyDeviceToDevice, st));
-    else HIP_TRY(hipMemsetAsync(c->gA, 0, bytes, st));
-    if (forward_pass(c, io, c->gA, false, false, c->vs, c->warped, c->z, nullptr, 1, st, 0)) return 1;
+    if (v_sample) HIP_TRY(hipMemcpyAsync(c->tmpB, v_sample, bytes, hipMemcpyDeviceToDevice, st));
+    else HIP_TRY(hipMemsetAsync(c->tmpB, 0, bytes, st));
+    if (forward_pass(c, io, c->tmpB, false, false, c->vs, c->warped, c->z, nullptr, 1, st, 0)) return 1;
     launch_masked_moments(c->z, io->mask, c->stat_partials, c->vol, st);
     launch_gmm_init_from_moments(c->state, c->stat_partials, stats_blocks(c->vol), c->dcfg, st);
     launch_stats(c->cfg.virtual_decimation, c->z, io->mask, c->state, c->stat_partials, c->vol, st);

@@ -32,18 +32,24 @@ class SyntheticDataLoader:
 
 class BiobankDataLoader(SyntheticDataLoader):
     """Reference contract (data_loader/data_loaders.py:5-19): `.nii.gz` triples under `data_dir` through BiobankDataset
-    (numpy NIfTI reader instead of SimpleITK).  When `data_dir` holds no usable pair -- the reference ships no image data --
-    the loader resolves to the synthetic pair of the same `dims`, with a warning."""
+    (numpy NIfTI reader instead of SimpleITK).  An unusable `data_dir` is an ERROR, as in the reference (its `listdir`
+    raises): a typo must not turn into a registration of fake data written out under the requested names.  The synthetic
+    pair of the same `dims` is only used when the config asks for it: `"allow_synthetic_fallback": true` (the reference
+    ships no image data, its configs point at the author's cluster), or the `SyntheticDataLoader` type."""
 
-    def __init__(self, data_dir=None, dims=None, sigma_v_init=0.5, u_v_init=0.1, cps=None, save_dirs=None, **kw):
+    def __init__(self, data_dir=None, dims=None, sigma_v_init=0.5, u_v_init=0.1, cps=None, save_dirs=None,
+                 allow_synthetic_fallback=False, **kw):
         super().__init__(dims, sigma_v_init, u_v_init, cps, save_dirs, **kw)
         self.data_dir, self.dataset = data_dir, None
+        from .datasets import BiobankDataset
         try:
-            from .datasets import BiobankDataset
             self.dataset = BiobankDataset(dims, data_dir, save_dirs, sigma_v_init, u_v_init, cps=cps)
-        except (FileNotFoundError, NotADirectoryError, TypeError) as e:
+        except (FileNotFoundError, NotADirectoryError) as e:
+            if not allow_synthetic_fallback:
+                raise FileNotFoundError(f'BiobankDataLoader: no usable image pair under data_dir={data_dir!r} ({e}); set '
+                                        f'"allow_synthetic_fallback": true in data_loader.args to run on the synthetic pair') from e
             import logging
-            logging.getLogger('default').warning(f'BiobankDataLoader: {e}; using the synthetic pair at {dims}')
+            logging.getLogger('default').warning(f'BiobankDataLoader: {e}; allow_synthetic_fallback: using the synthetic pair at {dims}')
 
     @property
     def im_spacing(self):

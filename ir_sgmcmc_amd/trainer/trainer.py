@@ -105,6 +105,7 @@ class Trainer(VIMixin, BaseTrainer):
     def _engine_init(self, fixed, moving):
         self.engine = TransitionEngine(self._engine_config(), self.device)
         self._fixed, self._moving = self.engine.prepare(fixed, moving)
+        self._mask_idx = None
         # hyper-parameters of the loss objects -> device state
         st = self.engine.state()
         data_loss, reg_loss = self.losses['data']['loss'], self.losses['reg']['loss']
@@ -174,7 +175,8 @@ class Trainer(VIMixin, BaseTrainer):
         torch.save(self.state_dict(), file_path)
 
     def load_checkpoint(self, file_path):
-        self.load_state_dict(torch.load(file_path, map_location='cpu', weights_only=False))
+        # plain tensors, numbers and bytes only: a checkpoint is data, never code
+        self.load_state_dict(torch.load(file_path, map_location='cpu', weights_only=True))
 
     # ---------------------------------------------------------------- reference-named pieces
     def _SGLD_init(self, var_params_q_v):
@@ -203,19 +205,26 @@ class Trainer(VIMixin, BaseTrainer):
 
     def _GMM_init(self, fixed, moving, var_params_q_v=None):
         """Trainer.__GMM_init (trainer.py:529-547): one velocity sample, std of the masked residual, 25 warm-up steps"""
+        # the reference draws sample_q_v(var_params_q_v) here whatever MCMC_init is (mu = 0, sigma_v_init, u_v_init at the
+        # start of a run): the residual std -- and with it the mixture's initial log_std and warm-up trajectory -- comes
+        # from THAT warp, not from the identity
         v_sample = None
-        if var_params_q_v is not None and self.MCMC_init == 'VI':
+        if var_params_q_v is not None:
             vp = {k: v.to(self.device).reshape(1, 3, *v.shape[-3:]) for k, v in var_params_q_v.items()}
             v_sample = sample_q_v(vp).contiguous()
         self.engine.gmm_init(self._fixed, self._moving, v_sample)
         self.sync_parameters()
 
-    def _SGLD_transition(self, fixed, moving, data_loss=None, reg_loss=None, eps=None, unif=None, with_outputs=True):
+    def _SGLD_transition(self, fixed, moving, data_loss=None, reg_loss=None, eps=None, unif=None, with_outputs=True,
+                         like_reference=True):
         """One SG-MCMC transition (trainer.py:291-356).  Returns (loss_terms, output, aux) with the reference's keys.
 
         `eps` / `unif` inject the two noise draws (parity runs); by default they come from in-kernel Philox.
-        The tensors in `output` are views of engine-owned buffers that the NEXT transition overwrites (the reference
-        clones four volumes every iteration, trainer.py:302-305; clone here if you keep them).
+        `like_reference` (default): `output[...]` are CLONES (trainer.py:302-305) and `aux['residuals']` is the masked view
+        `residuals[fixed['mask']].view(no_chains, -1)` (trainer.py:308) -- a caller that keeps samples or feeds the residuals
+        to its own code sees exactly the reference's objects.  With False the tensors are the engine-owned buffers the NEXT
+        transition overwrites and the residuals stay dense (C,1,D,H,W): what this package's own `_run_MCMC` loop uses, since
+        it consumes them at once (saves four volume copies and a gather per transition).
         """
         if self.engine is None:
             raise RuntimeError('call _engine_init / _run_MCMC first')
@@ -227,8 +236,20 @@ class Trainer(VIMixin, BaseTrainer):
         loss_terms = {'data': lazy('data_term'), 'reg': lazy('reg_term')}
         output = {'im_moving_warped': self._outputs['im_moving_warped'], 'displacement': self._outputs['displacement'],
                   'transformation': self._outputs['transformation'], 'curr_state': self._outputs['curr_state']}
-        aux = {'residuals': self._outputs['residuals'], 'alpha': lazy('alpha'), 'reg_energy': lazy('reg_energy')}
+        residuals = self._outputs['residuals']
+        if like_reference:
+            output = {k: v.clone() for k, v in output.items()}
+            residuals = residuals.reshape(-1).index_select(0, self._masked_index()).view(C, -1)
+        aux = {'residuals': residuals, 'alpha': lazy('alpha'), 'reg_energy': lazy('reg_energy')}
         return loss_terms, output, aux
+
+    def _masked_index(self):
+        """flat indices of the masked voxels of all chains, computed once (a boolean index would synchronise every transition)"""
+        if getattr(self, '_mask_idx', None) is None:
+            m = self._fixed['mask']
+            m = m.expand(self.no_chains, *m.shape[1:]) if m.shape[0] == 1 else m
+            self._mask_idx = m.reshape(-1).nonzero(as_tuple=False).squeeze(1)
+        return self._mask_idx
 
     step = _SGLD_transition  # BASELINE.json calls the iteration `step()`
 
@@ -239,7 +260,9 @@ class Trainer(VIMixin, BaseTrainer):
         log = self.logger.info
         log(f'\nNO. CHAINS: {self.no_chains}, BURNING IN...')
         n_total = self.no_iters_burn_in + self.no_samples_MCMC
-        every = 1 if self.no_samples_MCMC < 1e4 else 100
+        # the reference logs hyper-parameters and loss terms on every iteration of a short run (trainer.py:389), each a host
+        # read-back; `trainer.metrics_period` > 1 thins them out (the device then runs ahead of the host between reads)
+        every = int(self.config['trainer'].get('metrics_period', 1 if self.no_samples_MCMC < 1e4 else 100))
         # running posterior mean / M2 of the displacement on the device instead of a
         # host array of every logged sample (trainer.py:365-366)
         mean = torch.zeros_like(self._outputs['displacement'][0])
@@ -258,7 +281,7 @@ class Trainer(VIMixin, BaseTrainer):
         for sample_no in range(first, n_total + 1):
             if sample_no < self.no_iters_burn_in and sample_no % self.log_period_MCMC == 0:
                 log(f'burn-in sample no. {sample_no}/{self.no_iters_burn_in}')
-            loss_terms, output, aux = self._SGLD_transition(fixed, moving, data_loss, reg_loss)
+            loss_terms, output, aux = self._SGLD_transition(fixed, moving, data_loss, reg_loss, like_reference=False)
             if sample_no == self.no_iters_burn_in:
                 log('ENDED BURNING IN')
             self.writer.set_step(sample_no)
@@ -268,6 +291,12 @@ class Trainer(VIMixin, BaseTrainer):
                     for idx in range(data_loss.no_components):
                         self.metrics.update(f'MCMC/GMM/scale_{idx}', data_loss.scales[idx].item())
                         self.metrics.update(f'MCMC/GMM/proportion_{idx}', data_loss.proportions[idx].item())
+                if getattr(reg_loss, 'learnable', False):  # trainer.py:397-402
+                    if type(reg_loss).__name__ == 'RegLoss_LogNormal':
+                        self.metrics.update('MCMC/reg/loc', reg_loss.loc.item())
+                        self.metrics.update('MCMC/reg/scale', reg_loss.scale.item())
+                    elif type(reg_loss).__name__ == 'RegLoss_L2':
+                        self.metrics.update('MCMC/reg/w_reg', reg_loss.log_w_reg.exp().item())
                 total = sum(t.item() for t in loss_terms['data']) + sum(t.item() for t in loss_terms['reg'])
                 self.metrics.update('MCMC/avg_loss', total / self.no_chains)
                 for idx in range(self.no_chains):
@@ -308,14 +337,14 @@ class Trainer(VIMixin, BaseTrainer):
         self.displacement_std = torch.sqrt(m2 / max(n_rec - 1, 1))
         if n_rec > 0 and cfg_trainer.get('save_outputs', True):
             save_displacement_mean_and_std_dev(self.logger, self.config.save_dirs, spacing, self.displacement_mean,
-                                               self.displacement_std, fixed['mask'][0].to(mean.dtype), 'MCMC')
+                                               self.displacement_std, moving.get('mask', fixed['mask'])[0].to(mean.dtype), 'MCMC')  # trainer.py:461-462: the MOVING mask
 
         # speed test (trainer.py:467-476): 100 x [transition + nearest-neighbour warp of the segmentation]
         n_speed = 100
         torch.cuda.synchronize()
         start = time.perf_counter()
         for _ in range(n_speed):
-            _, output, _ = self._SGLD_transition(fixed, moving, data_loss, reg_loss)
+            _, output, _ = self._SGLD_transition(fixed, moving, data_loss, reg_loss, like_reference=False)
             if 'seg' in moving:
                 self.registration_module(moving['seg'], output['transformation'])
         torch.cuda.synchronize()

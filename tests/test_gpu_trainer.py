@@ -49,7 +49,7 @@ def test_trainer_transition_matches_oracle(tmp_path):
     fde = {k: v.expand(C, *v.shape[1:]) for k, v in fd.items()}
     mde = {k: v.expand(C, *v.shape[1:]) for k, v in md.items()}
     t._engine_init(fde, mde)
-    t._GMM_init(fde, mde, vp)
+    t._GMM_init(fde, mde, None)  # the zero velocity sample the oracle's init uses (with `vp` the trainer draws sample_q_v, as the reference)
     assert torch.allclose(t.losses['data']['loss'].log_std.detach(), orc.log_std.detach(), atol=2e-4)
     t._SGLD_init(vp)
     assert t.v_curr_state.shape == (C, 3, N, N, N) and float(t.v_curr_state.abs().max()) == 0.0
@@ -69,6 +69,11 @@ def test_trainer_transition_matches_oracle(tmp_path):
             check(T, 'alpha', aux['alpha'][c].item(), o['alpha'][c], 2e-5)
         check(T, 'displacement [voxels]', output['displacement'], o['displacement'], 1e-4)
         check(T, 'curr_state', output['curr_state'], o['curr_state'], 5e-6)
+        # the reference's objects: the masked residual view (trainer.py:308) and CLONES of the four volumes (trainer.py:302-305)
+        ref_masked = o['residuals'][fx['mask']].view(C, -1)
+        assert aux['residuals'].shape == ref_masked.shape
+        check(T, 'aux residuals (masked view)', aux['residuals'], ref_masked, 2e-4)
+        assert output['displacement'].data_ptr() != t._outputs['displacement'].data_ptr()
         check(T, 'v_new', t.v_curr_state, o['v_new'], 0.4 * GRAD_RTOL * float(o['grad_v'].abs().max()) + 1e-5)
         t.v_curr_state.copy_(o['v_new'].to(DEV))
     st = t.sync_parameters()

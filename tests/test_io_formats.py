@@ -117,8 +117,11 @@ def test_biobank_dataset_pipeline(tmp_path):
     dl = BiobankDataLoader(data_dir=str(tmp_path / 'data'), dims=dims, save_dirs={'dir': out})
     (f, m, v), = list(dl)
     assert f['im'].shape == (1, 1, 8, 8, 8) and v['mu'].shape == (1, 3, 8, 8, 8) and dl.im_spacing is not None
-    # no data: falls back to the synthetic pair
-    dl = BiobankDataLoader(data_dir=str(tmp_path / 'nowhere'), dims=dims)
+    # no data: an error, as in the reference (its listdir raises) -- never a silent run on fake data
+    with pytest.raises(FileNotFoundError):
+        BiobankDataLoader(data_dir=str(tmp_path / 'nowhere'), dims=dims)
+    # ... unless the config asks for the synthetic pair in so many words
+    dl = BiobankDataLoader(data_dir=str(tmp_path / 'nowhere'), dims=dims, allow_synthetic_fallback=True)
     (f, m, v), = list(dl)
     assert f['im'].shape == (1, 1, 8, 8, 8) and dl.im_spacing is None
 
