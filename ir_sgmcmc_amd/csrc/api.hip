@@ -621,7 +621,9 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     if (with_noise) launch_perturb(v, io->sigma, io->eps, (float)sqrt(2.0 * (double)cfg.lr), first, C, c->volv, cfg.seed, 0, it, st);
     else HIP_TRY(hipMemcpyAsync(first, v, (size_t)C * 3 * c->volv.V * sizeof(float), hipMemcpyDeviceToDevice, st));
     const bool lds = use_lds_exp();
-    if (lds) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (cfg.no_steps + 1), st));
+    // (the finalize kernel of a transition leaves the bound scratch cleared for the next one)
+    if (lds && !c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (cfg.no_steps + 1), st));
+    c->dmax_clean = false;
     bool have_dmax0 = false;
     if (cfg.sobolev_s > 0) {
         if (env_int("IRS_SOBOLEV_FUSED", 1)) {
@@ -713,6 +715,9 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
         if (depth > 0 && depth <= 3 && cap == hipStreamCaptureStatusNone && c->n_enqueued >= (uint64_t)depth)
             HIP_TRY(hipEventSynchronize(c->ra_ev[(c->n_enqueued - depth) % 4]));
     }
+    if (c->hint && c->hint[kHintWords - 7])
+        return fail("irs_transition: an earlier transition skipped a kernel variant its displacement then needed (results invalid); "
+                    "IRS_PREDICT_VARIANTS=0 launches every variant");
     if (timed) HIP_TRY(hipEventRecord(c->ev[0], st));
     // fused backward warp: the forward warp also writes d(warped)/d(d_last) into gA, and the first adjoint squaring step
     // multiplies it with g_warped while staging (kernels.h: gscale); only on the LDS path, which owns every variant of it
@@ -745,6 +750,7 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     if (timed) HIP_TRY(hipEventRecord(c->ev[3], st));
     const float* dense = c->ffd ? c->dense : vs;
     float* g0 = nullptr;
+    unsigned skipped_r2 = 0;  // steps whose radius-2 adjoint variant is not launched (validated by the finalize kernel)
     {
         // exp_backward ping-pongs between two buffers; the incoming gradient sits in gA, so start writing into gB
         const float* G = c->gA;
@@ -767,9 +773,11 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
                 // 2 voxels; otherwise the (rarely selected) radius-2 kernel owns everything above one voxel -- through its
                 // generic in-kernel fallback if the bound exceeds its ring after all
                 const bool skip_any = rad >= 2 && predicted_below(c, k, 1.5f);
+                const bool skip_r2 = rad >= 2 && skip_any && k < 32 && predicted_tiny(c, k);
+                if (skip_r2) skipped_r2 |= 1u << k;
                 // with the fused backward warp the first step's incoming gradient is the interleaved d(warped)/d(d_n)
                 const int lay = bwd_lay(c, k) | (gscale && aos_enabled() ? 2 : 0);
-                if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, rad, skip_any, gscale, lay,
+                if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, skip_r2 ? 1 : rad, skip_any, gscale, lay,
                                                    timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
                 if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, gscale, lay, c->cmm, st);
             }
@@ -793,7 +801,8 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
         launch_sgld_update(io->v, io->sigma, g0, vs, c->state, cfg.lr, s[0], s[1], s[2], io->grad_v, C, volv, st);
     }
     launch_finalize(c->state, c->nll_partials, c->nll_blocks, c->dcfg, true, use_lds_exp() ? c->dmax : nullptr, c->hint,
-                    4 * C * (cfg.no_steps + 1), st);
+                    4 * C * (cfg.no_steps + 1), skipped_r2, kHintWords - 7, true, st);
+    c->dmax_clean = use_lds_exp();
     LAUNCH_CHECK();
     if (timed) HIP_TRY(hipEventRecord(c->ev[5], st));
     HIP_TRY(hipEventRecord(c->ra_ev[c->n_enqueued % 4], st));
@@ -866,6 +875,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
     switch (stage) {
         case IRS_ST_BEGIN:
             HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * C * (cfg.no_steps + 1), st));
+            c->dmax_clean = false;
             break;
         case IRS_ST_PERTURB:
             if (!io->v) return fail("irs_stage: v is required");
@@ -946,7 +956,7 @@ int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, 
             break;
         }
         case IRS_ST_FINALIZE:
-            launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, nullptr, nullptr, 0, st);
+            launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, nullptr, nullptr, 0, 0u, 0, false, st);
             break;
         default:
             return fail("irs_stage: unknown stage %d", stage);

@@ -73,6 +73,7 @@ struct irs_ctx {
     hipEvent_t ev_bwd[64];
     hipEvent_t ra_ev[4];     // end of the last transitions: bounds how far the host may run ahead of the device
     uint64_t n_enqueued = 0;
+    bool dmax_clean = false;  // the bound scratch was cleared by the finalize kernel of the last transition
     // ---- z-slab decomposition (slab.hip)
     irs::SlabInfo sl;
     irs_comm* comm = nullptr;      // not owned
@@ -111,6 +112,12 @@ inline bool predicted_below(const irs_ctx* c, int k, float bound) {
     return m < bound;
 }
 inline bool predicted_small(const irs_ctx* c, int k) { return predicted_below(c, k, 0.75f); }
+// "max |d_k| is nowhere near one voxel": the radius-2 ADJOINT variant is not even launched.  Unlike the guesses above this one
+// is not backed by a fallback inside the kernel that remains (the radius-1 gather only covers |d| < 1), so it is (a) taken
+// from the production heuristic only, with a 2.5x margin -- d_k moves by O(0.1) voxel per transition and the host is at most
+// two transitions behind -- and (b) VALIDATED on the device: finalize_kernel compares the bounds of the steps whose variant
+// was skipped with 1 and raises a sticky flag that the next irs_transition returns as an error.
+inline bool predicted_tiny(const irs_ctx* c, int k) { return env_int("IRS_PREDICT_VARIANTS", 1) == 1 && predicted_below(c, k, 0.4f); }
 
 // Layouts of the INTERNAL fields of the fused path (exp_kernels.hip: Lay3; bits 1 displacement in, 2 gradient in, 4 out):
 // d_1 .. d_{n-1} and the gradients handed from one adjoint step to the next are interleaved ([V][3]); everything that crosses

@@ -94,8 +94,10 @@ void launch_refresh_derived(DevState* s, DevCfg cfg, hipStream_t st);
 void launch_chain_scalar(DevState* s, const double* stat_partials, int nblocks, int chain, int op, DevCfg cfg,
                          hipStream_t st);
 void launch_reg_scalar(DevState* s, const double* energy_partials, int nblocks, DevCfg cfg, hipStream_t st);
+// `skipped`: bit k set = the radius-2 adjoint variant of step k was not launched (ctx.h: predicted_tiny); a bound >= 1 voxel
+// on such a step raises hint[flag_word] (sticky).  `zero_bounds`: clear the bound scratch for the next transition.
 void launch_finalize(DevState* s, const double* nll_partials, int nblocks_per_chain, DevCfg cfg, bool advance,
-                     const unsigned* bounds, unsigned* hint, int nbounds,
+                     unsigned* bounds, unsigned* hint, int nbounds, unsigned skipped, int flag_word, bool zero_bounds,
                      hipStream_t st);
 void launch_gmm_init_from_moments(DevState* s, const double* moment_partials, int nblocks, DevCfg cfg, hipStream_t st);
 

@@ -67,52 +67,69 @@ void launch_refresh_derived(DevState* s, DevCfg cfg, hipStream_t st) {
 __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const double* __restrict__ partials,
                                                               int nblocks, int chain, int op, DevCfg cfg) {
     __shared__ double smem[kStatVals * (kBlock / kWave)];
+    __shared__ double rs[kStatVals];
+    __shared__ double alpha_s;
     double r[kStatVals];
     reduce_partials<kStatVals>(partials, nblocks, kStatVals, r, smem);
-    if (threadIdx.x != 0) return;
-
-    const double n = r[0];
-    double alpha = (op & 1) ? 1.0 : s->sc.alpha[chain];
-    if (cfg.vd && (op & 1)) {
-        const double var = r[1] / n;
-        double prod = 1.0;
-        for (int a = 0; a < 3; ++a) {
-            const double corr = (r[2 + a] / n) / var;
-            prod *= fmin(-2.0 / 3.14159265358979323846 * log(corr), 1.0);
+    if (threadIdx.x == 0) {
+        const double n = r[0];
+        double alpha = (op & 1) ? 1.0 : s->sc.alpha[chain];
+        if (cfg.vd && (op & 1)) {
+            const double var = r[1] / n;
+            double prod = 1.0;
+            for (int a = 0; a < 3; ++a) {
+                const double corr = (r[2 + a] / n) / var;
+                prod *= fmin(-2.0 / 3.14159265358979323846 * log(corr), 1.0);
+            }
+            alpha = sqrt(prod);  // NaN if a lag-1 correlation is negative, as in the reference
         }
-        alpha = sqrt(prod);  // NaN if a lag-1 correlation is negative, as in the reference
+        s->sc.alpha[chain] = alpha;
+        s->sc.n_mask[chain] = n;
+        alpha_s = alpha;
+#pragma unroll
+        for (int j = 0; j < kStatVals; ++j) rs[j] = r[j];
     }
-    s->sc.alpha[chain] = alpha;
-    s->sc.n_mask[chain] = n;
-
-    if (cfg.mode == IRS_DATA_GMM_LCC && (op & 2)) {
-        const int K = cfg.K;
-        const double* Gs = r + 5;
-        const double* Gl = r + 5 + IRS_MAX_COMPONENTS;
-        // proportions pi = softmax(logits + 1e-2)
-        double pi[IRS_MAX_COMPONENTS], mx = -1e300, sum = 0.0, csum = 0.0;
-        for (int k = 0; k < K; ++k) mx = fmax(mx, (double)s->st.gmm_logits[k]);
-        for (int k = 0; k < K; ++k) sum += exp((double)s->st.gmm_logits[k] - mx);
-        for (int k = 0; k < K; ++k) {
-            pi[k] = exp((double)s->st.gmm_logits[k] - mx) / sum;
-            csum += (double)cfg.conc[k] - 1.0;
-        }
-        const double sp2 = (double)cfg.scale_prior_scale * (double)cfg.scale_prior_scale;
-        const int64_t step0 = s->st.gmm_adam_step[0], step1 = s->st.gmm_adam_step[1];
-        for (int k = 0; k < K; ++k) {
+    __syncthreads();
+    if (!(cfg.mode == IRS_DATA_GMM_LCC && (op & 2))) return;
+    // one GMM Adam step (trainer.py:68-77), one lane per parameter: lanes 0 .. K-1 the log std, K .. 2K-1 the logits (the
+    // fp64 pow / exp / sqrt of sixteen serial updates on one lane were 20 us of every transition)
+    const int K = cfg.K;
+    const int t = threadIdx.x;
+    if (t < 2 * K) {
+        const double n = rs[0], alpha = alpha_s;
+        const double* Gs = rs + 5;
+        const double* Gl = rs + 5 + IRS_MAX_COMPONENTS;
+        const int k = t < K ? t : t - K;
+        float newv;
+        if (t < K) {
+            const double sp2 = (double)cfg.scale_prior_scale * (double)cfg.scale_prior_scale;
             // d/dlog_std_k [alpha NLL - log N(log_std; loc, scale)]
             const double g_ls = alpha * Gs[k] + ((double)s->st.gmm_log_std[k] - (double)cfg.scale_prior_loc) / sp2;
+            newv = (float)adam_step_decay((double)s->st.gmm_log_std[k], g_ls, s->st.gmm_adam_m[0][k], s->st.gmm_adam_v[0][k],
+                                          s->st.gmm_adam_step[0], cfg.gmm_lr_log_std, cfg.gmm_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
+        } else {
+            // proportions pi = softmax(logits + 1e-2)
+            double mx = -1e300, sum = 0.0, csum = 0.0;
+            for (int j = 0; j < K; ++j) mx = fmax(mx, (double)s->st.gmm_logits[j]);
+            for (int j = 0; j < K; ++j) {
+                sum += exp((double)s->st.gmm_logits[j] - mx);
+                csum += (double)cfg.conc[j] - 1.0;
+            }
+            const double pik = exp((double)s->st.gmm_logits[k] - mx) / sum;
             // d/dlogit_k [alpha NLL - log Dir(log pi)]
-            const double g_lg = alpha * (-Gl[k] + pi[k] * n) + (-((double)cfg.conc[k] - 1.0) + pi[k] * csum);
-            s->st.gmm_log_std[k] = (float)adam_step_decay((double)s->st.gmm_log_std[k], g_ls, s->st.gmm_adam_m[0][k],
-                                                          s->st.gmm_adam_v[0][k], step0, cfg.gmm_lr_log_std,
-                                                          cfg.gmm_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
-            s->st.gmm_logits[k] = (float)adam_step_decay((double)s->st.gmm_logits[k], g_lg, s->st.gmm_adam_m[1][k],
-                                                         s->st.gmm_adam_v[1][k], step1, cfg.gmm_lr_logits,
-                                                         cfg.gmm_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
+            const double g_lg = alpha * (-Gl[k] + pik * n) + (-((double)cfg.conc[k] - 1.0) + pik * csum);
+            newv = (float)adam_step_decay((double)s->st.gmm_logits[k], g_lg, s->st.gmm_adam_m[1][k], s->st.gmm_adam_v[1][k],
+                                          s->st.gmm_adam_step[1], cfg.gmm_lr_logits, cfg.gmm_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
         }
-        s->st.gmm_adam_step[0] = step0 + 1;
-        s->st.gmm_adam_step[1] = step1 + 1;
+        // every lane has read the old parameters (the logit lanes read all K of them) before any lane writes: one wavefront,
+        // and the writes below come after the reads above in program order for the whole wave
+        if (t < K) s->st.gmm_log_std[k] = newv;
+        else s->st.gmm_logits[k] = newv;
+    }
+    __syncthreads();
+    if (t == 0) {
+        s->st.gmm_adam_step[0] += 1;
+        s->st.gmm_adam_step[1] += 1;
         refresh_derived(s, cfg);
     }
 }
@@ -216,13 +233,23 @@ void launch_reg_scalar(DevState* s, const double* energy_partials, int nblocks, 
 // data_term[c] = alpha_c * sum(-log p(z_c)) with the parameters in force for chain c; advance the Philox counter
 __global__ __launch_bounds__(kBlock) void finalize_kernel(DevState* s, const double* __restrict__ partials,
                                                           int nblocks_per_chain, DevCfg cfg, int advance,
-                                                          const unsigned* __restrict__ bounds, unsigned* __restrict__ hint,
-                                                          int nbounds) {
+                                                          unsigned* __restrict__ bounds, unsigned* __restrict__ hint,
+                                                          int nbounds, unsigned skipped, int flag_word, int zero_bounds) {
     __shared__ double smem[kBlock / kWave];
     // publish the displacement bounds of this transition to pinned host memory (the host reads them unsynchronised, as a
     // hint for which kernel variants to launch next time)
-    if (bounds && hint)
-        for (int i = threadIdx.x; i < nbounds; i += kBlock) hint[i] = bounds[i];
+    if (bounds && hint) {
+        unsigned bad = 0;
+        for (int i = threadIdx.x; i < nbounds; i += kBlock) {
+            const unsigned b = bounds[i];
+            hint[i] = b;
+            // a step whose radius-2 adjoint variant was not launched must have stayed below one voxel
+            const int k = i / (4 * cfg.C);
+            if (k < 32 && ((skipped >> k) & 1u) && !(__uint_as_float(b) < 1.0f)) bad = 1;
+            if (zero_bounds) bounds[i] = 0u;
+        }
+        if (bad) atomicAdd(hint + flag_word, 1u);
+    }
     for (int c = 0; c < cfg.C; ++c) {
         double acc[1] = {0.0};
         for (int b = threadIdx.x; b < nblocks_per_chain; b += kBlock) acc[0] += partials[(int64_t)c * nblocks_per_chain + b];
@@ -234,9 +261,10 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(DevState* s, const dou
 }
 
 void launch_finalize(DevState* s, const double* nll_partials, int nblocks_per_chain, DevCfg cfg, bool advance,
-                     const unsigned* bounds, unsigned* hint, int nbounds, hipStream_t st) {
+                     unsigned* bounds, unsigned* hint, int nbounds, unsigned skipped, int flag_word, bool zero_bounds,
+                     hipStream_t st) {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, st, s, nll_partials, nblocks_per_chain, cfg,
-                       advance ? 1 : 0, bounds, hint, nbounds);
+                       advance ? 1 : 0, bounds, hint, nbounds, skipped, flag_word, zero_bounds ? 1 : 0);
 }
 
 // GMM.init_parameters (model/loss.py:61-65) from the unbiased std of the masked residuals (trainer.py:537-541)

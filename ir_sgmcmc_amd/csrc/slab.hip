@@ -352,7 +352,8 @@ int slab_forward(irs_ctx* c, Pipe& p, const irs_io& io, const float* v_src, floa
     auto W = [&](int e) { return window(c->vol, s.a - (s.has_lo ? e : 0), s.b + (s.has_hi ? e : 0)); };
     float* noisy = planar(c->tmpA, v);
 
-    HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));
+    if (!c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));
+    c->dmax_clean = false;
     // the first forward round lives off ghost planes of v_s that the smoothing stage computes itself from a wider exchange
     // of the perturbed velocity
     const int e0 = exact ? 1 : (plan.fw[0] > 1 ? plan.fw[0] : 1);
@@ -678,7 +679,8 @@ int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
     Used used;
     for (int k = 0; k < kMaxSteps; ++k) used.h[k] = k < n ? plan.h[k] : 0;
     hipLaunchKernelGGL(validate_widths_kernel, dim3(1), dim3(64), 0, st, c->dmax, used, n, C, c->hint + (kHintWords - 8));
-    launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, c->dmax, c->hint, 4 * C * (n + 1), st);
+    launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, c->dmax, c->hint, 4 * C * (n + 1), 0u, 0, true, st);
+    c->dmax_clean = true;
     LAUNCH_CHECK();
     HIP_TRY(hipEventRecord(c->ra_ev[c->n_enqueued % 4], st));
     ++c->n_enqueued;
