@@ -360,6 +360,35 @@ int irs_slab_status_get(irs_ctx* ctx, irs_slab_status* out, void* stream);
 int irs_slab_plan_rounds(const int32_t* h, int n, int ghost_max, int min_slab, int32_t* fwd_round, int32_t* fwd_width,
                          int32_t* n_fwd, int32_t* bwd_round, int32_t* bwd_width, int32_t* n_bwd);
 
+/* The schedule of one planned transition of rank `rank`, as data -- the list the executor inside irs_slab_transition
+ * interprets, built by the same host code (tests replay it on the CPU over two gloo ranks: tests/test_slab_schedule.py).
+ * h[0..no_steps): ghost width of every squaring step.  n_ops receives the number of operations (also when max_ops is 0). */
+enum { IRS_OP_LAUNCH = 0, IRS_OP_EXCHANGE = 1, IRS_OP_ALLREDUCE = 2, IRS_OP_WAIT = 3 };
+enum {  /* launch stages */
+    IRS_SG_PERTURB = 0, IRS_SG_COPY_V, IRS_SG_SMOOTH, IRS_SG_ENERGY, IRS_SG_EXP_FWD, IRS_SG_OUTPUTS, IRS_SG_WARP, IRS_SG_RESIDUAL,
+    IRS_SG_STATS, IRS_SG_DATA_BWD, IRS_SG_WARP_BWD, IRS_SG_EXP_BWD, IRS_SG_UPDATE,
+    IRS_SG_SCALARS = 32,  /* single-workgroup stages from here on (no output window) */
+    IRS_SG_CHAIN_SCALAR = 32, IRS_SG_REG_SCALAR, IRS_SG_FINALIZE
+};
+enum {  /* buffers */
+    IRS_SB_V = 0, IRS_SB_NOISY, IRS_SB_VS, IRS_SB_WARPED, IRS_SB_Z, IRS_SB_GM, IRS_SB_GRAD_A, IRS_SB_GRAD_B,
+    IRS_SB_STEP0 = 16  /* + k: output of squaring step k */
+};
+enum { IRS_AR_ENERGY = 0, IRS_AR_DMAX = 1, IRS_AR_NLL = 2, IRS_AR_STATS = 3, IRS_AR_MOMENTS = 7 };
+typedef struct irs_slab_op {
+    int32_t kind;              /* IRS_OP_* */
+    int32_t stage;             /* launch: IRS_SG_*; exchange: the buffer (IRS_SB_*); all-reduce: IRS_AR_* */
+    int32_t k;                 /* squaring step / chain */
+    int32_t lo0, hi0, lo1, hi1;/* launch: output window [lo0, hi0) and, for boundary strips, a second one [lo1, hi1) */
+    int32_t in0, in1;          /* launch: buffers read with a z reach (-1: none) */
+    int32_t reach;             /* launch: planes beyond the output window(s) read from in0 / in1 */
+    int32_t out;               /* launch: buffer written (-1: none) */
+    int32_t width;             /* exchange: ghost planes per side */
+    int32_t id;                /* exchange / all-reduce: its id; wait: the id waited for */
+} irs_slab_op;
+int irs_slab_trace(const irs_config* cfg, const irs_slab_config* scfg, int rank, int world, const int32_t* h, irs_slab_op* ops,
+                   int max_ops, int32_t* n_ops);
+
 const char* irs_last_error(void);
 const char* irs_version(void);
 

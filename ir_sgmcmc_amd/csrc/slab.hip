@@ -16,6 +16,7 @@
 // to pinned memory by the finalize kernel of an earlier transition) with a safety factor, and is validated on the device.
 #include <math.h>
 #include <new>
+#include <vector>
 
 #include "comm.h"
 #include "ctx.h"
@@ -75,9 +76,12 @@ int plan_rounds(Plan& p, int gmax, int min_slab) {
                 N += p.h[k];
                 ok = N <= E[k];
             }
-            // at most two steps: the adjoint ping-pongs between two gradient buffers, so the interior of a third step would
-            // overwrite planes of the buffer whose boundary strips are still being sent
-            if (!ok || N > gmax || k1 - c0 + 1 > 2) break;
+            // The adjoint ping-pongs between two gradient buffers: the second step of a round writes its interior into the
+            // buffer the round's exchange carries and the first step's boundary strips still read.  That is safe for at most
+            // two steps (a third interior would reach the strips being sent) and only while the first step's strips, which
+            // read 2 h_first planes into the slab, end before the second interior begins at h_first + h_second: h_first <=
+            // h_second (tests/test_slab_schedule.py replays exactly this).
+            if (!ok || N > gmax || k1 - c0 + 1 > 2 || p.h[k1] > p.h[c0]) break;
             k0 = c0;
         }
         int wsum = 0;
@@ -180,126 +184,6 @@ int exchange_planes(irs_ctx* c, float* virt, int kind, int chains, int w, hipStr
     return 0;
 }
 
-// events of the pipeline: a rotating pool (an event may be re-recorded once the waits that named it have been enqueued)
-struct Pipe {
-    irs_ctx* c;
-    hipStream_t st, cs;
-    int next = 0;
-    hipEvent_t take() { return c->sev[(next++) % 16]; }
-};
-
-// exchange `w` planes of a buffer whose boundary strips are final on `st` NOW; returns the event `st` must wait for before
-// it reads the ghost planes (nullptr: nothing was exchanged)
-int start_exchange(Pipe& p, float* virt, int kind, int chains, int w, hipEvent_t* recv_ev) {
-    *recv_ev = nullptr;
-    if (p.c->sl.world == 1 || w <= 0) return 0;
-    hipEvent_t prod = p.take(), recv = p.take();
-    HIP_TRY(hipEventRecord(prod, p.st));
-    HIP_TRY(hipStreamWaitEvent(p.cs, prod, 0));
-    if (exchange_planes(p.c, virt, kind, chains, w, p.cs)) return 1;
-    HIP_TRY(hipEventRecord(recv, p.cs));
-    *recv_ev = recv;
-    return 0;
-}
-int wait_exchange(Pipe& p, hipEvent_t recv_ev) {
-    if (recv_ev) HIP_TRY(hipStreamWaitEvent(p.st, recv_ev, 0));
-    return 0;
-}
-// small all-reduce of `buf`, which `st` has just produced; returns the event to wait for before `st` reads it again.
-// `slot` names a dedicated event pair: these results are waited for much later than the exchanges in between.
-enum { AR_ENERGY = 0, AR_DMAX, AR_NLL, AR_STATS };
-int start_allreduce(Pipe& p, void* buf, size_t count, int max_u32, int slot, hipEvent_t* done) {
-    *done = nullptr;
-    if (p.c->sl.world == 1) return 0;
-    hipEvent_t prod = p.c->sev[16 + 2 * slot], fin = p.c->sev[17 + 2 * slot];
-    HIP_TRY(hipEventRecord(prod, p.st));
-    HIP_TRY(hipStreamWaitEvent(p.cs, prod, 0));
-    if (comm_allreduce(p.c->comm, buf, count, max_u32, p.cs)) return 1;
-    HIP_TRY(hipEventRecord(fin, p.cs));
-    *done = fin;
-    return 0;
-}
-
-// all-reduce whose result `st` needs at once (one-off stages, the measuring mode)
-int allreduce_now(Pipe& p, void* buf, size_t count, int max_u32) {
-    hipEvent_t done;
-    if (start_allreduce(p, buf, count, max_u32, AR_STATS, &done)) return 1;
-    if (done) HIP_TRY(hipStreamWaitEvent(p.st, done, 0));
-    return 0;
-}
-
-// windows of one step of a round: e = planes beyond the slab its output must cover, r = how far into the slab outputs
-// depend on ghost planes.  Sides without a neighbour have neither.
-struct StepWin {
-    Vol interior, boundary;
-};
-StepWin step_windows(const irs_ctx* c, int e, int r, bool split) {
-    const SlabInfo& s = c->sl;
-    const int elo = s.has_lo ? e : 0, ehi = s.has_hi ? e : 0;
-    const int ilo = s.a + (s.has_lo ? r : 0), ihi = s.b - (s.has_hi ? r : 0);
-    StepWin w;
-    if (!split || s.world == 1 || ihi <= ilo) {  // one launch over everything (counted as "boundary": it needs the ghosts)
-        w.interior = window(c->vol, 0, 0);
-        w.boundary = window(c->vol, s.a - elo, s.b + ehi);
-        if (!split || s.world == 1) {
-            w.interior = w.boundary;
-            w.boundary = window(c->vol, 0, 0);
-        }
-        return w;
-    }
-    w.interior = window(c->vol, ilo, ihi);
-    w.boundary = window2(c->vol, s.has_lo ? s.a - e : 0, s.has_lo ? ilo : 0, s.has_hi ? ihi : 0, s.has_hi ? s.b + e : 0);
-    return w;
-}
-
-void fwd_step(irs_ctx* c, const Views& v, const float* vs, int k, int chains, Vol w, hipStream_t st) {
-    if (w.nz + w.nzb <= 0) return;
-    const float* in = k == 0 ? vs : step_buf(c, v, k - 1);
-    launch_exp_step_fwd_march(in, step_buf(c, v, k), k == 0, c->cfg.no_steps, chains, w, c->lin.lin(), c->dmax + (int64_t)k * c->C * 4,
-                              c->dmax + (int64_t)(k + 1) * c->C * 4, predicted_small(c, k), fwd_lay(c, k), st);
-}
-
-// `hplan`: the ghost width this transition was planned with for step k (0: unknown, launch every variant).  The plan is
-// validated against the measured bound afterwards (validate_widths_kernel: floor(max|d_k|) + 1 <= hplan, else the transition
-// is flagged invalid), so the variants that can only be selected above it need not be launched at all: hplan = 1 leaves the
-// radius-1 gather alone -- 24 idle launches less per transition than the fused path, which has no such guarantee.
-void bwd_step(irs_ctx* c, const Views& v, const float* vs, int k, int hplan, Vol w, hipStream_t st) {
-    if (w.nz + w.nzb <= 0) return;
-    const int lay = bwd_lay(c, k);
-    float* gi = grad_raw(c, k, true);
-    float* go = grad_raw(c, k, false);
-    const float* G = (lay & 2) ? aos(gi, v) : planar(gi, v);
-    float* out = (lay & 4) ? aos(go, v) : planar(go, v);
-    const float* dk = k == 0 ? vs : step_buf(c, v, k - 1);
-    const unsigned* dm = c->dmax + (int64_t)k * c->C * 4;
-    const bool skip_any = (hplan >= 1 && hplan <= 2) || predicted_below(c, k, 1.5f);
-    launch_exp_step_bwd_march(G, dk, out, k == 0, c->cfg.no_steps, c->C, w, c->lin.lin(), dm, hplan == 1 ? 1 : 2, skip_any, nullptr, lay, nullptr, st);
-    // the any-radius kernel bounds its sources by the global bound around the tile (no coarse grid: that one spans the volume)
-    if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, c->cfg.no_steps, c->C, w, c->lin.lin(), dm, 2, 2, nullptr, lay, nullptr, st);
-}
-
-// one round: [exchange of `xbuf`] + steps ks[0..m) in execution order with ghost widths hs[]
-template <typename StepFn>
-int run_round(Pipe& p, float* xbuf, int xkind, int chains, int w, const int* ks, const int* hs, int m, StepFn step) {
-    irs_ctx* c = p.c;
-    hipEvent_t recv = nullptr;
-    if (start_exchange(p, xbuf, xkind, chains, w, &recv)) return 1;
-    const bool split = recv != nullptr;
-    StepWin wins[kMaxSteps];
-    int r = 0;
-    for (int i = 0; i < m; ++i) {
-        r += hs[i];
-        wins[i] = step_windows(c, w - r, r, split);
-        step(ks[i], wins[i].interior);
-    }
-    if (split) {
-        if (wait_exchange(p, recv)) return 1;
-        for (int i = 0; i < m; ++i) step(ks[i], wins[i].boundary);
-    }
-    LAUNCH_CHECK();
-    return 0;
-}
-
 // validation of the planned ghost widths against the (all-reduced) bounds of this transition; sticky flag in pinned memory
 struct Used {
     int h[kMaxSteps];
@@ -308,6 +192,7 @@ __global__ void validate_widths_kernel(const unsigned* __restrict__ dmax, Used u
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned bad = 0;
     for (int k = 0; k < n; ++k) {
+        if (used.h[k] <= 0) continue;  // measured on the fly: nothing planned to validate
         float m = 0.0f;
         for (int i = 0; i < C * 4; ++i) m = fmaxf(m, __uint_as_float(dmax[k * C * 4 + i]));
         if (!(m >= 0.0f) || (int)floorf(m) + 1 > used.h[k]) bad = 1;
@@ -315,6 +200,412 @@ __global__ void validate_widths_kernel(const unsigned* __restrict__ dmax, Used u
     if (bad) flags[0] += 1;
 }
 
+// ================================================================================================
+// The schedule of a transition as DATA: a pure-host builder emits a list of operations (launches with their output windows,
+// exchanges, all-reduces, the waits that tie the two streams together); the executor below interprets it on the GPU, and
+// irs_slab_trace hands the same list to the tests, which replay it on the CPU with two gloo ranks (tests/test_slab_schedule.py).
+// ================================================================================================
+struct Sched {
+    const SlabInfo& s;
+    const irs_config& cfg;
+    Vol vol;
+    int chains;
+    std::vector<irs_slab_op> ops;
+    int next_id = 0;
+
+    Sched(const SlabInfo& s_, const irs_config& cfg_, int chains_) : s(s_), cfg(cfg_), vol(make_vol(cfg_.dims[0], cfg_.dims[1], cfg_.dims[2])), chains(chains_) {}
+    Vol W(int e) const { return window(vol, s.a - (s.has_lo ? e : 0), s.b + (s.has_hi ? e : 0)); }
+    int step_buf_id(int k) const { return k < 0 ? IRS_SB_VS : IRS_SB_STEP0 + k; }
+    // dL/d(d_last) lands in A; adjoint step n-1 writes B, the next one A, ...
+    int grad_id(int k, bool input) const {
+        const bool odd = ((cfg.no_steps - k) & 1) != 0;
+        return (odd == input) ? IRS_SB_GRAD_A : IRS_SB_GRAD_B;
+    }
+    void launch(int stage, int k, Vol w, int in0, int in1, int reach, int out) {
+        if (w.nz + w.nzb <= 0 && stage < IRS_SG_SCALARS) return;  // empty window: nothing to launch
+        irs_slab_op o;
+        memset(&o, 0, sizeof(o));
+        o.kind = IRS_OP_LAUNCH;
+        o.stage = stage;
+        o.k = k;
+        o.lo0 = w.z0;
+        o.hi0 = w.z0 + w.nz;
+        o.lo1 = w.nzb > 0 ? w.z0b : 0;
+        o.hi1 = w.nzb > 0 ? w.z0b + w.nzb : 0;
+        o.in0 = in0;
+        o.in1 = in1;
+        o.reach = reach;
+        o.out = out;
+        ops.push_back(o);
+    }
+    int comm(int kind, int what, int width) {  // EXCHANGE of buffer `what` / ALLREDUCE of reduction `what`; returns its id
+        irs_slab_op o;
+        memset(&o, 0, sizeof(o));
+        o.kind = kind;
+        o.stage = what;
+        o.width = width;
+        o.id = next_id++;
+        o.in0 = o.in1 = o.out = -1;
+        ops.push_back(o);
+        return o.id;
+    }
+    int exchange(int buf, int width) {
+        if (s.world == 1 || width <= 0) return -1;
+        return comm(IRS_OP_EXCHANGE, buf, width);
+    }
+    int allreduce(int which) { return s.world == 1 ? -1 : comm(IRS_OP_ALLREDUCE, which, 0); }
+    void wait(int id) {
+        if (id < 0) return;
+        irs_slab_op o;
+        memset(&o, 0, sizeof(o));
+        o.kind = IRS_OP_WAIT;
+        o.id = id;
+        o.in0 = o.in1 = o.out = -1;
+        ops.push_back(o);
+    }
+
+    // windows of one step of a round: e = planes beyond the slab its output must cover, r = how far into the slab outputs
+    // depend on ghost planes.  Sides without a neighbour have neither.
+    void step_windows(int e, int r, bool split, Vol* interior, Vol* boundary) const {
+        const int elo = s.has_lo ? e : 0, ehi = s.has_hi ? e : 0;
+        const int ilo = s.a + (s.has_lo ? r : 0), ihi = s.b - (s.has_hi ? r : 0);
+        if (!split) {
+            *interior = window(vol, s.a - elo, s.b + ehi);
+            *boundary = window(vol, 0, 0);
+        } else if (ihi <= ilo) {  // the slab is all boundary: one launch, after the ghost planes have arrived
+            *interior = window(vol, 0, 0);
+            *boundary = window(vol, s.a - elo, s.b + ehi);
+        } else {
+            *interior = window(vol, ilo, ihi);
+            *boundary = window2(vol, s.has_lo ? s.a - e : 0, s.has_lo ? ilo : 0, s.has_hi ? ihi : 0, s.has_hi ? s.b + e : 0);
+        }
+    }
+
+    // one round: [exchange of `xbuf`, w planes] + steps ks[0..m) in execution order with ghost widths hs[]: the interiors while
+    // the exchange is in flight, the boundary strips when the ghost planes have arrived
+    void round(bool backward, int xbuf, int w, const int* ks, const int* hs, int m) {
+        const int id = exchange(xbuf, w);
+        const bool split = id >= 0;
+        Vol in[kMaxSteps], bd[kMaxSteps];
+        int r = 0;
+        for (int i = 0; i < m; ++i) {
+            r += hs[i];
+            step_windows(w - r, r, split, &in[i], &bd[i]);
+            step(backward, ks[i], hs[i], in[i]);
+        }
+        if (split) {
+            wait(id);
+            for (int i = 0; i < m; ++i) step(backward, ks[i], hs[i], bd[i]);
+        }
+    }
+    void step(bool backward, int k, int h, Vol w) {
+        if (!backward) launch(IRS_SG_EXP_FWD, k, w, step_buf_id(k - 1), -1, h, step_buf_id(k));
+        else launch(IRS_SG_EXP_BWD, k, w, grad_id(k, true), step_buf_id(k - 1), h, grad_id(k, false));
+    }
+
+    // perturbation, smoothing (on slab +- e0, fed by a wider exchange of the perturbed velocity), regulariser energy
+    void head(bool noise, bool energy, int e0, int* energy_ar) {
+        const int sb = cfg.sobolev_s;
+        const int first = sb > 0 ? IRS_SB_NOISY : IRS_SB_VS;
+        launch(noise ? IRS_SG_PERTURB : IRS_SG_COPY_V, 0, W(0), IRS_SB_V, -1, 0, first);
+        wait(exchange(first, sb + e0));
+        launch(IRS_SG_SMOOTH, 0, W(e0), first, -1, sb, IRS_SB_VS);
+        *energy_ar = -1;
+        if (energy) {
+            launch(IRS_SG_ENERGY, 0, W(0), IRS_SB_VS, -1, 1, -1);
+            *energy_ar = allreduce(IRS_AR_ENERGY);
+        }
+    }
+    void forward_planned(const Plan& p) {
+        const int n = cfg.no_steps;
+        for (int r = 0; r < p.nf; ++r) {
+            int ks[kMaxSteps], hs[kMaxSteps], m = 0;
+            for (int k = 0; k < n; ++k)
+                if (p.fr[k] == r) {
+                    ks[m] = k;
+                    hs[m++] = p.h[k];
+                }
+            if (r == 0) {  // no exchange: v_s is valid on slab +- e0 >= fw[0]; single launches on the shrinking windows
+                int rr = 0;
+                for (int i = 0; i < m; ++i) {
+                    rr += hs[i];
+                    step(false, ks[i], hs[i], W(p.fw[0] - rr));
+                }
+            } else round(false, step_buf_id(ks[0] - 1), p.fw[r], ks, hs, m);
+        }
+    }
+    void forward_exact_step(int k, int h) {  // measuring mode: one step per round, width just read back
+        if (k == 0) step(false, 0, h, W(0));
+        else round(false, step_buf_id(k - 1), h, &k, &h, 1);
+    }
+    // outputs, warp, residual
+    void middle(bool outputs) {
+        const int n = cfg.no_steps;
+        if (outputs) launch(IRS_SG_OUTPUTS, 0, W(0), step_buf_id(n - 1), -1, 0, -1);
+        launch(IRS_SG_WARP, 0, W(0), step_buf_id(n - 1), -1, 0, IRS_SB_WARPED);
+        if (cfg.data_loss == IRS_DATA_GMM_LCC) {
+            const int ls = cfg.lcc_s;
+            wait(exchange(IRS_SB_WARPED, 4 * ls));
+            launch(IRS_SG_RESIDUAL, 0, W(2 * ls), IRS_SB_WARPED, -1, 2 * ls, IRS_SB_Z);
+        } else {
+            const int e = cfg.virtual_decimation ? 1 : 0;  // the lag-1 products of the VD statistics read one plane up
+            wait(exchange(IRS_SB_WARPED, e));
+            launch(IRS_SG_RESIDUAL, 0, window(vol, s.a, s.b + (s.has_hi ? e : 0)), IRS_SB_WARPED, -1, 0, IRS_SB_Z);
+        }
+    }
+    // statistics / mixture step / data term per chain, backward warp, the adjoint rounds, update
+    void backward_and_update(const Plan& p, bool stats, int energy_ar) {
+        const int n = cfg.no_steps, ls = cfg.data_loss == IRS_DATA_GMM_LCC ? cfg.lcc_s : 0;
+        // bounds of every d_k, all-reduced: variant selection of the adjoint steps, the next plans, the validation of this one
+        const int dmax_ar = allreduce(IRS_AR_DMAX);
+        for (int ch = 0; ch < chains; ++ch) {
+            if (stats) {
+                launch(IRS_SG_STATS, ch, W(0), IRS_SB_Z, -1, cfg.virtual_decimation ? 1 : 0, -1);
+                wait(allreduce(IRS_AR_STATS));
+                launch(IRS_SG_CHAIN_SCALAR, ch, W(0), -1, -1, 0, -1);
+            }
+            launch(IRS_SG_DATA_BWD, ch, W(0), IRS_SB_Z, -1, 2 * ls, IRS_SB_GM);
+        }
+        const int nll_ar = allreduce(IRS_AR_NLL);
+        launch(IRS_SG_WARP_BWD, 0, W(0), IRS_SB_GM, step_buf_id(n - 1), 0, IRS_SB_GRAD_A);
+        wait(dmax_ar);
+        for (int r = 0; r < p.nb; ++r) {
+            int ks[kMaxSteps], hs[kMaxSteps], m = 0;
+            for (int k = n - 1; k >= 0; --k)
+                if (p.br[k] == r) {
+                    ks[m] = k;
+                    hs[m++] = p.h[k];
+                }
+            round(true, grad_id(ks[0], true), p.bw[r], ks, hs, m);
+        }
+        // regulariser scalars (their all-reduce has been in flight since the smoothing stage), update, bookkeeping
+        wait(energy_ar);
+        launch(IRS_SG_REG_SCALAR, 0, W(0), -1, -1, 0, -1);
+        launch(IRS_SG_UPDATE, 0, W(0), grad_id(0, false), IRS_SB_VS, 1, IRS_SB_V);
+        wait(nll_ar);
+        launch(IRS_SG_FINALIZE, 0, W(0), -1, -1, 0, -1);
+    }
+};
+
+// ---- executor --------------------------------------------------------------------------------------------------------------
+struct Exec {
+    irs_ctx* c;
+    hipStream_t st, cs;
+    const irs_io& io;     // shifted
+    const float* v_src;   // velocity the forward pass starts from (io.v, or the staged sample of the mixture initialisation)
+    float *vs, *warped, *z;
+    const Plan* plan;     // ghost widths of the adjoint steps (variant selection); may be null before they are known
+    bool jitter;
+    int chains;
+    int next_ev = 0;
+    hipEvent_t pending[128];  // event to wait for, by comm id (ids of one transition are < 128)
+
+    hipEvent_t take() { return c->sev[(next_ev++) % 16]; }
+    float* buffer(int id, const Views& v, int* kind) const {
+        const int n = c->cfg.no_steps;
+        switch (id) {
+            case IRS_SB_V: *kind = F_PLANAR3; return const_cast<float*>(v_src);
+            case IRS_SB_NOISY: *kind = F_PLANAR3; return planar(c->tmpA, v);
+            case IRS_SB_VS: *kind = F_PLANAR3; return vs;
+            case IRS_SB_WARPED: *kind = F_IMAGE; return warped;
+            case IRS_SB_Z: *kind = F_IMAGE; return z;
+            case IRS_SB_GM: *kind = F_IMAGE; return planar(c->gM, v);
+            case IRS_SB_GRAD_A:
+            case IRS_SB_GRAD_B: {
+                // the layout of a gradient buffer is that of the adjoint step that READS it next
+                float* raw = id == IRS_SB_GRAD_A ? c->gA : c->gB;
+                bool a = false;
+                for (int k = 0; k < n; ++k)
+                    if (grad_raw(c, k, true) == raw && cur_bwd_k == k) a = (bwd_lay(c, k) & 2) != 0;
+                *kind = a ? F_AOS3 : F_PLANAR3;
+                return a ? aos(raw, v) : planar(raw, v);
+            }
+            default:
+                if (id >= IRS_SB_STEP0 && id < IRS_SB_STEP0 + n) {
+                    *kind = step_is_aos(c, id - IRS_SB_STEP0) ? F_AOS3 : F_PLANAR3;
+                    return step_buf(c, v, id - IRS_SB_STEP0);
+                }
+                *kind = -1;
+                return nullptr;
+        }
+    }
+    int cur_bwd_k = -1;  // the adjoint step whose input buffer an exchange is about to carry
+
+    int run(const irs_slab_op* ops, int n_ops) {
+        for (int i = 0; i < n_ops; ++i) {
+            const irs_slab_op& o = ops[i];
+            if (o.kind == IRS_OP_LAUNCH) {
+                if (launch(o)) return 1;
+            } else if (o.kind == IRS_OP_EXCHANGE) {
+                // the adjoint step that follows names the layout of a gradient buffer
+                cur_bwd_k = -1;
+                for (int j = i + 1; j < n_ops; ++j)
+                    if (ops[j].kind == IRS_OP_LAUNCH) {
+                        if (ops[j].stage == IRS_SG_EXP_BWD) cur_bwd_k = ops[j].k;
+                        break;
+                    }
+                if (exchange(o)) return 1;
+            } else if (o.kind == IRS_OP_ALLREDUCE) {
+                if (allreduce(o)) return 1;
+            } else if (o.kind == IRS_OP_WAIT) {
+                if (o.id < 0 || o.id >= 128) return fail("slab: bad wait id %d", o.id);
+                if (pending[o.id]) HIP_TRY(hipStreamWaitEvent(st, pending[o.id], 0));
+            } else return fail("slab: unknown op kind %d", o.kind);
+        }
+        LAUNCH_CHECK();
+        return 0;
+    }
+    int exchange(const irs_slab_op& o) {
+        if (o.id < 0 || o.id >= 128) return fail("slab: bad exchange id %d", o.id);
+        const Views v = views(c);
+        int kind;
+        float* buf = buffer(o.stage, v, &kind);
+        if (!buf) return fail("slab: exchange of unknown buffer %d", o.stage);
+        hipEvent_t prod = take(), recv = take();
+        HIP_TRY(hipEventRecord(prod, st));
+        HIP_TRY(hipStreamWaitEvent(cs, prod, 0));
+        if (exchange_planes(c, buf, kind, chains, o.width, cs)) return 1;
+        HIP_TRY(hipEventRecord(recv, cs));
+        pending[o.id] = recv;
+        return 0;
+    }
+    int allreduce(const irs_slab_op& o) {
+        if (o.id < 0 || o.id >= 128) return fail("slab: bad all-reduce id %d", o.id);
+        const int n = c->cfg.no_steps;
+        void* buf;
+        size_t count;
+        int mx = 0;
+        switch (o.stage) {
+            case IRS_AR_ENERGY: buf = c->energy_sum; count = (size_t)chains; break;
+            case IRS_AR_STATS: buf = c->stat_sum; count = kStatVals; break;
+            case IRS_AR_NLL: buf = c->nll_sum; count = (size_t)chains; break;
+            case IRS_AR_DMAX: buf = c->dmax; count = (size_t)4 * c->C * (n + 1); mx = 1; break;
+            case IRS_AR_MOMENTS: buf = c->stat_sum; count = 3; break;
+            default: return fail("slab: unknown all-reduce %d", o.stage);
+        }
+        // a dedicated event pair per reduction: these results are waited for much later than the exchanges in between
+        hipEvent_t prod = c->sev[16 + 2 * (o.stage % 4)], fin = c->sev[17 + 2 * (o.stage % 4)];
+        HIP_TRY(hipEventRecord(prod, st));
+        HIP_TRY(hipStreamWaitEvent(cs, prod, 0));
+        if (comm_allreduce(c->comm, buf, count, mx, cs)) return 1;
+        HIP_TRY(hipEventRecord(fin, cs));
+        pending[o.id] = fin;
+        return 0;
+    }
+    int launch(const irs_slab_op& o) {
+        const irs_config& cfg = c->cfg;
+        const Views v = views(c);
+        const int n = cfg.no_steps, C = chains;
+        const Vol w = o.hi1 > o.lo1 ? window2(c->vol, o.lo0, o.hi0, o.lo1, o.hi1) : window(c->vol, o.lo0, o.hi0);
+        const Lin lin = c->lin.lin();
+        const uint64_t* it = &c->state->st.iteration;
+        float* noisy = planar(c->tmpA, v);
+        const int64_t HW = (int64_t)c->vol.H * c->vol.W;
+        switch (o.stage) {
+            case IRS_SG_PERTURB:
+                launch_perturb(v_src, io.sigma, io.eps, (float)sqrt(2.0 * (double)cfg.lr), cfg.sobolev_s > 0 ? noisy : vs, C, w, cfg.seed, 0, it, st);
+                break;
+            case IRS_SG_COPY_V: {
+                float* first = cfg.sobolev_s > 0 ? noisy : vs;
+                for (int ch = 0; ch < 3 * C; ++ch)
+                    HIP_TRY(hipMemcpyAsync(first + (int64_t)ch * c->vol.V + (int64_t)w.z0 * HW, v_src + (int64_t)ch * c->vol.V + (int64_t)w.z0 * HW,
+                                           (size_t)w.nz * HW * sizeof(float), hipMemcpyDeviceToDevice, st));
+                break;
+            }
+            case IRS_SG_SMOOTH:
+                if (cfg.sobolev_s > 0) launch_sobolev_march(noisy, vs, c->sob, C * 3, w, c->dmax, n, st);
+                else launch_field_absmax(vs, true, n, c->dmax, C, w, st);
+                break;
+            case IRS_SG_ENERGY:
+                launch_reg_energy(vs, c->energy_partials, C, w, st);
+                launch_reduce_partials(c->energy_partials, energy_blocks(w), C, c->energy_sum, st);
+                break;
+            case IRS_SG_EXP_FWD: {
+                const int k = o.k;
+                const float* in = k == 0 ? vs : step_buf(c, v, k - 1);
+                launch_exp_step_fwd_march(in, step_buf(c, v, k), k == 0, n, C, w, lin, c->dmax + (int64_t)k * c->C * 4,
+                                          c->dmax + (int64_t)(k + 1) * c->C * 4, predicted_small(c, k), fwd_lay(c, k), st);
+                break;
+            }
+            case IRS_SG_OUTPUTS:
+                launch_svf_outputs(step_buf(c, v, n - 1), io.transformation, io.displacement, C, w, lin, st);
+                break;
+            case IRS_SG_WARP:
+                launch_warp_fwd(io.moving_im, io.moving_chains == 1 ? 0 : c->vol.Vg, step_buf(c, v, n - 1), io.unif,
+                                jitter && cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f, warped, nullptr, 0, C, w, lin, cfg.seed, 0, it, st);
+                break;
+            case IRS_SG_RESIDUAL:
+                if (cfg.data_loss == IRS_DATA_GMM_LCC)
+                    launch_lcc_fwd_march(planar(c->fhat, v), c->fhat_chains == 1 ? 0 : c->vol.V, warped, z, planar(c->sigM, v), cfg.lcc_s, C, w, st);
+                else launch_residual_ssd(io.fixed_im, io.fixed_chains == 1 ? 0 : c->vol.V, warped, z, C, w, st);
+                break;
+            case IRS_SG_STATS: {
+                const uint8_t* mask = io.mask + (io.mask_chains == 1 ? 0 : (int64_t)o.k * c->vol.V);
+                launch_stats(stats_vd, z + (int64_t)o.k * c->vol.V, mask, c->state, c->stat_partials, w, st);
+                launch_reduce_cols(c->stat_partials, stats_blocks(w), kStatVals, c->stat_sum, st);
+                break;
+            }
+            case IRS_SG_CHAIN_SCALAR:
+                launch_chain_scalar(c->state, c->stat_sum, 1, o.k, stats_op, c->dcfg, st);
+                break;
+            case IRS_SG_DATA_BWD: {
+                const int ch = o.k;
+                const uint8_t* mask = io.mask + (io.mask_chains == 1 ? 0 : (int64_t)ch * c->vol.V);
+                const float* f = cfg.data_loss == IRS_DATA_GMM_LCC ? planar(c->fhat, v) + (c->fhat_chains == 1 ? 0 : (int64_t)ch * c->vol.V) : nullptr;
+                double* part = c->nll_partials + (int64_t)ch * c->nll_blocks;
+                launch_data_bwd(cfg.data_loss, f, 0, z + (int64_t)ch * c->vol.V, planar(c->sigM, v) + (int64_t)ch * c->vol.V, mask, 0, nullptr, c->state, ch,
+                                planar(c->gM, v) + (int64_t)ch * c->vol.V, part, cfg.lcc_s, 1, w, st);
+                launch_reduce_partials(part, data_bwd_blocks(cfg.data_loss, w), 1, c->nll_sum + ch, st);
+                break;
+            }
+            case IRS_SG_WARP_BWD:
+                launch_warp_bwd(io.moving_im, io.moving_chains == 1 ? 0 : c->vol.Vg, step_buf(c, v, n - 1), io.unif,
+                                cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f, planar(c->gM, v), planar(c->gA, v), C, w, lin, cfg.seed, 0, it, st);
+                break;
+            case IRS_SG_EXP_BWD: {
+                // The plan is validated against the measured bounds afterwards (finalize stage: floor(max|d_k|) + 1 <= planned
+                // width, else the transition is flagged invalid), so the variants that can only be selected above it need not be
+                // launched at all: a planned width of 1 leaves the radius-1 gather alone.
+                const int k = o.k, hplan = plan ? plan->h[k] : 0;
+                const int lay = bwd_lay(c, k);
+                float* gi = grad_raw(c, k, true);
+                float* go = grad_raw(c, k, false);
+                const float* G = (lay & 2) ? aos(gi, v) : planar(gi, v);
+                float* out = (lay & 4) ? aos(go, v) : planar(go, v);
+                const float* dk = k == 0 ? vs : step_buf(c, v, k - 1);
+                const unsigned* dm = c->dmax + (int64_t)k * c->C * 4;
+                const bool skip_any = (hplan >= 1 && hplan <= 2) || predicted_below(c, k, 1.5f);
+                launch_exp_step_bwd_march(G, dk, out, k == 0, n, c->C, w, lin, dm, hplan == 1 ? 1 : 2, skip_any, nullptr, lay, nullptr, st);
+                // the any-radius kernel bounds its sources by the global bound around the tile (no coarse grid: that one spans the volume)
+                if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, n, c->C, w, lin, dm, 2, 2, nullptr, lay, nullptr, st);
+                break;
+            }
+            case IRS_SG_REG_SCALAR:
+                launch_reg_scalar(c->state, c->energy_sum, 1, c->dcfg, st);
+                break;
+            case IRS_SG_UPDATE: {
+                float sc3[3];
+                prescale_factors(c->vol, n, sc3);
+                launch_sgld_update(io.v, io.sigma, planar(grad_raw(c, 0, false), v), vs, c->state, cfg.lr, sc3[0], sc3[1], sc3[2], io.grad_v, C, w, st);
+                break;
+            }
+            case IRS_SG_FINALIZE: {
+                Used used;
+                for (int k = 0; k < kMaxSteps; ++k) used.h[k] = plan && k < n ? plan->h[k] : 0;
+                hipLaunchKernelGGL(validate_widths_kernel, dim3(1), dim3(64), 0, st, c->dmax, used, n, c->C, c->hint + (kHintWords - 8));
+                launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, c->dmax, c->hint, 4 * c->C * (n + 1), 0u, 0, true, st);
+                c->dmax_clean = true;
+                break;
+            }
+            default:
+                return fail("slab: unknown stage %d", o.stage);
+        }
+        return 0;
+    }
+    int stats_vd = 0, stats_op = 3;
+};
+
+// validation of the planned ghost widths against the (all-reduced) bounds of this transition; sticky flag in pinned memory
 int ghost_width_from_bound(float m, bool safety) {
     if (!(m >= 0.0f) || m > 1.0e6f) return -1;
     return (int)floorf(safety ? 1.25f * m + 0.25f : m) + 1;
@@ -334,123 +625,40 @@ float hint_bound(const irs_ctx* c, int k) {
     return m;
 }
 
-struct FwdOpts {
-    bool noise, jitter, energy;
-    int chains;
-};
-
-// perturbation .. residual on the slab.  `plan` in: predicted widths (exact == false) / out: measured widths (exact == true)
-int slab_forward(irs_ctx* c, Pipe& p, const irs_io& io, const float* v_src, float* vs, float* warped, float* z, Plan& plan,
-                 bool exact, const FwdOpts& o, hipEvent_t* energy_done) {
-    const irs_config& cfg = c->cfg;
-    const SlabInfo& s = c->sl;
-    const Views v = views(c);
-    const int n = cfg.no_steps, C = o.chains, D = c->vol.D;
-    hipStream_t st = p.st;
-    const Lin lin = c->lin.lin();
-    const uint64_t* it = &c->state->st.iteration;
-    auto W = [&](int e) { return window(c->vol, s.a - (s.has_lo ? e : 0), s.b + (s.has_hi ? e : 0)); };
-    float* noisy = planar(c->tmpA, v);
-
-    if (!c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));
-    c->dmax_clean = false;
-    // the first forward round lives off ghost planes of v_s that the smoothing stage computes itself from a wider exchange
-    // of the perturbed velocity
-    const int e0 = exact ? 1 : (plan.fw[0] > 1 ? plan.fw[0] : 1);
-    float* first = cfg.sobolev_s > 0 ? noisy : vs;
-    if (o.noise) launch_perturb(v_src, io.sigma, io.eps, (float)sqrt(2.0 * (double)cfg.lr), first, C, W(0), cfg.seed, 0, it, st);
-    else {
-        for (int ch = 0; ch < 3 * C; ++ch)  // own planes of every channel
-            HIP_TRY(hipMemcpyAsync(first + (int64_t)ch * c->vol.V + (int64_t)s.a * c->vol.H * c->vol.W,
-                                   v_src + (int64_t)ch * c->vol.V + (int64_t)s.a * c->vol.H * c->vol.W,
-                                   (size_t)(s.b - s.a) * c->vol.H * c->vol.W * sizeof(float), hipMemcpyDeviceToDevice, st));
-    }
-    {
-        hipEvent_t recv;
-        if (start_exchange(p, first, F_PLANAR3, C, cfg.sobolev_s + e0, &recv) || wait_exchange(p, recv)) return 1;
-    }
-    if (cfg.sobolev_s > 0) launch_sobolev_march(noisy, vs, c->sob, C * 3, W(e0), c->dmax, n, st);
-    else launch_field_absmax(vs, true, n, c->dmax, C, W(e0), st);
-    if (o.energy) {
-        launch_reg_energy(vs, c->energy_partials, C, W(0), st);
-        launch_reduce_partials(c->energy_partials, energy_blocks(W(0)), C, c->energy_sum, st);
-        if (start_allreduce(p, c->energy_sum, C, 0, AR_ENERGY, energy_done)) return 1;
-    }
-    LAUNCH_CHECK();
-
-    auto fstep = [&](int k, Vol w) { fwd_step(c, v, vs, k, C, w, st); };
-    if (exact) {
-        // measure: the bound of d_k is all-reduced and read back before step k (one host synchronisation per step)
-        plan.n = n;
-        for (int k = 0; k < n; ++k) {
-            unsigned* dm = c->dmax + (int64_t)k * c->C * 4;
-            if (allreduce_now(p, dm, (size_t)c->C * 4, 1)) return 1;
-            unsigned host[4 * IRS_MAX_CHAINS];
-            HIP_TRY(hipMemcpyAsync(host, dm, sizeof(unsigned) * 4 * c->C, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            float m = 0.0f;
-            for (int i = 0; i < 4 * c->C; ++i) {
-                float f;
-                memcpy(&f, &host[i], sizeof(f));
-                if (!(f >= 0.0f)) return fail("slab: displacement bound of step %d is not finite", k);
-                m = f > m ? f : m;
-            }
-            const int h = ghost_width_from_bound(m, false);
-            if (h < 1) return fail("slab: displacement bound of step %d out of range", k);
-            if (k == 0 && h > 1) return fail("slab: |d_0| >= 1 voxel: velocity field too large for %d squaring steps", n);
-            plan.h[k] = h;
-            plan.m[k] = m;
-            plan.fr[k] = k;
-            plan.fw[k] = h;
-            if (k == 0) {  // reads v_s, whose ghost plane the smoothing stage made
-                fstep(0, W(0));
-                LAUNCH_CHECK();
-            } else {
-                const int ks[1] = {k}, hs[1] = {h};
-                if (run_round(p, step_buf(c, v, k - 1), step_is_aos(c, k - 1) ? F_AOS3 : F_PLANAR3, C, h, ks, hs, 1, fstep)) return 1;
-            }
+// the measuring forward pass: the bound of d_k is all-reduced and read back before step k (one host synchronisation per step)
+int forward_exact(Exec& ex, Sched& sch, Plan& plan) {
+    irs_ctx* c = ex.c;
+    const int n = c->cfg.no_steps;
+    plan.n = n;
+    for (int k = 0; k < n; ++k) {
+        size_t from = sch.ops.size();
+        sch.wait(sch.allreduce(IRS_AR_DMAX));  // (every bound published so far; only row k is read)
+        if (ex.run(sch.ops.data() + from, (int)(sch.ops.size() - from))) return 1;
+        unsigned host[4 * IRS_MAX_CHAINS];
+        HIP_TRY(hipMemcpyAsync(host, c->dmax + (int64_t)k * c->C * 4, sizeof(unsigned) * 4 * c->C, hipMemcpyDeviceToHost, ex.st));
+        HIP_TRY(hipStreamSynchronize(ex.st));
+        float m = 0.0f;
+        for (int i = 0; i < 4 * c->C; ++i) {
+            float f;
+            memcpy(&f, &host[i], sizeof(f));
+            if (!(f >= 0.0f)) return fail("slab: displacement bound of step %d is not finite", k);
+            m = f > m ? f : m;
         }
-        plan.nf = n;
-    } else {
-        for (int r = 0; r < plan.nf; ++r) {
-            int ks[kMaxSteps], hs[kMaxSteps], m = 0;
-            for (int k = 0; k < n; ++k)
-                if (plan.fr[k] == r) {
-                    ks[m] = k;
-                    hs[m++] = plan.h[k];
-                }
-            const int k0 = ks[0];
-            if (r == 0) {
-                // no exchange: v_s is valid on slab +- e0 >= fw[0]; single launches on the shrinking windows
-                int rr = 0;
-                for (int i = 0; i < m; ++i) {
-                    rr += hs[i];
-                    fstep(ks[i], W(plan.fw[0] - rr));
-                }
-                LAUNCH_CHECK();
-            } else if (run_round(p, step_buf(c, v, k0 - 1), step_is_aos(c, k0 - 1) ? F_AOS3 : F_PLANAR3, C, plan.fw[r], ks, hs, m, fstep))
-                return 1;
-        }
+        const int h = ghost_width_from_bound(m, false);
+        if (h < 1) return fail("slab: displacement bound of step %d out of range", k);
+        if (k == 0 && h > 1) return fail("slab: |d_0| >= 1 voxel: velocity field too large for %d squaring steps", n);
+        plan.h[k] = h;
+        plan.m[k] = m;
+        plan.fr[k] = k;
+        plan.fw[k] = h;
+        // the backward pass lives off E_k = h_k: one step per round as well
+        plan.br[k] = n - 1 - k;
+        plan.bw[n - 1 - k] = h;
+        from = sch.ops.size();
+        sch.forward_exact_step(k, h);
+        if (ex.run(sch.ops.data() + from, (int)(sch.ops.size() - from))) return 1;
     }
-
-    const float* d_last = step_buf(c, v, n - 1);
-    if (io.transformation || io.displacement) launch_svf_outputs(d_last, io.transformation, io.displacement, C, W(0), lin, st);
-    const float alpha = o.jitter && cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f;
-    launch_warp_fwd(io.moving_im, io.moving_chains == 1 ? 0 : c->vol.Vg, d_last, io.unif, alpha, warped, nullptr, 0, C, W(0), lin, cfg.seed,
-                    0, it, st);
-    if (cfg.data_loss == IRS_DATA_GMM_LCC) {
-        const int ls = cfg.lcc_s;
-        hipEvent_t recv;
-        if (start_exchange(p, warped, F_IMAGE, C, 4 * ls, &recv) || wait_exchange(p, recv)) return 1;
-        launch_lcc_fwd_march(planar(c->fhat, v), c->fhat_chains == 1 ? 0 : c->vol.V, warped, z, planar(c->sigM, v), ls, C, W(2 * ls), st);
-    } else {
-        const int e = cfg.virtual_decimation ? 1 : 0;  // the lag-1 products of the VD statistics read one plane up
-        hipEvent_t recv;
-        if (start_exchange(p, warped, F_IMAGE, C, e, &recv) || wait_exchange(p, recv)) return 1;
-        launch_residual_ssd(io.fixed_im, io.fixed_chains == 1 ? 0 : c->vol.V, warped, z, C, window(c->vol, s.a, s.b + (s.has_hi ? e : 0)), st);
-    }
-    (void)D;
-    LAUNCH_CHECK();
+    plan.nf = plan.nb = n;
     return 0;
 }
 
@@ -471,20 +679,6 @@ irs_io shifted_io(const irs_ctx* c, const irs_io* io) {
     o.transformation = planar(io->transformation, v);
     o.grad_v = planar(io->grad_v, v);
     return o;  // moving_im stays: it is the whole volume
-}
-
-int stats_for_chain(irs_ctx* c, Pipe& p, const irs_io& io, const float* z, int ch, int want_vd, int op) {
-    const SlabInfo& s = c->sl;
-    const Vol w0 = window(c->vol, s.a, s.b);
-    const uint8_t* mask = io.mask + (io.mask_chains == 1 ? 0 : (int64_t)ch * c->vol.V);
-    launch_stats(want_vd, z + (int64_t)ch * c->vol.V, mask, c->state, c->stat_partials, w0, p.st);
-    launch_reduce_cols(c->stat_partials, stats_blocks(w0), kStatVals, c->stat_sum, p.st);
-    hipEvent_t done;
-    if (start_allreduce(p, c->stat_sum, kStatVals, 0, AR_STATS, &done)) return 1;
-    if (done) HIP_TRY(hipStreamWaitEvent(p.st, done, 0));
-    launch_chain_scalar(c->state, c->stat_sum, 1, ch, op, c->dcfg, p.st);
-    LAUNCH_CHECK();
-    return 0;
 }
 
 }  // namespace
@@ -576,6 +770,21 @@ int irs_slab_status_get(irs_ctx* c, irs_slab_status* out, void* stream) {
     return 0;
 }
 
+// ghost widths of this transition: from bounds the host has already seen (safety factor), or unknown -> measure
+static bool plan_widths(irs_ctx* c, Plan& plan) {
+    const int n = c->cfg.no_steps;
+    plan.n = n;
+    if (!c->have_pred || env_int("IRS_SLAB_EXACT", 0) != 0) return false;
+    const bool fresh = c->n_enqueued >= 2;  // the hint holds the all-reduced bounds of a finished transition
+    for (int k = 0; k < n; ++k) {
+        const int hh = fresh ? ghost_width_from_bound(hint_bound(c, k), true) : c->pred[k];
+        if (hh < 1) return false;
+        plan.h[k] = hh;
+    }
+    plan.h[0] = 1;  // |d_0| = |v_s| / 2^n voxels (validated like the others)
+    return true;
+}
+
 int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
     if (check_io(c, io_in, "irs_slab_transition")) return 1;
     if (!c->sl.on) return fail("irs_slab_transition: not a slab context (irs_slab_create)");
@@ -591,97 +800,41 @@ int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
         const int depth = env_int("IRS_RUN_AHEAD", 2);
         if (depth > 0 && depth <= 3 && c->n_enqueued >= (uint64_t)depth) HIP_TRY(hipEventSynchronize(c->ra_ev[(c->n_enqueued - depth) % 4]));
     }
-    Pipe p{c, st, c->cs};
-    // ---- plan of the ghost widths
     Plan plan;
-    plan.n = n;
-    bool exact = !c->have_pred || env_int("IRS_SLAB_EXACT", 0) != 0;
-    if (!exact) {
-        const bool fresh = c->n_enqueued >= 2;  // the hint holds the all-reduced bounds of a finished transition
-        for (int k = 0; k < n && !exact; ++k) {
-            const int hh = fresh ? ghost_width_from_bound(hint_bound(c, k), true) : c->pred[k];
-            if (hh < 1) exact = true;
-            plan.h[k] = hh;
-        }
-        if (!exact) {
-            plan.h[0] = 1;  // |d_0| = |v_s| / 2^n voxels (validated like the others)
-            if (plan_rounds(plan, s.gmax, s.world > 1 ? s.min_slab : 1 << 30)) return 1;
-        }
-    }
-    float* vs = io.curr_state ? io.curr_state : planar(c->vs, v);
-    float* warped = io.im_moving_warped ? io.im_moving_warped : planar(c->warped, v);
-    float* z = io.residuals ? io.residuals : planar(c->z, v);
-    const Vol w0 = window(c->vol, s.a, s.b);
-    const Lin lin = c->lin.lin();
-    const uint64_t* it = &c->state->st.iteration;
+    const bool planned = plan_widths(c, plan);
+    if (planned && plan_rounds(plan, s.gmax, s.world > 1 ? s.min_slab : 1 << 30)) return 1;
 
-    hipEvent_t energy_done = nullptr;
-    const FwdOpts fo{true, cfg.uniform_alpha > 0.0f, true, C};
-    if (slab_forward(c, p, io, io.v, vs, warped, z, plan, exact, fo, &energy_done)) return 1;
-    if (exact) {
-        // the forward pass ran one step per round (E_k = h_k): so does the backward pass
-        for (int k = 0; k < n; ++k) {
-            plan.br[k] = n - 1 - k;
-            plan.bw[n - 1 - k] = plan.h[k];
-            c->pred[k] = ghost_width_from_bound(plan.m[k], true);
-        }
-        plan.nb = n;
+    Exec ex{c, st, c->cs, io, io.v, io.curr_state ? io.curr_state : planar(c->vs, v), io.im_moving_warped ? io.im_moving_warped : planar(c->warped, v),
+            io.residuals ? io.residuals : planar(c->z, v), planned ? &plan : nullptr, cfg.uniform_alpha > 0.0f, C};
+    memset(ex.pending, 0, sizeof(ex.pending));
+    ex.stats_vd = cfg.virtual_decimation;
+    ex.stats_op = 3;
+    Sched sch(s, cfg, C);
+    if (!c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));
+    c->dmax_clean = false;
+    int energy_ar = -1;
+    if (planned) {
+        // the first forward round lives off ghost planes of v_s that the smoothing stage computes itself
+        sch.head(true, true, plan.fw[0] > 1 ? plan.fw[0] : 1, &energy_ar);
+        sch.forward_planned(plan);
+    } else {
+        sch.head(true, true, 1, &energy_ar);
+        if (ex.run(sch.ops.data(), (int)sch.ops.size())) return 1;
+        if (forward_exact(ex, sch, plan)) return 1;
+        for (int k = 0; k < n; ++k) c->pred[k] = ghost_width_from_bound(plan.m[k], true);
         c->have_pred = true;
         c->slab_exact += 1;
+        ex.plan = &plan;
     }
+    const size_t done = planned ? 0 : sch.ops.size();
+    sch.middle(io.transformation || io.displacement);
+    // (SSD without virtual decimation has alpha = 1 and no mixture: the statistics stage and its all-reduce drop out; the
+    // measuring transition runs it once, for n_mask)
+    sch.backward_and_update(plan, cfg.data_loss == IRS_DATA_GMM_LCC || cfg.virtual_decimation || !planned, energy_ar);
+    if (sch.next_id > 128) return fail("irs_slab_transition: schedule with %d exchanges", sch.next_id);
+    if (ex.run(sch.ops.data() + done, (int)(sch.ops.size() - done))) return 1;
     c->last_nf = plan.nf;
     c->last_nb = plan.nb;
-    // bounds of every d_k, all-reduced: variant selection of the adjoint steps, the next plans, the validation of this one
-    hipEvent_t dmax_done = nullptr;
-    if (start_allreduce(p, c->dmax, (size_t)4 * C * (n + 1), 1, AR_DMAX, &dmax_done)) return 1;
-
-    // ---- per chain, serially (trainer.py:316-327): VD factor -> GMM step -> data term with the UPDATED mixture
-    // (SSD without virtual decimation has alpha = 1 and no mixture: the statistics stage and its all-reduce drop out)
-    const bool need_stats = cfg.data_loss == IRS_DATA_GMM_LCC || cfg.virtual_decimation || exact;  // (once, for n_mask)
-    for (int ch = 0; ch < C; ++ch) {
-        if (need_stats && stats_for_chain(c, p, io, z, ch, cfg.virtual_decimation, 3)) return 1;
-        const uint8_t* mask = io.mask + (io.mask_chains == 1 ? 0 : (int64_t)ch * c->vol.V);
-        const float* f = cfg.data_loss == IRS_DATA_GMM_LCC ? planar(c->fhat, v) + (c->fhat_chains == 1 ? 0 : (int64_t)ch * c->vol.V) : nullptr;
-        double* part = c->nll_partials + (int64_t)ch * c->nll_blocks;
-        launch_data_bwd(cfg.data_loss, f, 0, z + (int64_t)ch * c->vol.V, planar(c->sigM, v) + (int64_t)ch * c->vol.V, mask, 0, nullptr, c->state, ch,
-                        planar(c->gM, v) + (int64_t)ch * c->vol.V, part, cfg.lcc_s, 1, w0, st);
-        launch_reduce_partials(part, data_bwd_blocks(cfg.data_loss, w0), 1, c->nll_sum + ch, st);
-    }
-    hipEvent_t nll_done = nullptr;
-    if (start_allreduce(p, c->nll_sum, C, 0, AR_NLL, &nll_done)) return 1;
-    // ---- back through the warp and the squaring steps
-    const float* d_last = step_buf(c, v, n - 1);
-    launch_warp_bwd(io.moving_im, io.moving_chains == 1 ? 0 : c->vol.Vg, d_last, io.unif, cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f,
-                    planar(c->gM, v), planar(c->gA, v), C, w0, lin, cfg.seed, 0, it, st);
-    LAUNCH_CHECK();
-    if (dmax_done) HIP_TRY(hipStreamWaitEvent(st, dmax_done, 0));
-    auto bstep = [&](int k, Vol w) { bwd_step(c, v, vs, k, plan.h[k], w, st); };
-    for (int r = 0; r < plan.nb; ++r) {
-        int ks[kMaxSteps], hs[kMaxSteps], m = 0;
-        for (int k = n - 1; k >= 0; --k)
-            if (plan.br[k] == r) {
-                ks[m] = k;
-                hs[m++] = plan.h[k];
-            }
-        const int k1 = ks[0];
-        float* gi = grad_raw(c, k1, true);
-        const bool gaos = (bwd_lay(c, k1) & 2) != 0;
-        if (run_round(p, gaos ? aos(gi, v) : planar(gi, v), gaos ? F_AOS3 : F_PLANAR3, C, plan.bw[r], ks, hs, m, bstep)) return 1;
-    }
-    // ---- regulariser scalars (its all-reduce has been in flight since the smoothing stage), update, bookkeeping
-    if (energy_done) HIP_TRY(hipStreamWaitEvent(st, energy_done, 0));
-    launch_reg_scalar(c->state, c->energy_sum, 1, c->dcfg, st);
-    float sc3[3];
-    prescale_factors(c->vol, n, sc3);
-    float* g0 = grad_raw(c, 0, false);
-    launch_sgld_update(io.v, io.sigma, planar(g0, v), vs, c->state, cfg.lr, sc3[0], sc3[1], sc3[2], io.grad_v, C, w0, st);
-    if (nll_done) HIP_TRY(hipStreamWaitEvent(st, nll_done, 0));
-    Used used;
-    for (int k = 0; k < kMaxSteps; ++k) used.h[k] = k < n ? plan.h[k] : 0;
-    hipLaunchKernelGGL(validate_widths_kernel, dim3(1), dim3(64), 0, st, c->dmax, used, n, C, c->hint + (kHintWords - 8));
-    launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, c->dmax, c->hint, 4 * C * (n + 1), 0u, 0, true, st);
-    c->dmax_clean = true;
-    LAUNCH_CHECK();
     HIP_TRY(hipEventRecord(c->ra_ev[c->n_enqueued % 4], st));
     ++c->n_enqueued;
     return 0;
@@ -694,10 +847,14 @@ int irs_slab_gmm_init(irs_ctx* c, const irs_io* io_in, const float* v_sample, in
     hipStream_t st = (hipStream_t)stream;
     const Views v = views(c);
     const SlabInfo& s = c->sl;
-    const irs_io io = shifted_io(c, io_in);
-    Pipe p{c, st, c->cs};
-    // trainer.py:529-547: one velocity sample (no Langevin noise, no jitter), batch of one
-    float* vsrc = planar(c->gB, v);
+    const int n = c->cfg.no_steps;
+    irs_io io = shifted_io(c, io_in);
+    io.sigma = nullptr;
+    io.eps = nullptr;
+    io.unif = nullptr;
+    io.transformation = nullptr;
+    io.displacement = nullptr;
+    // trainer.py:529-547: one velocity sample (no Langevin noise, no jitter), batch of one; staged in gB (free until the backward pass)
     const int64_t HW = (int64_t)c->vol.H * c->vol.W;
     for (int ch = 0; ch < 3; ++ch) {
         float* dst = c->gB + (int64_t)ch * c->vol.V + (int64_t)(s.a - s.lo) * HW;
@@ -706,34 +863,61 @@ int irs_slab_gmm_init(irs_ctx* c, const irs_io* io_in, const float* v_sample, in
         else HIP_TRY(hipMemsetAsync(dst, 0, bytes, st));
     }
     Plan plan;
-    hipEvent_t unused = nullptr;
-    irs_io io1 = io;
-    io1.sigma = nullptr;
-    io1.eps = nullptr;
-    io1.unif = nullptr;
-    io1.transformation = nullptr;
-    io1.displacement = nullptr;
-    const FwdOpts fo{false, false, false, 1};
-    if (slab_forward(c, p, io1, vsrc, planar(c->vs, v), planar(c->warped, v), planar(c->z, v), plan, true, fo, &unused)) return 1;
+    Exec ex{c, st, c->cs, io, planar(c->gB, v), planar(c->vs, v), planar(c->warped, v), planar(c->z, v), nullptr, false, 1};
+    memset(ex.pending, 0, sizeof(ex.pending));
+    Sched sch(s, c->cfg, 1);
+    HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));
+    c->dmax_clean = false;
+    int unused = -1;
+    sch.head(false, false, 1, &unused);
+    if (ex.run(sch.ops.data(), (int)sch.ops.size())) return 1;
+    if (forward_exact(ex, sch, plan)) return 1;
+    size_t from = sch.ops.size();
+    sch.middle(false);
+    if (ex.run(sch.ops.data() + from, (int)(sch.ops.size() - from))) return 1;
+    // std of the masked residual -> initial mixture; VD factor; warm-up steps with that factor (each a blocking all-reduce:
+    // a one-off stage)
     const Vol w0 = window(c->vol, s.a, s.b);
-    const float* z = planar(c->z, v);
-    launch_masked_moments(z, io.mask, c->stat_partials, w0, st);
+    launch_masked_moments(ex.z, io.mask, c->stat_partials, w0, st);
     launch_reduce_cols(c->stat_partials, stats_blocks(w0), 3, c->stat_sum, st);
-    if (allreduce_now(p, c->stat_sum, 3, 0)) return 1;
+    from = sch.ops.size();
+    sch.wait(sch.allreduce(IRS_AR_MOMENTS));
+    if (ex.run(sch.ops.data() + from, (int)(sch.ops.size() - from))) return 1;
     launch_gmm_init_from_moments(c->state, c->stat_sum, 1, c->dcfg, st);
     LAUNCH_CHECK();
-    auto stats = [&](int want_vd, int op) {
-        launch_stats(want_vd, z, io.mask, c->state, c->stat_partials, w0, st);
-        launch_reduce_cols(c->stat_partials, stats_blocks(w0), kStatVals, c->stat_sum, st);
-        if (allreduce_now(p, c->stat_sum, kStatVals, 0)) return 1;
-        launch_chain_scalar(c->state, c->stat_sum, 1, 0, op, c->dcfg, st);
-        return 0;
-    };
-    if (stats(c->cfg.virtual_decimation, 1)) return 1;  // alpha, fixed below
-    for (int i = 0; i < warm_up; ++i)
-        if (stats(0, 2)) return 1;
-    LAUNCH_CHECK();
+    for (int i = 0; i <= warm_up; ++i) {
+        ex.stats_vd = i == 0 ? c->cfg.virtual_decimation : 0;
+        ex.stats_op = i == 0 ? 1 : 2;  // first: alpha (kept for the warm-up); then: one mixture step each
+        Sched one(s, c->cfg, 1);
+        one.launch(IRS_SG_STATS, 0, w0, IRS_SB_Z, -1, ex.stats_vd ? 1 : 0, -1);
+        one.wait(one.allreduce(IRS_AR_STATS));
+        one.launch(IRS_SG_CHAIN_SCALAR, 0, w0, -1, -1, 0, -1);
+        memset(ex.pending, 0, sizeof(ex.pending));
+        if (ex.run(one.ops.data(), (int)one.ops.size())) return 1;
+    }
     HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int irs_slab_trace(const irs_config* cfg, const irs_slab_config* scfg, int rank, int world, const int32_t* h, irs_slab_op* ops,
+                   int max_ops, int32_t* n_ops) {
+    if (!cfg || !h || !n_ops || (max_ops > 0 && !ops)) return fail("irs_slab_trace: bad arguments");
+    if (cfg->no_steps < 1 || cfg->no_steps > kMaxSteps) return fail("irs_slab_trace: no_steps out of range");
+    SlabInfo s;
+    if (plan_layout(cfg, scfg, rank, world, &s)) return 1;
+    Plan plan;
+    plan.n = cfg->no_steps;
+    for (int k = 0; k < plan.n; ++k) plan.h[k] = h[k];
+    if (plan_rounds(plan, s.gmax, world > 1 ? s.min_slab : 1 << 30)) return 1;
+    Sched sch(s, *cfg, cfg->no_chains);
+    int energy_ar = -1;
+    sch.head(true, true, plan.fw[0] > 1 ? plan.fw[0] : 1, &energy_ar);
+    sch.forward_planned(plan);
+    sch.middle(true);
+    sch.backward_and_update(plan, cfg->data_loss == IRS_DATA_GMM_LCC || cfg->virtual_decimation != 0, energy_ar);
+    *n_ops = (int32_t)sch.ops.size();
+    if ((int)sch.ops.size() > max_ops) return max_ops > 0 ? fail("irs_slab_trace: %zu operations, room for %d", sch.ops.size(), max_ops) : 0;
+    memcpy(ops, sch.ops.data(), sch.ops.size() * sizeof(irs_slab_op));
     return 0;
 }
 

@@ -147,6 +147,18 @@ def plan_rounds(h, ghost_max=4, min_slab=1 << 30):
     return {'fwd_round': list(fr[:n]), 'fwd_width': list(fw[:nf.value]), 'bwd_round': list(br[:n]), 'bwd_width': list(bw[:nb.value])}
 
 
+def trace(cfg: EngineConfig, rank, world, h, ghost_max=0, margin=0):
+    """the operation list of one planned transition of `rank` (pure host arithmetic: what irs_slab_transition executes):
+    list of dicts with the fields of irs_slab_op"""
+    lib = L.load()
+    c, sc = irs_config(cfg), L.IrsSlabConfig(ghost_max, margin)
+    hh, n = (C.c_int32 * len(h))(*h), C.c_int32()
+    L.check(lib.irs_slab_trace(C.byref(c), C.byref(sc), rank, world, hh, None, 0, C.byref(n)))
+    ops = (L.IrsSlabOp * n.value)()
+    L.check(lib.irs_slab_trace(C.byref(c), C.byref(sc), rank, world, hh, ops, n.value, C.byref(n)))
+    return [{f: getattr(o, f) for f, _ in o._fields_} for o in ops]
+
+
 class SlabEngine(TransitionEngine):
     """one rank's share of a chain: same surface as TransitionEngine, slab-local tensors (moving image whole)"""
 

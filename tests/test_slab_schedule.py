@@ -1,0 +1,206 @@
+"""The exchange schedule of the z-slab decomposition, replayed on the CPU (no GPU, no kernels).
+
+`irs_slab_trace` returns the operation list that `irs_slab_transition` executes (csrc/slab.hip builds both from the same host
+code): launches with their output windows and read reach, exchanges with their ghost widths, all-reduces, waits.  The
+replay keeps, per buffer, which planes currently hold which tensor; world_size-2 and -3 gloo ranks carry the exchanges as
+real point-to-point messages between neighbours (tokens instead of planes) and the all-reduces as real collectives, so a
+mismatch in order, width or peer hangs or fails here.  Checked:
+
+  * every launch finds the planes it reads (output window +- reach, clipped to the volume) valid and of the right tensor;
+  * an exchange sends strips that are final, both sides agree on the width, the ghost planes become valid at the WAIT only;
+  * nothing writes the strips in flight or touches the ghost planes in flight (the interior / boundary split);
+  * every plane of the slab is written by exactly the launches of a step (interior + boundary strips tile the window);
+  * held planes suffice (nothing is read or received outside [lo, hi)).
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ir_sgmcmc_amd import _lib as L
+from ir_sgmcmc_amd.engine import EngineConfig
+from ir_sgmcmc_amd.slab import plan_layout, plan_rounds, trace
+
+
+def test_round_plans():
+    n = 12
+    for h, gmax in (([1] * n, 4), ([1] * n, 1), ([1] * 8 + [1, 2, 2, 3], 4), ([1] * 6 + [1, 1, 2, 3, 5, 9], 4), ([1] * n, 6)):
+        p = plan_rounds(h, gmax, 64)
+        fr, fw, br, bw = p['fwd_round'], p['fwd_width'], p['bwd_round'], p['bwd_width']
+        assert fr[0] == 0 and all(0 <= b - a <= 1 for a, b in zip(fr, fr[1:]))             # rounds in step order
+        for r, w in enumerate(fw):
+            ks = [k for k in range(n) if fr[k] == r]
+            assert w == sum(h[k] for k in ks) and (w <= gmax or len(ks) == 1)              # width = sum of its steps' ghost widths
+        assert br[n - 1] == 0 and all(0 <= a - b <= 1 for a, b in zip(br, br[1:]))          # backward rounds run from the last step down
+        E = [sum(h[j] for j in range(k, max(j for j in range(n) if fr[j] == fr[k]) + 1)) for k in range(n)]
+        for r, w in enumerate(bw):
+            ks = [k for k in range(n) if br[k] == r]
+            assert w == sum(h[k] for k in ks) and len(ks) <= 2
+            for k in ks:  # the ghost planes of d_k the forward pass left behind cover what the adjoint round reads
+                assert sum(h[j] for j in range(min(ks), k + 1)) <= E[k]
+    with pytest.raises(L.IrsError):
+        plan_rounds([1] * 11 + [9], 4, 8)  # a ghost zone wider than the smallest slab
+
+
+def test_layout_partitions_the_volume():
+    cfg = EngineConfig(dims=(100, 32, 32))
+    for world in (1, 2, 3, 7, 8):
+        lay = [plan_layout(cfg, r, world) for r in range(world)]
+        assert lay[0]['a'] == 0 and lay[-1]['b'] == 100 and all(x['b'] == y['a'] for x, y in zip(lay, lay[1:]))
+        for x in lay:
+            assert x['lo'] == max(x['a'] - x['margin'], 0) * (x['rank'] > 0) and x['hi'] == (min(x['b'] + x['margin'], 100) if x['rank'] < world - 1 else 100)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Replay:
+    """one rank's view: which planes of which buffer hold which tensor"""
+
+    def __init__(self, cfg, rank, world, h, ghost_max):
+        self.lay = plan_layout(cfg, rank, world, ghost_max=ghost_max)
+        self.rank, self.world, self.D, self.n = rank, world, cfg.dims[0], cfg.no_steps
+        self.a, self.b, self.lo, self.hi = (self.lay[k] for k in ('a', 'b', 'lo', 'hi'))
+        self.h = h
+        self.ops = trace(cfg, rank, world, h, ghost_max=ghost_max)
+        self.valid = {L.IRS_SB_V: {z: ('input', 0) for z in range(self.a, self.b)}}   # buffer -> {plane: tensor it holds}
+        self.flight = {}                                                        # exchange id -> (buf, sent planes, ghost planes, reqs, bufs)
+        self.written = {}                                                       # (stage, k) -> planes written so far
+        self.n_exchanges = 0
+
+    def clip(self, lo, hi):
+        return set(range(max(lo, 0), min(hi, self.D)))
+
+    def expect_tag(self, o, which):
+        """the tensor a squaring-step launch must find in its input buffers"""
+        k, n = o['k'], self.n
+        if o['stage'] == L.IRS_SG_EXP_FWD:
+            return (L.IRS_SG_SMOOTH, 0) if k == 0 else (L.IRS_SG_EXP_FWD, k - 1)
+        if o['stage'] == L.IRS_SG_EXP_BWD:
+            if which == 0:
+                return (L.IRS_SG_WARP_BWD, 0) if k == n - 1 else (L.IRS_SG_EXP_BWD, k + 1)
+            return (L.IRS_SG_SMOOTH, 0) if k == 0 else (L.IRS_SG_EXP_FWD, k - 1)
+        return None
+
+    def launch(self, o):
+        wins = self.clip(o['lo0'], o['hi0']) | self.clip(o['lo1'], o['hi1'])
+        reads = set()
+        for lo, hi in ((o['lo0'], o['hi0']), (o['lo1'], o['hi1'])):
+            if hi > lo:
+                reads |= self.clip(lo - o['reach'], hi + o['reach'])
+        assert not reads or (min(reads) >= self.lo and max(reads) < self.hi), f'rank {self.rank}: {o} reads outside the held planes'
+        busy_ghost = set().union(*[f[2] for f in self.flight.values()]) if self.flight else set()
+        for which, buf in enumerate((o['in0'], o['in1'])):
+            if buf < 0:
+                continue
+            planes = self.valid.get(buf, {})
+            assert reads <= set(planes), f'rank {self.rank}: {o} reads planes {sorted(reads - set(planes))} of buffer {buf} that were never written'
+            want = self.expect_tag(o, which)
+            if want is not None:
+                wrong = {z: planes[z] for z in reads if planes[z] != want}
+                assert not wrong, f'rank {self.rank}: {o} expects tensor {want} in buffer {buf}, finds {wrong}'
+            for f in self.flight.values():
+                assert not (f[0] == buf and reads & f[2]), f'rank {self.rank}: {o} reads ghost planes of buffer {buf} that are still in flight'
+        if o['out'] >= 0 and o['stage'] < 32:
+            tag = (o['stage'], o['k']) if o['stage'] != L.IRS_SG_COPY_V else (L.IRS_SG_PERTURB, 0)
+            if o['stage'] == L.IRS_SG_PERTURB and o['out'] == L.IRS_SB_VS:
+                tag = (L.IRS_SG_SMOOTH, 0)  # no Sobolev smoothing: the perturbed field is v_s
+            for f in self.flight.values():
+                assert not (f[0] == o['out'] and wins & (f[1] | f[2])), f'rank {self.rank}: {o} overwrites strips of buffer {o["out"]} in flight'
+            self.valid.setdefault(o['out'], {}).update({z: tag for z in wins})
+            done = self.written.setdefault(tag, set())
+            assert not (done & wins), f'rank {self.rank}: {o} writes planes {sorted(done & wins)} twice'
+            done |= wins
+
+    def exchange(self, o):
+        buf, w = o['stage'], o['width']
+        planes = self.valid[buf]
+        sent, ghost, reqs, bufs, tag = set(), set(), [], [], None
+        for peer, s_lo, g_lo in ((self.rank + 1, self.b - w, self.b), (self.rank - 1, self.a, self.a - w)):
+            if not 0 <= peer < self.world:
+                continue
+            strip = set(range(s_lo, s_lo + w))
+            assert strip <= set(planes) and strip <= set(range(self.a, self.b)), f'rank {self.rank}: exchange {o} sends planes that are not final'
+            tags = {planes[z] for z in strip}
+            assert len(tags) == 1 and (tag is None or tags == {tag}), f'rank {self.rank}: exchange {o} sends a mix of tensors {tags}'
+            tag = tags.pop()
+            assert self.lo <= g_lo and g_lo + w <= self.hi, f'rank {self.rank}: exchange {o} receives outside the held planes'
+            sent |= strip
+            ghost |= set(range(g_lo, g_lo + w))
+            tok = torch.tensor([buf, w, tag[0], tag[1], o['id']], dtype=torch.int64)
+            got = torch.zeros(5, dtype=torch.int64)
+            reqs += [dist.isend(tok, peer), dist.irecv(got, peer)]
+            bufs.append(got)
+        self.flight[o['id']] = (buf, sent, ghost, reqs, bufs, tag, w)
+        self.n_exchanges += 1
+
+    def wait(self, o):
+        f = self.flight.pop(o['id'], None)
+        if f is None:
+            return  # an all-reduce: carried out when it was issued
+        buf, sent, ghost, reqs, bufs, tag, w = f
+        for r in reqs:
+            r.wait()
+        for got in bufs:  # the neighbour sent the same tensor, the same width, in the same exchange
+            assert got.tolist() == [buf, w, tag[0], tag[1], o['id']], (self.rank, got.tolist(), buf, w, tag)
+        self.valid[buf].update({z: tag for z in ghost})
+
+    def allreduce(self, o):
+        t = torch.tensor([o['stage'], -o['stage'], o['id'], -o['id']], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # every rank issues the same reduction at the same point
+        assert t.tolist() == [o['stage'], -o['stage'], o['id'], -o['id']]
+
+    def run(self):
+        for o in self.ops:
+            {L.IRS_OP_LAUNCH: self.launch, L.IRS_OP_EXCHANGE: self.exchange, L.IRS_OP_ALLREDUCE: self.allreduce, L.IRS_OP_WAIT: self.wait}[o['kind']](o)
+        assert not self.flight
+        own = set(range(self.a, self.b))
+        # every squaring step and its adjoint covered the slab; the update wrote v on the owned planes
+        for k in range(self.n):
+            assert own <= self.written[(L.IRS_SG_EXP_FWD, k)] and own <= self.written[(L.IRS_SG_EXP_BWD, k)]
+        assert self.written[(L.IRS_SG_UPDATE, 0)] == own
+        return self.n_exchanges
+
+
+def _worker(rank, world, port, q, N, h, ghost_max, loss):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        cfg = EngineConfig(dims=(N, 16, 16), data_loss=loss, virtual_decimation=(loss == 'GMM'))
+        n = Replay(cfg, rank, world, h, ghost_max).run()
+        if rank == 0:
+            q.put(n)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,N,h,ghost_max,loss', [
+    (2, 64, [1] * 12, 4, 'GMM'),                      # the common case: sub-voxel steps, rounds of four
+    (2, 64, [1] * 12, 1, 'SSD'),                      # one step per round
+    (2, 96, [1] * 8 + [1, 2, 2, 3], 4, 'GMM'),        # late steps with wider ghost zones
+    (3, 96, [1] * 12, 4, 'SSD'),                      # a middle rank with two neighbours
+    (3, 120, [1] * 6 + [1, 1, 2, 2, 4, 7], 4, 'GMM'),  # a single step wider than ghost_max is a round of its own
+])
+def test_schedule_replay_over_gloo(world, N, h, ghost_max, loss):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, N, h, ghost_max, loss)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    n_exchanges = q.get(timeout=10)
+    rounds = plan_rounds(h, ghost_max, N // world)
+    # perturbed velocity + (forward rounds - the first, which lives off the widened smoothing) + warped image + backward rounds
+    assert n_exchanges == 1 + (len(rounds['fwd_width']) - 1) + (1 if loss == 'GMM' else 0) + len(rounds['bwd_width'])
