@@ -482,6 +482,15 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #ifndef IRS_MARCH_WAVES
 #define IRS_MARCH_WAVES 4
 #endif
+// IRS_BWD_HZ=1: z weights of the gather formed once per source at commit time instead of by each of its nine in-plane
+// gatherers.  Correct (parity suite green) and 3 VALU instructions fewer per candidate, but
+// MEASURED SLOWER: 205.9 vs 200.2 us per launch at 256^3 (tools/build_variant.sh hz1 -DIRS_BWD_HZ=1; tools/sweep_lib.sh) --
+// the records grow from three ds_read_b64 (6 LDS cycles) to two ds_read_b128 (8) per candidate and from 28 to 36 cycles of
+// LDS store path per source, on a kernel whose LDS pipe is already ~50 % busy next to a 74 % busy VALU.
+// Kept as a build variant, off.
+#ifndef IRS_BWD_HZ
+#define IRS_BWD_HZ 0
+#endif
 
 // hat of (r + c) for a relative position r and a compile-time integer offset c.
 template <int R>
@@ -592,8 +601,15 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     //   q_xy = (rx, ry)   q_zg = (rz, G2)   q_g = (G0, G1)   q_d = (d0, d1)   q_dz = d2
     // where r = clipped sampling position - the source's own coordinate (|r| <= max|d|): every hat weight of the
     // gather is then a function of r plus a compile-time offset
-    __shared__ float2 q_xy[NP * PN], q_zg[NP * PN], q_g[NP * PN], q_d[NP * PN];
+    // HZ (radius 1): the three z weights of a source -- hat(rz + 1), hat(rz), hat(rz - 1), its contributions to the output
+    // planes s - 1, s, s + 1 -- are formed ONCE when the source is committed instead of by each of its nine in-plane gatherers:
+    //   qa = (rx, ry, hz-, hz0)   qb = (G0, G1, G2, hz+)   (two ds_read_b128 per candidate, packed operands on even registers;
+    //   rz = hz+ - hz- exactly)
+    // and only the source plane being gathered and the one before it (own term) are kept: two slots, 34 KB with the d ring.
+    constexpr bool HZ = (R == 1) && (IRS_BWD_HZ != 0);
+    __shared__ float2 q_xy[HZ ? 1 : NP * PN], q_zg[HZ ? 1 : NP * PN], q_g[HZ ? 1 : NP * PN], q_d[NP * PN];
     __shared__ float q_dz[NP * PN];
+    __shared__ float4 qa[HZ ? 2 * PN : 1], qb[HZ ? 2 * PN : 1];
     // XCD-aware tile assignment: consecutive tiles (x fastest, then y, then z-segment, then chain) stay on one L2
     const int tile_ = xcd_swizzle_runs(tile_id, (int)(tiles.x * tiles.y * tiles.z), swz_run);
     const int tbx = tile_ % tiles.x, tby = (tile_ / tiles.x) % tiles.y, tbz = tile_ / (tiles.x * tiles.y);
@@ -682,6 +698,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
             if (gs_) pgs[it] = ld_off(gs_ + zo, g);
         }
     };
+    const int sbase_ = z0 - R;  // first source plane of the segment (slot parity of the two-slot records)
     auto commit = [&](int s, int slot) {  // registers -> ring slot (with the clipped sampling position)
         const bool zin = s >= 0 && s < vol.D;
         const float lz_ = zin ? lin.z[s] : 0.0f, fs_ = (float)s;
@@ -689,10 +706,16 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
             const int i = slot * PN + threadIdx.x + it * kMarchBlock;
+            const int iab = HZ ? ((s - sbase_) & 1) * PN + threadIdx.x + it * kMarchBlock : 0;
             if (!zin) {  // plane outside the volume: no source there (G = 0 removes it from every gather)
-                q_xy[i] = make_float2(0.0f, 0.0f);
-                q_zg[i] = make_float2(0.0f, 0.0f);
-                q_g[i] = make_float2(0.0f, 0.0f);
+                if (HZ) {
+                    qa[iab] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    qb[iab] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                } else {
+                    q_xy[i] = make_float2(0.0f, 0.0f);
+                    q_zg[i] = make_float2(0.0f, 0.0f);
+                    q_g[i] = make_float2(0.0f, 0.0f);
+                }
                 q_d[i] = make_float2(0.0f, 0.0f);
                 q_dz[i] = 0.0f;
                 continue;
@@ -710,9 +733,15 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
             const float gm_ = gs_ ? pgs[it] : 1.0f;
             const float g0 = sin_[it] ? pre[it][3] * gm_ : 0.0f, g1 = sin_[it] ? pre[it][4] * gm_ : 0.0f,
                         g2 = sin_[it] ? pre[it][5] * gm_ : 0.0f;
-            q_xy[i] = make_float2(p0 - sfx[it], p1 - sfy[it]);
-            q_zg[i] = make_float2(p2 - fs_, g2);
-            q_g[i] = make_float2(g0, g1);
+            if (HZ) {
+                const float rz = p2 - fs_;
+                qa[iab] = make_float4(p0 - sfx[it], p1 - sfy[it], clamp01(-rz), hat01(rz));
+                qb[iab] = make_float4(g0, g1, g2, clamp01(rz));
+            } else {
+                q_xy[i] = make_float2(p0 - sfx[it], p1 - sfy[it]);
+                q_zg[i] = make_float2(p2 - fs_, g2);
+                q_g[i] = make_float2(g0, g1);
+            }
             q_d[i] = make_float2(d0, d1);
             q_dz[i] = d2;
         }
@@ -743,6 +772,20 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                 for (int dy = 0; dy <= 2 * R; ++dy)
 #pragma unroll
                     for (int dx = 0; dx <= 2 * R; ++dx) {
+                        if (HZ) {
+                            const int ri = ((s - sbase_) & 1) * PN + (ly + dy) * PX + (lx + dx);
+                            const float4 A = qa[ri], B = qb[ri];
+                            const float hxy = rel_hat<R>(A.x, dx - R) * rel_hat<R>(A.y, dy - R);
+                            const float wz[3] = {hxy * A.z, hxy * A.w, hxy * B.w};  // output planes s - 1, s, s + 1
+#pragma unroll
+                            for (int oo = -1; oo <= 1; ++oo) {
+                                const int a = (PH + oo + NP) % NP;
+                                acc01[a].x = fmaf(wz[oo + 1], B.x, acc01[a].x);
+                                acc01[a].y = fmaf(wz[oo + 1], B.y, acc01[a].y);
+                                acc2[a] = fmaf(wz[oo + 1], B.z, acc2[a]);
+                            }
+                            continue;
+                        }
                         const int ri = PH * PN + (ly + dy) * PX + (lx + dx);
                         const float2 rxy = q_xy[ri], rzg = q_zg[ri], g01 = q_g[ri];
                         // weight of source (x + dx - R, y + dy - R, s) on output (x, y, s + oo): hat(r + offset) per axis.
@@ -767,8 +810,24 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                 if (zo >= z0 && zo < z1 && col_in) {
                     const int ci = a * PN + (ly + R) * PX + (lx + R);  // plane zo sits in slot (zo - sbase) % NP == a
                     // the sample this voxel took in the forward step: its clipped position is already in the ring
-                    const float2 pc = q_xy[ci], zg = q_zg[ci], Gc01 = q_g[ci];
-                    const float G0 = Gc01.x, G1 = Gc01.y, G2 = zg.y;
+                    float2 pc, zg;
+                    float G0, G1, G2;
+                    if (HZ) {
+                        const int cj = ((zo - sbase_) & 1) * PN + (ly + R) * PX + (lx + R);
+                        const float4 A = qa[cj], B = qb[cj];
+                        pc = make_float2(A.x, A.y);
+                        zg = make_float2(B.w - A.z, 0.0f);  // rz = max(0, rz) - max(0, -rz), exactly
+                        G0 = B.x;
+                        G1 = B.y;
+                        G2 = B.z;
+                    } else {
+                        pc = q_xy[ci];
+                        zg = q_zg[ci];
+                        const float2 Gc01 = q_g[ci];
+                        G0 = Gc01.x;
+                        G1 = Gc01.y;
+                        G2 = zg.y;
+                    }
                     const float fx0 = floorf(pc.x), fy0 = floorf(pc.y), fz0 = floorf(zg.x);  // of the RELATIVE position
                     const float wx1 = __fsub_rn(pc.x, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), pc.x);
                     const float wy1 = __fsub_rn(pc.y, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.0f), pc.y);
