@@ -222,11 +222,24 @@ def main():
     f1, m1 = synthetic_pair(dims, seed=0)
     fixed = {k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'}
     moving = {k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'}
-    slab_status = None
+    slab_status, slab_failure = None, None
     if slab:
         from ir_sgmcmc_amd.slab import SlabComm, SlabEngine
-        comm = SlabComm.rccl() if backend == 'nccl' else SlabComm.rehearsal(dev)
-        comm.selftest()  # one all-reduce of each kind + a ring exchange, verified: a broken transport stops here
+        # The library's own RCCL communicator + a verified all-reduce of each kind and ring exchange.  A transport that cannot
+        # be brought up (on ANY rank: the verdict is all-reduced) does not take the run down with it: the bench then measures
+        # the chain decomposition and SAYS SO in its output (`slab_transport_failure`, "scaling": "weak").
+        comm = None
+        try:
+            comm = SlabComm.rccl() if backend == 'nccl' else SlabComm.rehearsal(dev)
+            comm.selftest()
+        except Exception as e:  # noqa: BLE001
+            slab_failure = f'{type(e).__name__}: {e}'
+            print(f'[bench] rank {rank}: slab transport failed: {slab_failure}', file=sys.stderr, flush=True)
+        ok = torch.tensor([0 if slab_failure else 1], device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            slab, slab_failure = False, slab_failure or 'transport failed on another rank'
+    if slab:
         cfg = engine_config(N, args.loss, 1234)  # one chain: every rank draws the Philox noise of ITS planes of the same field
         eng = SlabEngine(cfg, dev, comm, ghost_max=args.ghost_max)
         fixed, moving = eng.prepare(fixed, moving)   # fixed image / mask cut to the held planes; the moving image stays whole
@@ -347,6 +360,8 @@ def main():
                              'achieved_GBps': FWD_STEP_BYTES_PER_VOXEL * V / (fwd_kernel_ms * 1e-3) / 1e9},
             'stage_ms': tm, 'workspace_GB': eng.workspace_bytes / 1e9, **extras,
         }
+        if slab_failure:
+            out['slab_transport_failure'] = slab_failure
         if slab:
             st = slab_status
             out['slab'] = {'planes_owned': eng.b - eng.a, 'planes_held': eng.hi - eng.lo, 'ghost_max': eng.ghost_max,

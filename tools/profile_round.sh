@@ -8,11 +8,11 @@ OUT=$PWD/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 10 --warmup 2 > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k -- python3 "$REPO/bench.py" --no-cpu-baseline --no-extras --steps 10 --warmup 2 > "$OUT/trace.log" 2>&1
 echo "kernel trace done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o f -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o f -- python3 "$REPO/bench.py" --no-cpu-baseline --no-extras --steps 3 --warmup 1 > "$OUT/pmc_fetch.log" 2>&1
 echo "FETCH_SIZE pass done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o w -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o w -- python3 "$REPO/bench.py" --no-cpu-baseline --no-extras --steps 3 --warmup 1 > "$OUT/pmc_write.log" 2>&1
 echo "WRITE_SIZE pass done"
 cd "$REPO"
 python3 tools/pmc_aggregate.py "$OUT" "$TAG"
