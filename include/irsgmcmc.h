@@ -228,55 +228,6 @@ typedef struct irs_timings {
 int irs_transition_timed(irs_ctx* ctx, const irs_io* io, void* stream, irs_timings* out);
 
 /* ------------------------------------------------------------------------------------------------
- * staged transition for the z-slab decomposition (BASELINE.json config 4).
- * The same kernels as irs_transition, launched stage by stage on a window [zlo, zhi) of output planes; all arrays keep
- * their full size and global indexing, so a rank computes its slab and the caller (ir_sgmcmc_amd/slab.py) moves ghost
- * planes between neighbouring ranks and all-reduces the few partial sums between stages.  With the full window and no
- * exchange the stage sequence reproduces irs_transition.  SVF_3D only.
- * `k` is the squaring step (EXP_FWD / EXP_BWD) or the chain (STATS / CHAIN_SCALAR / DATA_BWD), otherwise ignored.
- * ---------------------------------------------------------------------------------------------- */
-enum {
-    IRS_ST_BEGIN = 0,     /* reset the displacement bounds */
-    IRS_ST_PERTURB,       /* v + sqrt(2 tau) sigma eps              -> noisy        needs: v on the window */
-    IRS_ST_SMOOTH,        /* Sobolev smoothing                      -> curr_state   needs: noisy on window +/- s */
-    IRS_ST_ENERGY,        /* regulariser energy partial sums        -> energy_sum   needs: curr_state on window + 1 */
-    IRS_ST_REG_SCALAR,    /* loss terms, coefficients, Adam step     (consumes the all-reduced energy_sum) */
-    IRS_ST_EXP_FWD,       /* squaring step k                        -> step k       needs: step k-1 on window +/- ceil(max|d|) */
-    IRS_ST_OUTPUTS,       /* transformation / displacement outputs */
-    IRS_ST_WARP,          /* warp of the moving image               -> warped */
-    IRS_ST_RESIDUAL,      /* LCC map / SSD residual                 -> residuals    needs: warped on window +/- 2 s */
-    IRS_ST_STATS,         /* chain k: VD / GMM statistics            -> stat_sum     needs: residuals on window + 1 */
-    IRS_ST_CHAIN_SCALAR,  /* chain k: alpha + GMM Adam step          (consumes the all-reduced stat_sum) */
-    IRS_ST_DATA_BWD,      /* chain k: data term + dL/d(warped)       -> nll_sum      needs: residuals, sigma on window +/- 2 s */
-    IRS_ST_WARP_BWD,      /* dL/d(d_last)                            -> grad A */
-    IRS_ST_EXP_BWD,       /* adjoint of squaring step k              needs: incoming gradient + step k-1 on window +/- halo */
-    IRS_ST_UPDATE,        /* gradient assembly + SGLD update         needs: curr_state on window +/- 1 */
-    IRS_ST_FINALIZE       /* data terms from the all-reduced nll_sum, iteration += 1 */
-};
-int irs_stage(irs_ctx* ctx, const irs_io* io, int stage, int k, int zlo, int zhi, void* stream);
-
-/* device buffers the slab orchestrator exchanges / reduces */
-enum {
-    IRS_BUF_NOISY = 0,    /* (C,3,D,H,W) float  perturbed velocity */
-    IRS_BUF_STEP,         /* index k: (C,3,D,H,W) float  d_{k+1}, normalised units */
-    IRS_BUF_GRAD_A,       /* (C,3,D,H,W) float */
-    IRS_BUF_GRAD_B,       /* (C,3,D,H,W) float */
-    IRS_BUF_SIGMA_M,      /* (C,1,D,H,W) float  local std of the warped image */
-    IRS_BUF_DMAX,         /* index k: (C,4) uint32 = float bits of max|d_k| in voxels per axis */
-    IRS_BUF_STAT_SUM,     /* 21 doubles */
-    IRS_BUF_ENERGY_SUM,   /* C doubles */
-    IRS_BUF_NLL_SUM       /* C doubles */
-};
-int irs_buffer(irs_ctx* ctx, int which, int index, void** ptr, size_t* bytes);
-/* which gradient buffer holds the INPUT / OUTPUT of adjoint step k (IRS_BUF_GRAD_A or IRS_BUF_GRAD_B) */
-int irs_grad_buffers(const irs_ctx* ctx, int k, int* in_buf, int* out_buf);
-/* memory layout of a staged field: 0 = planar (C,3,D,H,W) like the reference's tensors, 1 = interleaved (C,D,H,W,3) -- the
- * layout of the fields that only the squaring-step kernels touch (a run of z-planes of one chain is then ONE contiguous
- * block: what a ghost-plane exchange sends).  what = 0: IRS_BUF_STEP index k (output of squaring step k);
- * what = 1: the gradient buffer that is the INPUT of adjoint step k.  -1 on bad arguments. */
-int irs_layout(const irs_ctx* ctx, int what, int k);
-
-/* ------------------------------------------------------------------------------------------------
  * z-slab decomposition INSIDE the library (BASELINE.json config 4): one chain, the volume split
  * along z over the ranks of a node, one process per GPU.  What is sharded is the single-device loop body
  * trainer/trainer.py:291-356 (the reference has no multi-device code, base/base_trainer.py:16).

@@ -133,10 +133,6 @@ SIGNATURES = {
     'irs_gmm_init': [_P, C.POINTER(IrsIO), _P, _I, _P],
     'irs_transition': [_P, C.POINTER(IrsIO), _P],
     'irs_transition_timed': [_P, C.POINTER(IrsIO), _P, C.POINTER(IrsTimings)],
-    'irs_stage': [_P, C.POINTER(IrsIO), _I, _I, _I, _I, _P],
-    'irs_buffer': [_P, _I, _I, C.POINTER(_P), C.POINTER(C.c_size_t)],
-    'irs_grad_buffers': [_P, _I, C.POINTER(_I), C.POINTER(_I)],
-    'irs_layout': [_P, _I, _I],
     'irs_comm_unique_id': [C.POINTER(C.c_uint8 * IRS_COMM_ID_BYTES)],
     'irs_comm_create_rccl': [C.POINTER(C.c_uint8 * IRS_COMM_ID_BYTES), _I, _I, C.POINTER(_P)],
     'irs_comm_create_callbacks': [EXCHANGE_FN, ALLREDUCE_FN, _P, _I, _I, C.POINTER(_P)],

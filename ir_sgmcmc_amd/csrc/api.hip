@@ -811,160 +811,6 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
 }
 
 
-// ================================================================================================
-// staged transition (z-slab decomposition)
-// ================================================================================================
-
-int irs_grad_buffers(const irs_ctx* c, int k, int* in_buf, int* out_buf) {
-    if (!c || !in_buf || !out_buf || k < 0 || k >= c->cfg.no_steps) return fail("irs_grad_buffers: bad arguments");
-    // dL/d(d_last) lands in A; step no_steps-1 writes B, the next one A, ...
-    const bool odd = ((c->cfg.no_steps - k) & 1) != 0;
-    *in_buf = odd ? IRS_BUF_GRAD_A : IRS_BUF_GRAD_B;
-    *out_buf = odd ? IRS_BUF_GRAD_B : IRS_BUF_GRAD_A;
-    return 0;
-}
-
-int irs_layout(const irs_ctx* c, int what, int k) {
-    if (!c || k < 0 || k >= c->cfg.no_steps) return -1;
-    if (what == 0) return (fwd_lay(c, k) & 4) ? 1 : 0;
-    if (what == 1) return (bwd_lay(c, k) & 2) ? 1 : 0;
-    return -1;
-}
-
-int irs_buffer(irs_ctx* c, int which, int index, void** ptr, size_t* bytes) {
-    if (!c || !ptr || !bytes) return fail("irs_buffer: null argument");
-    const size_t fieldI = (size_t)c->C * 3 * c->vol.V * sizeof(float);
-    switch (which) {
-        case IRS_BUF_NOISY: *ptr = c->tmpA; *bytes = (size_t)c->C * 3 * c->volv.V * sizeof(float); return 0;
-        case IRS_BUF_STEP:
-            if (index < 0 || index >= c->cfg.no_steps) return fail("irs_buffer: step index out of range");
-            *ptr = c->steps + (size_t)index * (fieldI / sizeof(float)); *bytes = fieldI; return 0;
-        case IRS_BUF_GRAD_A: *ptr = c->gA; *bytes = fieldI; return 0;
-        case IRS_BUF_GRAD_B: *ptr = c->gB; *bytes = fieldI; return 0;
-        case IRS_BUF_SIGMA_M: *ptr = c->sigM; *bytes = (size_t)c->C * c->vol.V * sizeof(float); return 0;
-        case IRS_BUF_DMAX:
-            if (index < 0 || index > c->cfg.no_steps) return fail("irs_buffer: dmax index out of range");
-            *ptr = c->dmax + (size_t)index * c->C * 4; *bytes = sizeof(unsigned) * 4 * c->C; return 0;
-        case IRS_BUF_STAT_SUM: *ptr = c->stat_sum; *bytes = sizeof(double) * kStatVals; return 0;
-        case IRS_BUF_ENERGY_SUM: *ptr = c->energy_sum; *bytes = sizeof(double) * c->C; return 0;
-        case IRS_BUF_NLL_SUM: *ptr = c->nll_sum; *bytes = sizeof(double) * c->C; return 0;
-        default: return fail("irs_buffer: unknown buffer %d", which);
-    }
-}
-
-int irs_stage(irs_ctx* c, const irs_io* io, int stage, int k, int zlo, int zhi, void* stream) {
-    if (check_io(c, io, "irs_stage")) return 1;
-    if (c->ffd) return fail("irs_stage: the slab path supports SVF_3D only");
-    if (!use_lds_exp()) return fail("irs_stage: needs the LDS squaring kernels (IRS_EXP_LDS=1)");
-    const irs_config& cfg = c->cfg;
-    hipStream_t st = (hipStream_t)stream;
-    const int C = c->C;
-    const Vol w = window(c->vol, zlo, zhi);
-    if (w.nz <= 0 && stage != IRS_ST_BEGIN && stage != IRS_ST_REG_SCALAR && stage != IRS_ST_CHAIN_SCALAR && stage != IRS_ST_FINALIZE)
-        return 0;  // empty window: nothing to launch
-    const Lin lin = c->lin.lin();
-    const uint64_t* it = &c->state->st.iteration;
-    const int64_t field = (int64_t)C * 3 * c->vol.V;
-    float* vs = io->curr_state ? io->curr_state : c->vs;
-    float* warped = io->im_moving_warped ? io->im_moving_warped : c->warped;
-    float* z = io->residuals ? io->residuals : c->z;
-    const float* d_last = c->steps + (int64_t)(cfg.no_steps - 1) * field;
-    const bool chain_stage = stage == IRS_ST_STATS || stage == IRS_ST_CHAIN_SCALAR || stage == IRS_ST_DATA_BWD;
-    if (chain_stage && (k < 0 || k >= C)) return fail("irs_stage: chain out of range");
-    if ((stage == IRS_ST_EXP_FWD || stage == IRS_ST_EXP_BWD) && (k < 0 || k >= cfg.no_steps)) return fail("irs_stage: step out of range");
-    switch (stage) {
-        case IRS_ST_BEGIN:
-            HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * C * (cfg.no_steps + 1), st));
-            c->dmax_clean = false;
-            break;
-        case IRS_ST_PERTURB:
-            if (!io->v) return fail("irs_stage: v is required");
-            launch_perturb(io->v, io->sigma, io->eps, (float)sqrt(2.0 * (double)cfg.lr), cfg.sobolev_s > 0 ? c->tmpA : vs, C, w,
-                           cfg.seed, 0, it, st);
-            break;
-        case IRS_ST_SMOOTH:
-            if (cfg.sobolev_s > 0) launch_sobolev_march(c->tmpA, vs, c->sob, C * 3, w, c->dmax, cfg.no_steps, st);
-            else launch_field_absmax(vs, true, cfg.no_steps, c->dmax, C, w, st);
-            break;
-        case IRS_ST_ENERGY:
-            launch_reg_energy(vs, c->energy_partials, C, w, st);
-            launch_reduce_partials(c->energy_partials, energy_blocks(w), C, c->energy_sum, st);
-            break;
-        case IRS_ST_REG_SCALAR:
-            launch_reg_scalar(c->state, c->energy_sum, 1, c->dcfg, st);
-            break;
-        case IRS_ST_EXP_FWD: {
-            const float* in = k == 0 ? vs : c->steps + (int64_t)(k - 1) * field;
-            launch_exp_step_fwd_march(in, c->steps + (int64_t)k * field, k == 0, cfg.no_steps, C, w, lin, c->dmax + (int64_t)k * C * 4,
-                                      c->dmax + (int64_t)(k + 1) * C * 4, false, fwd_lay(c, k), st);
-            break;
-        }
-        case IRS_ST_OUTPUTS:
-            if (io->transformation || io->displacement) launch_svf_outputs(d_last, io->transformation, io->displacement, C, w, lin, st);
-            break;
-        case IRS_ST_WARP:
-            launch_warp_fwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif,
-                            cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f, warped, nullptr, 0, C, w, lin, cfg.seed, 0, it, st);
-            break;
-        case IRS_ST_RESIDUAL:
-            if (cfg.data_loss == IRS_DATA_GMM_LCC)
-                launch_lcc_fwd_march(c->fhat, c->fhat_chains == 1 ? 0 : c->vol.V, warped, z, c->sigM, cfg.lcc_s, C, w, st);
-            else
-                launch_residual_ssd(io->fixed_im, io->fixed_chains == 1 ? 0 : c->vol.V, warped, z, C, w, st);
-            break;
-        case IRS_ST_STATS: {
-            const uint8_t* mask = io->mask + (io->mask_chains == 1 ? 0 : (int64_t)k * c->vol.V);
-            launch_stats(cfg.virtual_decimation, z + (int64_t)k * c->vol.V, mask, c->state, c->stat_partials, w, st);
-            launch_reduce_cols(c->stat_partials, stats_blocks(w), kStatVals, c->stat_sum, st);
-            break;
-        }
-        case IRS_ST_CHAIN_SCALAR:
-            launch_chain_scalar(c->state, c->stat_sum, 1, k, 3, c->dcfg, st);
-            break;
-        case IRS_ST_DATA_BWD: {
-            const uint8_t* mask = io->mask + (io->mask_chains == 1 ? 0 : (int64_t)k * c->vol.V);
-            const float* f = cfg.data_loss == IRS_DATA_GMM_LCC ? c->fhat + (c->fhat_chains == 1 ? 0 : (int64_t)k * c->vol.V) : nullptr;
-            double* part = c->nll_partials + (int64_t)k * c->nll_blocks;
-            launch_data_bwd(cfg.data_loss, f, 0, z + (int64_t)k * c->vol.V, c->sigM + (int64_t)k * c->vol.V, mask, 0, nullptr,
-                            c->state, k, c->gM + (int64_t)k * c->vol.V, part, cfg.lcc_s, 1, w, st);
-            launch_reduce_partials(part, data_bwd_blocks(cfg.data_loss, w), 1, c->nll_sum + k, st);
-            break;
-        }
-        case IRS_ST_WARP_BWD:
-            launch_warp_bwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif,
-                            cfg.uniform_alpha > 0.0f ? cfg.uniform_alpha : 0.0f, c->gM, c->gA, C, w, lin, cfg.seed, 0, it, st);
-            break;
-        case IRS_ST_EXP_BWD: {
-            int ib, ob;
-            if (irs_grad_buffers(c, k, &ib, &ob)) return 1;
-            const float* G = ib == IRS_BUF_GRAD_A ? c->gA : c->gB;
-            float* out = ob == IRS_BUF_GRAD_A ? c->gA : c->gB;
-            const float* dk = k == 0 ? vs : c->steps + (int64_t)(k - 1) * field;
-            const unsigned* dm = c->dmax + (int64_t)k * C * 4;
-            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, false, nullptr, bwd_lay(c, k), nullptr, st);
-            launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, w, lin, dm, 2, 2, nullptr, bwd_lay(c, k), c->cmm, st);
-            break;
-        }
-        case IRS_ST_UPDATE: {
-            if (!io->v) return fail("irs_stage: v is required");
-            int ib, ob;
-            if (irs_grad_buffers(c, 0, &ib, &ob)) return 1;
-            float s3[3];
-            prescale_factors(c->vol, cfg.no_steps, s3);
-            launch_sgld_update(io->v, io->sigma, ob == IRS_BUF_GRAD_A ? c->gA : c->gB, vs, c->state, cfg.lr, s3[0], s3[1], s3[2],
-                               io->grad_v, C, w, st);
-            break;
-        }
-        case IRS_ST_FINALIZE:
-            launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, nullptr, nullptr, 0, 0u, 0, false, st);
-            break;
-        default:
-            return fail("irs_stage: unknown stage %d", stage);
-    }
-    LAUNCH_CHECK();
-    return 0;
-}
-
 int irs_transition(irs_ctx* c, const irs_io* io, void* stream) { return transition_impl(c, io, (hipStream_t)stream, 0); }
 
 int irs_transition_timed(irs_ctx* c, const irs_io* io, void* stream, irs_timings* out) {
