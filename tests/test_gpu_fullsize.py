@@ -204,3 +204,51 @@ def test_ssd_transition_reproducible_and_gradient_is_the_adjoint():
     lm, _ = data_term(v - eps * u)
     lhs = (lp - lm) / (2 * eps)
     assert abs(lhs - rhs) < 1e-2 * max(abs(lhs), abs(rhs)), (lhs, rhs)
+
+
+def test_config5_192_cubed_psgld_two_chains():
+    """BASELINE.json config 5 at its own size: 192^3, configs/experiment1 semantics -- GMM / LCC s = 1 with virtual decimation,
+    learnable RegLoss_LogNormal, Sobolev s = 3, jitter 0.1, TWO chains, and the pre-conditioned ("pSGLD") update with a sigma
+    FIELD as the VI stage leaves it (sigma = exp(log_var / 2), here 0.5 with a smooth modulation).  Size-independent properties:
+    bit-identical repeat runs; the two chains, started apart, share the mixture (updated serially, trainer.py:316-327) but
+    stay distinct; with sigma = s everywhere, one transition from the same state moves v by s^2 times the sigma = 1 step's
+    gradient part (SGLD.backward: grad * sigma^2, utils/functions.py:83-84)."""
+    M = 192
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    f, m = synthetic_pair((M, M, M), seed=0)
+    to = lambda d: {k: v.unsqueeze(0).to(DEV).contiguous() for k, v in d.items() if k != 'seg'}
+    fixed, moving = to(f), to(m)
+    cfg = lambda: EngineConfig(dims=(M, M, M), no_chains=2, reg_loss='RegLoss_LogNormal', reg_learnable=True, seed=9)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    v0 = G.perturb_smooth(torch.randn(2, 3, M, M, M, generator=g, device=DEV), G.sobolev_kernel_1d(3, 0.5))
+    t = torch.linspace(0.0, math.pi, M, device=DEV)
+    sigma = (0.5 * (1.0 + 0.2 * torch.sin(t).view(M, 1, 1) * torch.sin(t).view(1, M, 1))).expand(2, 3, M, M, M).contiguous()
+    res = []
+    for _ in range(2):
+        eng = TransitionEngine(cfg(), DEV)
+        fd, md = eng.prepare(fixed, moving)
+        eng.gmm_init(fd, md)
+        v = v0.clone()
+        for _ in range(3):
+            eng.transition(fd, md, v, sigma)
+        sc, st = eng.scalars(), eng.state()
+        assert st.iteration == 3 and st.gmm_adam_step[0] == 25 + 3 * 2  # one mixture step per chain and transition
+        assert bool(torch.isfinite(v).all()) and all(0.0 < a <= 1.0 for a in sc['alpha'])
+        res.append((v.clone(), sc['data_term'], list(st.gmm_log_std)))
+        del eng
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert float((res[0][0][0] - res[0][0][1]).abs().max()) > 1e-3  # two chains, two states
+    # the pre-conditioner: no noise (eps = 0 injected), no jitter; v_new - v = -lr sigma^2 grad
+    zero = torch.zeros(2, 3, M, M, M, device=DEV)
+    steps = {}
+    for s in (1.0, 0.5):
+        eng = TransitionEngine(EngineConfig(dims=(M, M, M), no_chains=2, reg_loss='RegLoss_LogNormal', reg_learnable=True,
+                                            uniform_noise=0.0, seed=9), DEV)
+        fd, md = eng.prepare(fixed, moving)
+        eng.gmm_init(fd, md)
+        v = v0.clone()
+        eng.transition(fd, md, v, torch.full_like(v0, s), zero)
+        steps[s] = v - v0
+        del eng
+    ref = steps[1.0]
+    assert float((steps[0.5] - 0.25 * ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-9
