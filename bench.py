@@ -118,9 +118,9 @@ def initial_velocity(kind, amp, N, dev):
     return torch.zeros(1, 3, *dims, device=dev)  # MCMC_init: identity (trainer.py:596-598)
 
 
-def engine_config(N, loss, seed):
+def engine_config(N, loss, seed, chains=1):
     from ir_sgmcmc_amd.engine import EngineConfig
-    return EngineConfig(dims=(N, N, N), no_chains=1, data_loss='GMM' if loss == 'gmm' else 'SSD', virtual_decimation=(loss == 'gmm'),
+    return EngineConfig(dims=(N, N, N), no_chains=chains, data_loss='GMM' if loss == 'gmm' else 'SSD', virtual_decimation=(loss == 'gmm'),
                         reg_loss='RegLoss_L2', w_reg=1.4, seed=seed)
 
 
@@ -129,17 +129,17 @@ def workload_name(N, loss):
             + ', RegLoss_L2 w=1.4, Sobolev s=3, uniform noise 0.1, SGLD lr 0.4, Philox noise')
 
 
-def side_run(N, loss, init, amp, steps, warmup, dev, timed_reps=0):
+def side_run(N, loss, init, amp, steps, warmup, dev, timed_reps=0, chains=1):
     """one fused single-GPU workload outside the headline: ms per transition (+ the per-stage events when asked)"""
     import torch
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from ir_sgmcmc_amd.engine import TransitionEngine
-    eng = TransitionEngine(engine_config(N, loss, 1234), dev)
+    eng = TransitionEngine(engine_config(N, loss, 1234, chains), dev)
     f1, m1 = synthetic_pair((N, N, N), seed=0)
     fixed, moving = eng.prepare({k: v.unsqueeze(0).to(dev) for k, v in f1.items() if k != 'seg'},
                                 {k: v.unsqueeze(0).to(dev) for k, v in m1.items() if k != 'seg'})
     eng.gmm_init(fixed, moving)
-    v = initial_velocity(init, amp, N, dev)
+    v = initial_velocity(init, amp, N, dev).expand(chains, 3, N, N, N).contiguous()
     for _ in range(warmup):
         eng.transition(fixed, moving, v)
     torch.cuda.synchronize(dev)
@@ -147,9 +147,9 @@ def side_run(N, loss, init, amp, steps, warmup, dev, timed_reps=0):
     for _ in range(steps):
         eng.transition(fixed, moving, v)
     torch.cuda.synchronize(dev)
-    ms = 1e3 * (time.perf_counter() - t0) / steps
+    ms = 1e3 * (time.perf_counter() - t0) / steps / chains  # per chain: every chain of the batch makes one transition per call
     assert bool(torch.isfinite(v).all()), 'chain diverged'
-    out = {'ms_per_transition': ms, 'transitions_per_s': 1e3 / ms, 'steps': steps, 'warmup': warmup,
+    out = {'ms_per_transition': ms, 'transitions_per_s': 1e3 / ms, 'steps': steps, 'warmup': warmup, 'chains_in_engine': chains,
            'achieved_GBps': BYTES_PER_VOXEL[loss] * N ** 3 / (ms * 1e-3) / 1e9,
            'frac_of_8TBps': BYTES_PER_VOXEL[loss] * N ** 3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if timed_reps:
@@ -380,6 +380,9 @@ def main():
                                           note='last squaring steps leave the radius-1 kernels (DESIGN.md section 4)')
             if N != 128:
                 also['size_128'] = dict(side_run(128, args.loss, 'identity', 0.0, 50, 10, dev, timed_reps=5), workload=workload_name(128, args.loss))
+            if N != 128:  # the reference runs C = 2 chains of a pair (configs/*/config.json): batched in one engine they fill the GPU at 128^3
+                also['size_128_two_chains'] = dict(side_run(128, args.loss, 'identity', 0.0, 50, 10, dev, chains=2), workload=workload_name(128, args.loss),
+                                                   note='C = 2 chains in one engine, as every reference config; ms per chain-transition')
             also['sustained'] = dict(side_run(N, args.loss, 'identity', 0.0, 500, 5, dev), note='500 consecutive transitions from the identity')
             out['also'] = also
         if not args.no_cpu_baseline and world == 1:

@@ -249,7 +249,11 @@ int irs_transition_timed(irs_ctx* ctx, const irs_io* io, void* stream, irs_timin
  *     while the exchange is in flight) and its two boundary strips (launched when the ghost planes have arrived);
  *   - the adjoint is an owner-computes gather, so the backward pass also only RECEIVES ghost planes (of the incoming
  *     gradient): no reverse halo accumulation.
- * With one rank the schedule degenerates to the single-GPU launch sequence.  SVF_3D only.
+ * With one rank the schedule degenerates to the single-GPU launch sequence.
+ * SVFFD_3D: the control grid is small, so v / sigma / eps / curr_state / grad_v stay WHOLE (control-grid sized, replicated on
+ * every rank: same Philox noise, same smoothing, same update); the dense velocity is up-sampled on the planes a rank needs,
+ * and the adjoint of the up-sampling sums over a rank's own planes, one more all-reduce (floats) making the control-grid
+ * gradient whole.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct irs_comm irs_comm;
 #define IRS_COMM_ID_BYTES 128
@@ -266,7 +270,7 @@ typedef struct irs_xfer {
     int32_t recv;   /* 0 = send, 1 = receive */
 } irs_xfer;
 typedef int (*irs_exchange_fn)(void* user, const irs_xfer* xfers, int n, void* stream);
-typedef int (*irs_allreduce_fn)(void* user, void* buf, size_t count, int max_u32, void* stream); /* SUM f64 | MAX u32 */
+typedef int (*irs_allreduce_fn)(void* user, void* buf, size_t count, int kind, void* stream); /* 0 SUM f64 | 1 MAX u32 | 2 SUM f32 */
 int irs_comm_create_callbacks(irs_exchange_fn ex, irs_allreduce_fn ar, void* user, int rank, int world, irs_comm** out);
 void irs_comm_destroy(irs_comm* comm);
 int irs_comm_rank(const irs_comm* comm);
@@ -317,15 +321,16 @@ int irs_slab_plan_rounds(const int32_t* h, int n, int ghost_max, int min_slab, i
 enum { IRS_OP_LAUNCH = 0, IRS_OP_EXCHANGE = 1, IRS_OP_ALLREDUCE = 2, IRS_OP_WAIT = 3 };
 enum {  /* launch stages */
     IRS_SG_PERTURB = 0, IRS_SG_COPY_V, IRS_SG_SMOOTH, IRS_SG_ENERGY, IRS_SG_EXP_FWD, IRS_SG_OUTPUTS, IRS_SG_WARP, IRS_SG_RESIDUAL,
-    IRS_SG_STATS, IRS_SG_DATA_BWD, IRS_SG_WARP_BWD, IRS_SG_EXP_BWD, IRS_SG_UPDATE,
+    IRS_SG_STATS, IRS_SG_DATA_BWD, IRS_SG_WARP_BWD, IRS_SG_EXP_BWD, IRS_SG_UPDATE, IRS_SG_FFD_UP, IRS_SG_FFD_ADJ,
     IRS_SG_SCALARS = 32,  /* single-workgroup stages from here on (no output window) */
     IRS_SG_CHAIN_SCALAR = 32, IRS_SG_REG_SCALAR, IRS_SG_FINALIZE
 };
 enum {  /* buffers */
     IRS_SB_V = 0, IRS_SB_NOISY, IRS_SB_VS, IRS_SB_WARPED, IRS_SB_Z, IRS_SB_GM, IRS_SB_GRAD_A, IRS_SB_GRAD_B,
+    IRS_SB_DENSE,      /* SVFFD: the dense velocity (V, NOISY, VS then live on the control grid, replicated on every rank) */
     IRS_SB_STEP0 = 16  /* + k: output of squaring step k */
 };
-enum { IRS_AR_ENERGY = 0, IRS_AR_DMAX = 1, IRS_AR_NLL = 2, IRS_AR_STATS = 3, IRS_AR_MOMENTS = 7 };
+enum { IRS_AR_ENERGY = 0, IRS_AR_DMAX = 1, IRS_AR_NLL = 2, IRS_AR_STATS = 3, IRS_AR_CPGRAD = 4, IRS_AR_MOMENTS = 7 };
 typedef struct irs_slab_op {
     int32_t kind;              /* IRS_OP_* */
     int32_t stage;             /* launch: IRS_SG_*; exchange: the buffer (IRS_SB_*); all-reduce: IRS_AR_* */

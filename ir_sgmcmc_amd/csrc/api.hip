@@ -199,28 +199,38 @@ int irs_svf_exp_bwd(const float* v, const float* steps, const float* g_last, flo
     return 0;
 }
 
-static int ffd_up(const float* v_cp, float* dense, float* tmp, int C, Vol vol, const int G[3], const SplineTaps spl[3],
-                  hipStream_t st) {
+}  // extern "C"
+
+// `dense` / `g_dense` hold the planes [store_lo, store_lo + store_n) of the volume (whole volume: 0, D); up-sampling produces the
+// planes [w_lo, w_lo + w_n), the adjoint sums over them (a rank's own planes: partial control-grid gradients, all-reduced)
+int irs::ffd_up(const float* v_cp, float* dense, float* tmp, int C, Vol vol, const int G[3], const SplineTaps spl[3], hipStream_t st,
+                int w_lo, int w_n, int store_lo, int store_n) {
     // axis order of utils/transformation.py:146-149: tensor axis 2 (D, cps[0]), 3 (H, cps[1]), 4 (W, cps[2])
+    if (w_n < 0) { w_lo = 0; w_n = vol.D; }
+    if (store_n < 0) { store_lo = 0; store_n = vol.D; }
     const int64_t CC = (int64_t)C * 3;
     float* t1 = tmp;
-    float* t2 = tmp + CC * vol.D * G[1] * G[2];
-    launch_ffd_axis(v_cp, t1, spl[0], false, CC, G[0], vol.D, (int64_t)G[1] * G[2], st);
-    launch_ffd_axis(t1, t2, spl[1], false, CC * vol.D, G[1], vol.H, G[2], st);
-    launch_ffd_axis(t2, dense, spl[2], false, CC * vol.D * vol.H, G[2], vol.W, 1, st);
+    float* t2 = tmp + CC * store_n * G[1] * G[2];
+    launch_ffd_axis(v_cp, t1, spl[0], false, CC, G[0], vol.D, (int64_t)G[1] * G[2], st, w_lo, w_n, store_lo, store_n);
+    launch_ffd_axis(t1, t2, spl[1], false, CC * store_n, G[1], vol.H, G[2], st);
+    launch_ffd_axis(t2, dense, spl[2], false, CC * store_n * vol.H, G[2], vol.W, 1, st);
     return 0;
 }
 
-static int ffd_adjoint(const float* g_dense, float* g_cp, float* tmp, int C, Vol vol, const int G[3],
-                       const SplineTaps spl[3], hipStream_t st) {
+int irs::ffd_adjoint(const float* g_dense, float* g_cp, float* tmp, int C, Vol vol, const int G[3], const SplineTaps spl[3],
+                     hipStream_t st, int w_lo, int w_n, int store_lo, int store_n) {
+    if (w_n < 0) { w_lo = 0; w_n = vol.D; }
+    if (store_n < 0) { store_lo = 0; store_n = vol.D; }
     const int64_t CC = (int64_t)C * 3;
     float* t1 = tmp;
-    float* t2 = tmp + CC * vol.D * vol.H * G[2];
-    launch_ffd_axis(g_dense, t1, spl[2], true, CC * vol.D * vol.H, vol.W, G[2], 1, st);
-    launch_ffd_axis(t1, t2, spl[1], true, CC * vol.D, vol.H, G[1], G[2], st);
-    launch_ffd_axis(t2, g_cp, spl[0], true, CC, vol.D, G[0], (int64_t)G[1] * G[2], st);
+    float* t2 = tmp + CC * store_n * vol.H * G[2];
+    launch_ffd_axis(g_dense, t1, spl[2], true, CC * store_n * vol.H, vol.W, G[2], 1, st);
+    launch_ffd_axis(t1, t2, spl[1], true, CC * store_n, vol.H, G[1], G[2], st);
+    launch_ffd_axis(t2, g_cp, spl[0], true, CC, vol.D, G[0], (int64_t)G[1] * G[2], st, w_lo, w_n, store_lo, store_n);
     return 0;
 }
+
+extern "C" {
 
 int irs_ffd_up(const float* v_cp, float* dense, float* tmp, int C, int D, int H, int W, int c0, int c1, int c2,
                void* stream) {
@@ -441,7 +451,12 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     const size_t fieldI = (size_t)C * 3 * c->vol.V * sizeof(float);   // image-grid field
     const size_t fieldV = (size_t)C * 3 * c->volv.V * sizeof(float);  // velocity-grid field
     const size_t imageI = (size_t)C * c->vol.V * sizeof(float);
-    const size_t ffd_tmp = c->ffd ? 2 * fieldI : 0;
+    // scratch of the three axis passes: (C 3, planes held, G1 G2) + the larger of (., H, G2) [up] and (., H, G2) after (., H W -> G2) [adjoint]
+    size_t ffd_tmp = 0;
+    if (c->ffd) {
+        const size_t planes = (size_t)(c->vol.V / ((int64_t)H * W)), g1 = c->volv.H, g2 = c->volv.W;
+        ffd_tmp = sizeof(float) * (size_t)C * 3 * planes * ((size_t)g1 * g2 + (size_t)H * g2 + (size_t)H * W);
+    }
     c->nll_blocks = data_bwd_blocks(cfg->data_loss, c->vol);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };

@@ -16,6 +16,7 @@ struct irs_comm {
 namespace irs {
 // one grouped round of point-to-point transfers, asynchronous on `st`
 int comm_exchange(irs_comm* c, const irs_xfer* x, int n, hipStream_t st);
-// in-place all-reduce on `st`: SUM of `count` doubles, or (max_u32) MAX of `count` uint32 (non-negative float bits order like integers)
+// in-place all-reduce on `st`; kind 0: SUM of `count` doubles, 1: MAX of `count` uint32 (non-negative float bits order like
+// integers), 2: SUM of `count` floats
 int comm_allreduce(irs_comm* c, void* buf, size_t count, int max_u32, hipStream_t st);
 }  // namespace irs

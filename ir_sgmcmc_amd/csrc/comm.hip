@@ -102,7 +102,8 @@ int comm_allreduce(irs_comm* cm, void* buf, size_t count, int max_u32, hipStream
         if (cm->ar(cm->user, buf, count, max_u32, (void*)st)) return fail("all-reduce callback failed");
         return 0;
     }
-    if (max_u32) NCCL_TRY(g_rccl.AllReduce(buf, buf, count, ncclUint32, ncclMax, (ncclComm_t)cm->nccl, st));
+    if (max_u32 == 1) NCCL_TRY(g_rccl.AllReduce(buf, buf, count, ncclUint32, ncclMax, (ncclComm_t)cm->nccl, st));
+    else if (max_u32 == 2) NCCL_TRY(g_rccl.AllReduce(buf, buf, count, ncclFloat32, ncclSum, (ncclComm_t)cm->nccl, st));
     else NCCL_TRY(g_rccl.AllReduce(buf, buf, count, ncclFloat64, ncclSum, (ncclComm_t)cm->nccl, st));
     return 0;
 }

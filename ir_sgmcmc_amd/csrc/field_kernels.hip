@@ -422,39 +422,55 @@ void launch_warp_nearest_i16(const int16_t* im, int64_t im_stride, const float* 
 // which is conv_transpose1d(stride c, padding 2c-1) followed by the crop [c : c+N] of
 // utils/transformation.py:146-153, and its transpose.
 // ------------------------------------------------------------------------------------------------
+// Row window (z-slab decomposition, slab.hip): the dense side of the D-axis pass is slab-local.  UP produces the output rows
+// [w_lo, w_lo + w_n) only; ADJOINT sums the input rows [w_lo, w_lo + w_n) only (a rank's own planes: the partial sums are
+// all-reduced).  The windowed array stores the rows [store_lo, store_lo + store_n) of its axis.  Full arrays: w = store = whole axis.
 template <bool ADJ>
 __global__ __launch_bounds__(kBlock) void ffd_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           SplineTaps taps, int64_t outer, int n_in, int n_out,
-                                                          int64_t inner) {
-    const int64_t total = outer * n_out * inner;
+                                                          int64_t inner, int w_lo, int w_n, int store_lo, int store_n) {
+    const int rows = ADJ ? n_out : w_n;
+    const int64_t total = outer * rows * inner;
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= total) return;
     const int64_t i = e % inner;
-    const int p = (int)((e / inner) % n_out);
-    const int64_t o = e / (inner * n_out);
-    const float* src = in + o * n_in * inner + i;
+    const int p = (int)((e / inner) % rows) + (ADJ ? 0 : w_lo);
+    const int64_t o = e / (inner * rows);
     const int c = taps.cps;
     float acc = 0.0f;
     if (!ADJ) {
+        const float* src = in + o * n_in * inner + i;
         const int j0 = p / c;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int j = j0 + jj;
             if (j < n_in) acc = fmaf(src[(int64_t)j * inner], taps.k[p + 3 * c - 1 - j * c], acc);
         }
+        out[(o * store_n + (p - store_lo)) * inner + i] = acc;
     } else {
-        const int lo = max((p - 3) * c + 1, 0), hi = min((p + 1) * c - 1, n_in - 1);
+        const float* src = in + (o * store_n - store_lo) * inner + i;
+        const int lo = max(max((p - 3) * c + 1, 0), w_lo), hi = min(min((p + 1) * c - 1, n_in - 1), w_lo + w_n - 1);
         for (int xq = lo; xq <= hi; ++xq) acc = fmaf(src[(int64_t)xq * inner], taps.k[xq + 3 * c - 1 - p * c], acc);
+        out[(o * n_out + p) * inner + i] = acc;
     }
-    out[e] = acc;
 }
 
 void launch_ffd_axis(const float* in, float* out, const SplineTaps& taps, bool adjoint, int64_t outer, int n_in,
-                     int n_out, int64_t inner, hipStream_t st) {
-    const int64_t total = outer * n_out * inner;
+                     int n_out, int64_t inner, hipStream_t st, int w_lo, int w_n, int store_lo, int store_n) {
+    const int axis = adjoint ? n_in : n_out;  // the dense side
+    if (w_n < 0) {
+        w_lo = 0;
+        w_n = axis;
+    }
+    if (store_n < 0) {
+        store_lo = 0;
+        store_n = axis;
+    }
+    const int64_t total = outer * (adjoint ? n_out : w_n) * inner;
+    if (total <= 0) return;
     dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
-    if (adjoint) hipLaunchKernelGGL(ffd_axis_kernel<true>, grid, dim3(kBlock), 0, st, in, out, taps, outer, n_in, n_out, inner);
-    else hipLaunchKernelGGL(ffd_axis_kernel<false>, grid, dim3(kBlock), 0, st, in, out, taps, outer, n_in, n_out, inner);
+    if (adjoint) hipLaunchKernelGGL(ffd_axis_kernel<true>, grid, dim3(kBlock), 0, st, in, out, taps, outer, n_in, n_out, inner, w_lo, w_n, store_lo, store_n);
+    else hipLaunchKernelGGL(ffd_axis_kernel<false>, grid, dim3(kBlock), 0, st, in, out, taps, outer, n_in, n_out, inner, w_lo, w_n, store_lo, store_n);
 }
 
 // out[c] = in[c] * s_c  (chain rule of the prescale: d_0 = v * 2/(n_c-1) / 2^steps)

@@ -46,8 +46,10 @@ void launch_warp_nearest_u8(const uint8_t* im, int64_t im_stride, const float* t
                             hipStream_t st);
 void launch_warp_nearest_i16(const int16_t* im, int64_t im_stride, const float* t, int16_t* out, int C, Vol vol,
                              hipStream_t st);
+// rows [w_lo, w_lo + w_n) of the dense axis produced (up) / summed (adjoint); the windowed array stores rows
+// [store_lo, store_lo + store_n) of that axis.  w_n < 0 / store_n < 0: the whole axis.
 void launch_ffd_axis(const float* in, float* out, const SplineTaps& taps, bool adjoint, int64_t outer, int n_in,
-                     int n_out, int64_t inner, hipStream_t st);
+                     int n_out, int64_t inner, hipStream_t st, int w_lo = 0, int w_n = -1, int store_lo = 0, int store_n = -1);
 void launch_scale_channels(const float* in, float* out, float s0, float s1, float s2, int C, Vol vol, hipStream_t st);
 
 // ---- exp_kernels.hip (z-marching squaring step + owner-computes gather adjoint, LDS-scatter fallback)

@@ -213,9 +213,16 @@ struct Sched {
     std::vector<irs_slab_op> ops;
     int next_id = 0;
 
-    Sched(const SlabInfo& s_, const irs_config& cfg_, int chains_) : s(s_), cfg(cfg_), vol(make_vol(cfg_.dims[0], cfg_.dims[1], cfg_.dims[2])), chains(chains_) {}
+    bool ffd;   // SVFFD_3D: v / noisy / v_s live on the control grid, whole on every rank; d_0 is the up-sampled DENSE field
+    Vol volv;   // the velocity grid (control grid, or the image grid for SVF_3D)
+
+    Sched(const SlabInfo& s_, const irs_config& cfg_, int chains_) : s(s_), cfg(cfg_), vol(make_vol(cfg_.dims[0], cfg_.dims[1], cfg_.dims[2])), chains(chains_) {
+        ffd = cfg.cps[0] || cfg.cps[1] || cfg.cps[2];
+        volv = ffd ? make_vol(control_points(cfg.dims[0], cfg.cps[0]), control_points(cfg.dims[1], cfg.cps[1]), control_points(cfg.dims[2], cfg.cps[2])) : vol;
+    }
+    static int control_points(int n, int cps) { return (int)ceil((double)(n - 1) / (double)cps) + 1 + 2; }  // utils/util.py:61-69
     Vol W(int e) const { return window(vol, s.a - (s.has_lo ? e : 0), s.b + (s.has_hi ? e : 0)); }
-    int step_buf_id(int k) const { return k < 0 ? IRS_SB_VS : IRS_SB_STEP0 + k; }
+    int step_buf_id(int k) const { return k < 0 ? (ffd ? IRS_SB_DENSE : IRS_SB_VS) : IRS_SB_STEP0 + k; }
     // dL/d(d_last) lands in A; adjoint step n-1 writes B, the next one A, ...
     int grad_id(int k, bool input) const {
         const bool odd = ((cfg.no_steps - k) & 1) != 0;
@@ -307,6 +314,19 @@ struct Sched {
     void head(bool noise, bool energy, int e0, int* energy_ar) {
         const int sb = cfg.sobolev_s;
         const int first = sb > 0 ? IRS_SB_NOISY : IRS_SB_VS;
+        if (ffd) {
+            // the control grid is whole on every rank: no exchange, no all-reduce (every rank computes the same numbers); the
+            // dense velocity is up-sampled on the planes the first forward round reads
+            *energy_ar = -1;
+            launch(noise ? IRS_SG_PERTURB : IRS_SG_COPY_V, 0, volv, -1, -1, 0, -1);
+            launch(IRS_SG_SMOOTH, 0, volv, -1, -1, 0, -1);
+            if (energy) {
+                launch(IRS_SG_ENERGY, 0, volv, -1, -1, 0, -1);
+                launch(IRS_SG_REG_SCALAR, 0, volv, -1, -1, 0, -1);
+            }
+            launch(IRS_SG_FFD_UP, 0, W(e0), -1, -1, 0, IRS_SB_DENSE);
+            return;
+        }
         launch(noise ? IRS_SG_PERTURB : IRS_SG_COPY_V, 0, W(0), IRS_SB_V, -1, 0, first);
         wait(exchange(first, sb + e0));
         launch(IRS_SG_SMOOTH, 0, W(e0), first, -1, sb, IRS_SB_VS);
@@ -378,6 +398,16 @@ struct Sched {
                 }
             round(true, grad_id(ks[0], true), p.bw[r], ks, hs, m);
         }
+        if (ffd) {
+            // adjoint of the up-sampling over the owned planes -> partial control-grid gradient -> whole; the update then runs on
+            // the whole control grid on every rank (replicated state stays replicated)
+            launch(IRS_SG_FFD_ADJ, 0, W(0), grad_id(0, false), -1, 0, -1);
+            wait(allreduce(IRS_AR_CPGRAD));
+            launch(IRS_SG_UPDATE, 0, volv, -1, -1, 0, -1);
+            wait(nll_ar);
+            launch(IRS_SG_FINALIZE, 0, W(0), -1, -1, 0, -1);
+            return;
+        }
         // regulariser scalars (their all-reduce has been in flight since the smoothing stage), update, bookkeeping
         wait(energy_ar);
         launch(IRS_SG_REG_SCALAR, 0, W(0), -1, -1, 0, -1);
@@ -410,6 +440,7 @@ struct Exec {
             case IRS_SB_WARPED: *kind = F_IMAGE; return warped;
             case IRS_SB_Z: *kind = F_IMAGE; return z;
             case IRS_SB_GM: *kind = F_IMAGE; return planar(c->gM, v);
+            case IRS_SB_DENSE: *kind = F_PLANAR3; return planar(c->dense, v);
             case IRS_SB_GRAD_A:
             case IRS_SB_GRAD_B: {
                 // the layout of a gradient buffer is that of the adjoint step that READS it next
@@ -481,6 +512,7 @@ struct Exec {
             case IRS_AR_NLL: buf = c->nll_sum; count = (size_t)chains; break;
             case IRS_AR_DMAX: buf = c->dmax; count = (size_t)4 * c->C * (n + 1); mx = 1; break;
             case IRS_AR_MOMENTS: buf = c->stat_sum; count = 3; break;
+            case IRS_AR_CPGRAD: buf = c->tmpB; count = (size_t)chains * 3 * c->volv.V; mx = 2; break;
             default: return fail("slab: unknown all-reduce %d", o.stage);
         }
         // a dedicated event pair per reduction: these results are waited for much later than the exchanges in between
@@ -499,30 +531,53 @@ struct Exec {
         const Vol w = o.hi1 > o.lo1 ? window2(c->vol, o.lo0, o.hi0, o.lo1, o.hi1) : window(c->vol, o.lo0, o.hi0);
         const Lin lin = c->lin.lin();
         const uint64_t* it = &c->state->st.iteration;
-        float* noisy = planar(c->tmpA, v);
+        // SVFFD: the velocity-grid arrays (v, sigma, eps, noisy, v_s, grad_v) are whole control-grid arrays, not slab-local
+        float* noisy = c->ffd ? c->tmpA : planar(c->tmpA, v);
+        const Vol wv = c->ffd ? c->volv : w;  // window of the velocity-grid stages
+        const float* d0 = c->ffd ? planar(c->dense, v) : vs;  // what squaring step 0 reads
         const int64_t HW = (int64_t)c->vol.H * c->vol.W;
         switch (o.stage) {
             case IRS_SG_PERTURB:
-                launch_perturb(v_src, io.sigma, io.eps, (float)sqrt(2.0 * (double)cfg.lr), cfg.sobolev_s > 0 ? noisy : vs, C, w, cfg.seed, 0, it, st);
+                launch_perturb(v_src, io.sigma, io.eps, (float)sqrt(2.0 * (double)cfg.lr), cfg.sobolev_s > 0 ? noisy : vs, C, wv, cfg.seed, 0, it, st);
                 break;
             case IRS_SG_COPY_V: {
                 float* first = cfg.sobolev_s > 0 ? noisy : vs;
+                if (c->ffd) {
+                    HIP_TRY(hipMemcpyAsync(first, v_src, (size_t)C * 3 * c->volv.V * sizeof(float), hipMemcpyDeviceToDevice, st));
+                    break;
+                }
                 for (int ch = 0; ch < 3 * C; ++ch)
                     HIP_TRY(hipMemcpyAsync(first + (int64_t)ch * c->vol.V + (int64_t)w.z0 * HW, v_src + (int64_t)ch * c->vol.V + (int64_t)w.z0 * HW,
                                            (size_t)w.nz * HW * sizeof(float), hipMemcpyDeviceToDevice, st));
                 break;
             }
             case IRS_SG_SMOOTH:
-                if (cfg.sobolev_s > 0) launch_sobolev_march(noisy, vs, c->sob, C * 3, w, c->dmax, n, st);
-                else launch_field_absmax(vs, true, n, c->dmax, C, w, st);
+                if (cfg.sobolev_s > 0) launch_sobolev_march(noisy, vs, c->sob, C * 3, wv, c->ffd ? nullptr : c->dmax, n, st);
+                else if (!c->ffd) launch_field_absmax(vs, true, n, c->dmax, C, w, st);
                 break;
             case IRS_SG_ENERGY:
-                launch_reg_energy(vs, c->energy_partials, C, w, st);
-                launch_reduce_partials(c->energy_partials, energy_blocks(w), C, c->energy_sum, st);
+                launch_reg_energy(vs, c->energy_partials, C, wv, st);
+                launch_reduce_partials(c->energy_partials, energy_blocks(wv), C, c->energy_sum, st);
                 break;
+            case IRS_SG_FFD_UP: {
+                const int G[3] = {c->volv.D, c->volv.H, c->volv.W};
+                ffd_up(vs, c->dense, c->tmpA, C, c->vol, G, c->spl, st, w.z0, w.nz, c->sl.lo, c->sl.hi - c->sl.lo);
+                launch_field_absmax(d0, true, n, c->dmax, C, w, st);  // bound of d_0
+                break;
+            }
+            case IRS_SG_FFD_ADJ: {
+                float sc3[3];
+                prescale_factors(c->vol, n, sc3);
+                float* g0 = grad_raw(c, 0, false);
+                float* scaled = g0 == c->gA ? c->gB : c->gA;
+                launch_scale_channels(planar(g0, v), planar(scaled, v), sc3[0], sc3[1], sc3[2], C, w, st);
+                const int G[3] = {c->volv.D, c->volv.H, c->volv.W};
+                ffd_adjoint(scaled, c->tmpB, c->tmpA, C, c->vol, G, c->spl, st, w.z0, w.nz, c->sl.lo, c->sl.hi - c->sl.lo);
+                break;
+            }
             case IRS_SG_EXP_FWD: {
                 const int k = o.k;
-                const float* in = k == 0 ? vs : step_buf(c, v, k - 1);
+                const float* in = k == 0 ? d0 : step_buf(c, v, k - 1);
                 launch_exp_step_fwd_march(in, step_buf(c, v, k), k == 0, n, C, w, lin, c->dmax + (int64_t)k * c->C * 4,
                                           c->dmax + (int64_t)(k + 1) * c->C * 4, predicted_small(c, k), fwd_lay(c, k), st);
                 break;
@@ -572,7 +627,7 @@ struct Exec {
                 float* go = grad_raw(c, k, false);
                 const float* G = (lay & 2) ? aos(gi, v) : planar(gi, v);
                 float* out = (lay & 4) ? aos(go, v) : planar(go, v);
-                const float* dk = k == 0 ? vs : step_buf(c, v, k - 1);
+                const float* dk = k == 0 ? d0 : step_buf(c, v, k - 1);
                 const unsigned* dm = c->dmax + (int64_t)k * c->C * 4;
                 const bool skip_any = (hplan >= 1 && hplan <= 2) || predicted_below(c, k, 1.5f);
                 launch_exp_step_bwd_march(G, dk, out, k == 0, n, c->C, w, lin, dm, hplan == 1 ? 1 : 2, skip_any, nullptr, lay, nullptr, st);
@@ -586,7 +641,8 @@ struct Exec {
             case IRS_SG_UPDATE: {
                 float sc3[3];
                 prescale_factors(c->vol, n, sc3);
-                launch_sgld_update(io.v, io.sigma, planar(grad_raw(c, 0, false), v), vs, c->state, cfg.lr, sc3[0], sc3[1], sc3[2], io.grad_v, C, w, st);
+                if (c->ffd) launch_sgld_update(io.v, io.sigma, c->tmpB, vs, c->state, cfg.lr, 1.0f, 1.0f, 1.0f, io.grad_v, C, wv, st);
+                else launch_sgld_update(io.v, io.sigma, planar(grad_raw(c, 0, false), v), vs, c->state, cfg.lr, sc3[0], sc3[1], sc3[2], io.grad_v, C, w, st);
                 break;
             }
             case IRS_SG_FINALIZE: {
@@ -668,16 +724,18 @@ irs_io shifted_io(const irs_ctx* c, const irs_io* io) {
     irs_io o = *io;
     o.fixed_im = planar(io->fixed_im, v);
     o.mask = planar(io->mask, v);
-    o.v = planar(io->v, v);
-    o.sigma = planar(io->sigma, v);
-    o.eps = planar(io->eps, v);
+    if (!c->ffd) {  // (SVFFD: these live on the control grid, whole on every rank)
+        o.v = planar(io->v, v);
+        o.sigma = planar(io->sigma, v);
+        o.eps = planar(io->eps, v);
+        o.curr_state = planar(io->curr_state, v);
+        o.grad_v = planar(io->grad_v, v);
+    }
     o.unif = planar(io->unif, v);
-    o.curr_state = planar(io->curr_state, v);
     o.im_moving_warped = planar(io->im_moving_warped, v);
     o.residuals = planar(io->residuals, v);
     o.displacement = planar(io->displacement, v);
     o.transformation = planar(io->transformation, v);
-    o.grad_v = planar(io->grad_v, v);
     return o;  // moving_im stays: it is the whole volume
 }
 
@@ -724,7 +782,6 @@ int irs_slab_plan_layout(const irs_config* cfg, const irs_slab_config* scfg, int
 int irs_slab_create(const irs_config* cfg, const irs_slab_config* scfg, irs_comm* comm, irs_ctx** out) {
     if (!cfg || !out) return fail("irs_slab_create: null argument");
     const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
-    if (cfg->cps[0] || cfg->cps[1] || cfg->cps[2]) return fail("irs_slab_create: the slab decomposition supports SVF_3D only");
     if (!use_lds_exp()) return fail("irs_slab_create: needs the LDS squaring kernels (IRS_EXP_LDS=1)");
     if (cfg->no_steps > kMaxSteps) return fail("irs_slab_create: at most %d squaring steps", kMaxSteps);
     SlabInfo s;
@@ -804,7 +861,7 @@ int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
     const bool planned = plan_widths(c, plan);
     if (planned && plan_rounds(plan, s.gmax, s.world > 1 ? s.min_slab : 1 << 30)) return 1;
 
-    Exec ex{c, st, c->cs, io, io.v, io.curr_state ? io.curr_state : planar(c->vs, v), io.im_moving_warped ? io.im_moving_warped : planar(c->warped, v),
+    Exec ex{c, st, c->cs, io, io.v, io.curr_state ? io.curr_state : (c->ffd ? c->vs : planar(c->vs, v)), io.im_moving_warped ? io.im_moving_warped : planar(c->warped, v),
             io.residuals ? io.residuals : planar(c->z, v), planned ? &plan : nullptr, cfg.uniform_alpha > 0.0f, C};
     memset(ex.pending, 0, sizeof(ex.pending));
     ex.stats_vd = cfg.virtual_decimation;
@@ -856,14 +913,19 @@ int irs_slab_gmm_init(irs_ctx* c, const irs_io* io_in, const float* v_sample, in
     io.displacement = nullptr;
     // trainer.py:529-547: one velocity sample (no Langevin noise, no jitter), batch of one; staged in gB (free until the backward pass)
     const int64_t HW = (int64_t)c->vol.H * c->vol.W;
-    for (int ch = 0; ch < 3; ++ch) {
-        float* dst = c->gB + (int64_t)ch * c->vol.V + (int64_t)(s.a - s.lo) * HW;
-        const size_t bytes = (size_t)(s.b - s.a) * HW * sizeof(float);
-        if (v_sample) HIP_TRY(hipMemcpyAsync(dst, v_sample + (int64_t)ch * c->vol.V + (int64_t)(s.a - s.lo) * HW, bytes, hipMemcpyDeviceToDevice, st));
-        else HIP_TRY(hipMemsetAsync(dst, 0, bytes, st));
-    }
+    if (c->ffd) {  // the sample is a whole control-grid field: staged in tmpB (velocity-grid sized, untouched by the forward pass)
+        const size_t bytes = (size_t)3 * c->volv.V * sizeof(float);
+        if (v_sample) HIP_TRY(hipMemcpyAsync(c->tmpB, v_sample, bytes, hipMemcpyDeviceToDevice, st));
+        else HIP_TRY(hipMemsetAsync(c->tmpB, 0, bytes, st));
+    } else
+        for (int ch = 0; ch < 3; ++ch) {
+            float* dst = c->gB + (int64_t)ch * c->vol.V + (int64_t)(s.a - s.lo) * HW;
+            const size_t bytes = (size_t)(s.b - s.a) * HW * sizeof(float);
+            if (v_sample) HIP_TRY(hipMemcpyAsync(dst, v_sample + (int64_t)ch * c->vol.V + (int64_t)(s.a - s.lo) * HW, bytes, hipMemcpyDeviceToDevice, st));
+            else HIP_TRY(hipMemsetAsync(dst, 0, bytes, st));
+        }
     Plan plan;
-    Exec ex{c, st, c->cs, io, planar(c->gB, v), planar(c->vs, v), planar(c->warped, v), planar(c->z, v), nullptr, false, 1};
+    Exec ex{c, st, c->cs, io, c->ffd ? c->tmpB : planar(c->gB, v), c->ffd ? c->vs : planar(c->vs, v), planar(c->warped, v), planar(c->z, v), nullptr, false, 1};
     memset(ex.pending, 0, sizeof(ex.pending));
     Sched sch(s, c->cfg, 1);
     HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));

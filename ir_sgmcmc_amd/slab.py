@@ -97,10 +97,11 @@ class SlabComm:
         def allreduce(user, buf, count, max_u32, stream):
             try:
                 wait(stream)
-                nbytes = count * (4 if max_u32 else 8)
-                raw = view(buf, nbytes)
-                host = raw.cpu().view(torch.int32 if max_u32 else torch.float64)  # non-negative float bits order like int32
-                dist.all_reduce(host, op=dist.ReduceOp.MAX if max_u32 else dist.ReduceOp.SUM)
+                # kind 0: SUM of doubles, 1: MAX of uint32 (non-negative float bits order like int32), 2: SUM of floats
+                dtype = {0: torch.float64, 1: torch.int32, 2: torch.float32}[max_u32]
+                raw = view(buf, count * (8 if max_u32 == 0 else 4))
+                host = raw.cpu().view(dtype)
+                dist.all_reduce(host, op=dist.ReduceOp.MAX if max_u32 == 1 else dist.ReduceOp.SUM)
                 raw.copy_(host.view(torch.uint8))
                 torch.cuda.synchronize(device)
                 return 0
@@ -160,11 +161,10 @@ def trace(cfg: EngineConfig, rank, world, h, ghost_max=0, margin=0):
 
 
 class SlabEngine(TransitionEngine):
-    """one rank's share of a chain: same surface as TransitionEngine, slab-local tensors (moving image whole)"""
+    """one rank's share of a chain: same surface as TransitionEngine, slab-local tensors (moving image whole; for SVFFD_3D the
+    control-grid tensors v / sigma / eps / curr_state / grad_v whole too: `local_v`)"""
 
     def __init__(self, cfg: EngineConfig, device='cuda:0', comm: SlabComm = None, ghost_max=0, margin=0):
-        if cfg.cps:
-            raise L.IrsError('the slab decomposition supports SVF_3D only')
         self.comm = comm
         self._scfg = L.IrsSlabConfig(ghost_max, margin)
         super().__init__(cfg, device)
@@ -183,6 +183,11 @@ class SlabEngine(TransitionEngine):
     def local(self, t):
         """the held planes [lo, hi) of a full (C, ch, D, H, W) tensor, contiguous, on the engine's device"""
         return t[:, :, self.lo:self.hi].to(self.device).contiguous()
+
+    def local_v(self, t):
+        """a velocity-grid tensor (v, sigma, eps, curr_state, grad_v) as the engine wants it: cut to the held planes for SVF_3D;
+        WHOLE for SVFFD_3D, whose control grid is replicated on every rank"""
+        return t.to(self.device).contiguous() if self.cfg.cps else self.local(t)
 
     def new_local(self, channels, dtype=torch.float32):
         return torch.zeros(self.cfg.no_chains, channels, self.hi - self.lo, *self.cfg.dims[1:], device=self.device, dtype=dtype)

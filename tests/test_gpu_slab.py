@@ -21,19 +21,20 @@ DEV = 'cuda:0'
 T = 3  # transitions: the first measures the ghost widths (exact mode), the second and third run from predicted widths
 
 
-def _setup(N, C, data_loss, seed=0, vd=True, amp=9.0, reg='RegLoss_LogNormal', with_noise=True):
+def _setup(N, C, data_loss, seed=0, vd=True, amp=9.0, reg='RegLoss_LogNormal', with_noise=True, cps=None):
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from ir_sgmcmc_amd.engine import EngineConfig
     from oracle import ops as O
     cfg = EngineConfig(dims=(N, N, N), no_chains=C, data_loss=data_loss, virtual_decimation=vd, lcc_s=1,
-                       reg_loss=reg, reg_learnable=(reg == 'RegLoss_LogNormal'), seed=seed)
+                       reg_loss=reg, reg_learnable=(reg == 'RegLoss_LogNormal'), seed=seed, cps=cps, lr=0.01 if cps else 0.4)
     f1, m1 = synthetic_pair((N, N, N), seed=3)
     fixed = {k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'}
     moving = {k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'}
     g = torch.Generator().manual_seed(17)
-    v0 = O.separable_conv3d_replicate(amp * torch.randn(C, 3, N, N, N, generator=g), O.sobolev_kernel_1d(3, 0.5)).contiguous()
+    dv = cfg.dims_v  # the control grid for SVFFD_3D, the image grid otherwise
+    v0 = O.separable_conv3d_replicate(amp * torch.randn(C, 3, *dv, generator=g), O.sobolev_kernel_1d(3, 0.5)).contiguous()
     # without injected noise every rank draws the in-kernel Philox noise of ITS planes of the same field
-    noise = [(torch.randn(C, 3, N, N, N, generator=g), torch.rand(C, 3, N, N, N, generator=g)) if with_noise else (None, None)
+    noise = [(torch.randn(C, 3, *dv, generator=g), torch.rand(C, 3, N, N, N, generator=g)) if with_noise else (None, None)
              for _ in range(T)]
     return cfg, fixed, moving, v0, noise
 
@@ -58,19 +59,19 @@ def _run_slab(cfg, fixed, moving, v0, noise, comm=None, **kw):
     eng = SlabEngine(cfg, DEV, comm, **kw)
     fd, md = eng.prepare(fixed, moving)
     eng.gmm_init(fd, md)
-    v = eng.local(v0)
+    v = eng.local_v(v0)
     disp = eng.new_local(3)
     scal = []
     for eps, unif in noise:
-        eng.transition(fd, md, v, None, eng.local(eps) if eps is not None else None, eng.local(unif) if unif is not None else None,
+        eng.transition(fd, md, v, None, eng.local_v(eps) if eps is not None else None, eng.local(unif) if unif is not None else None,
                        {'displacement': disp})
         scal.append(eng.scalars())
     return eng, v, disp, scal
 
 
-@pytest.mark.parametrize('data_loss,C', [('GMM', 1), ('SSD', 2)])
-def test_slab_single_rank_equals_fused(data_loss, C):
-    cfg, fixed, moving, v0, noise = _setup(24, C, data_loss)
+@pytest.mark.parametrize('data_loss,C,cps', [('GMM', 1, None), ('SSD', 2, None), ('GMM', 1, (4, 4, 4))])
+def test_slab_single_rank_equals_fused(data_loss, C, cps):
+    cfg, fixed, moving, v0, noise = _setup(24, C, data_loss, cps=cps, amp=20.0 if cps else 9.0)
     v_ref, d_ref, s_ref, st_ref = _run_fused(cfg, fixed, moving, v0, noise)
     eng, v, d, s = _run_slab(cfg, fixed, moving, v0, noise)
     assert (eng.a, eng.b, eng.lo, eng.hi) == (0, 24, 0, 24)
@@ -93,7 +94,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max):
+def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max, cps=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -101,13 +102,13 @@ def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max):
         torch.cuda.set_device(0)
         comm = SlabComm.rehearsal(DEV)
         comm.selftest()
-        cfg, fixed, moving, v0, noise = _setup(N, C, data_loss, vd=vd, amp=amp, reg=reg, with_noise=N < 128)
+        cfg, fixed, moving, v0, noise = _setup(N, C, data_loss, vd=vd, amp=amp, reg=reg, with_noise=N < 128, cps=cps)
         eng, v, d, s = _run_slab(cfg, fixed, moving, v0, noise, comm, ghost_max=ghost_max)
         assert (eng.a, eng.b) == ((rank * N) // world, ((rank + 1) * N) // world)
         assert eng.hi - eng.lo < N  # slab-local arrays
         st = eng.status()
         assert st['exchanges'] > 0 and st['mispredictions'] == 0 and st['exact_transitions'] == 1, st
-        v_full, d_full = eng.gather(v), eng.gather(d)
+        v_full, d_full = (v.cpu() if cps else eng.gather(v)), eng.gather(d)  # (SVFFD: the control grid is whole on every rank)
         if rank == 0:
             v_ref, d_ref, s_ref, _ = _run_fused(cfg, fixed, moving, v0, noise)
             dv = float((v_full - v_ref).abs().max()) / float(v_ref.abs().max())
@@ -144,6 +145,18 @@ def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max):
     check(name, 'loss terms (rel)', ds, 0.0, 1e-6)
     # communication-avoiding rounds: 12 squaring steps in fewer forward exchanges than steps
     assert st['last_fwd_rounds'] < 12 or ghost_max == 1, st
+
+
+@pytest.mark.parametrize('data_loss,C,N,world,cps', [('GMM', 1, 32, 2, (4, 4, 4)), ('SSD', 2, 36, 3, (2, 2, 2))])
+def test_slab_svffd(data_loss, C, N, world, cps):
+    """SVFFD_3D (utils/transformation.py:126-164; the experiment5 configs): control grid whole on every rank, dense velocity
+    up-sampled per slab, control-grid gradient all-reduced"""
+    dv, dd, ds, st = _launch(world, data_loss, C, N, True, 20.0, 'RegLoss_LogNormal', 4, cps)
+    from tests._report import check
+    name = f'slab/svffd{cps[0]}_{data_loss}_C{C}_N{N}_ranks{world}'
+    check(name, 'v_new (rel to max)', dv, 0.0, 1e-5)
+    check(name, 'displacement [voxels]', dd, 0.0, 1e-5)
+    check(name, 'loss terms (rel)', ds, 0.0, 1e-6)
 
 
 def test_config4_256_cubed_ssd_two_slabs():

@@ -68,6 +68,7 @@ class Replay:
     def __init__(self, cfg, rank, world, h, ghost_max):
         self.lay = plan_layout(cfg, rank, world, ghost_max=ghost_max)
         self.rank, self.world, self.D, self.n = rank, world, cfg.dims[0], cfg.no_steps
+        self.ffd = bool(cfg.cps)
         self.a, self.b, self.lo, self.hi = (self.lay[k] for k in ('a', 'b', 'lo', 'hi'))
         self.h = h
         self.ops = trace(cfg, rank, world, h, ghost_max=ghost_max)
@@ -82,15 +83,18 @@ class Replay:
     def expect_tag(self, o, which):
         """the tensor a squaring-step launch must find in its input buffers"""
         k, n = o['k'], self.n
+        d0 = (L.IRS_SG_FFD_UP, 0) if self.ffd else (L.IRS_SG_SMOOTH, 0)  # SVFFD: the up-sampled dense velocity
         if o['stage'] == L.IRS_SG_EXP_FWD:
-            return (L.IRS_SG_SMOOTH, 0) if k == 0 else (L.IRS_SG_EXP_FWD, k - 1)
+            return d0 if k == 0 else (L.IRS_SG_EXP_FWD, k - 1)
         if o['stage'] == L.IRS_SG_EXP_BWD:
             if which == 0:
                 return (L.IRS_SG_WARP_BWD, 0) if k == n - 1 else (L.IRS_SG_EXP_BWD, k + 1)
-            return (L.IRS_SG_SMOOTH, 0) if k == 0 else (L.IRS_SG_EXP_FWD, k - 1)
+            return d0 if k == 0 else (L.IRS_SG_EXP_FWD, k - 1)
         return None
 
     def launch(self, o):
+        if o['stage'] >= 32 or (self.ffd and o['stage'] in (L.IRS_SG_PERTURB, L.IRS_SG_COPY_V, L.IRS_SG_SMOOTH, L.IRS_SG_ENERGY, L.IRS_SG_UPDATE)):
+            return  # single-workgroup scalar stages; SVFFD control-grid stages (whole on every rank): no plane bookkeeping
         wins = self.clip(o['lo0'], o['hi0']) | self.clip(o['lo1'], o['hi1'])
         reads = set()
         for lo, hi in ((o['lo0'], o['hi0']), (o['lo1'], o['hi1'])):
@@ -166,35 +170,42 @@ class Replay:
         # every squaring step and its adjoint covered the slab; the update wrote v on the owned planes
         for k in range(self.n):
             assert own <= self.written[(L.IRS_SG_EXP_FWD, k)] and own <= self.written[(L.IRS_SG_EXP_BWD, k)]
-        assert self.written[(L.IRS_SG_UPDATE, 0)] == own
+        if self.ffd:
+            assert own <= self.written[(L.IRS_SG_FFD_UP, 0)] and any(o['kind'] == L.IRS_OP_ALLREDUCE and o['stage'] == 4 for o in self.ops)
+        else:
+            assert self.written[(L.IRS_SG_UPDATE, 0)] == own
         return self.n_exchanges
 
 
-def _worker(rank, world, port, q, N, h, ghost_max, loss):
+def _worker(rank, world, port, q, N, h, ghost_max, loss, cps=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        cfg = EngineConfig(dims=(N, 16, 16), data_loss=loss, virtual_decimation=(loss == 'GMM'))
+        cfg = EngineConfig(dims=(N, 16, 16), data_loss=loss, virtual_decimation=(loss == 'GMM'), cps=cps)
         n = Replay(cfg, rank, world, h, ghost_max).run()
         if rank == 0:
             q.put(n)
-    finally:
-        dist.barrier()
-        dist.destroy_process_group()
+    except BaseException:  # leave at once: the peers then fail on their next message instead of waiting for this rank
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,N,h,ghost_max,loss', [
-    (2, 64, [1] * 12, 4, 'GMM'),                      # the common case: sub-voxel steps, rounds of four
-    (2, 64, [1] * 12, 1, 'SSD'),                      # one step per round
-    (2, 96, [1] * 8 + [1, 2, 2, 3], 4, 'GMM'),        # late steps with wider ghost zones
-    (3, 96, [1] * 12, 4, 'SSD'),                      # a middle rank with two neighbours
-    (3, 120, [1] * 6 + [1, 1, 2, 2, 4, 7], 4, 'GMM'),  # a single step wider than ghost_max is a round of its own
+@pytest.mark.parametrize('world,N,h,ghost_max,loss,cps', [
+    (2, 64, [1] * 12, 4, 'GMM', None),                # the common case: sub-voxel steps, rounds of four
+    (2, 64, [1] * 9 + [1, 2, 2], 4, 'GMM', (4, 4, 4)),  # SVFFD_3D: control grid whole, dense velocity per slab
+    (2, 64, [1] * 12, 1, 'SSD', None),                    # one step per round
+    (2, 96, [1] * 8 + [1, 2, 2, 3], 4, 'GMM', None),      # late steps with wider ghost zones
+    (3, 96, [1] * 12, 4, 'SSD', None),                    # a middle rank with two neighbours
+    (3, 120, [1] * 6 + [1, 1, 2, 2, 4, 7], 4, 'GMM', None),  # a single step wider than ghost_max is a round of its own
 ])
-def test_schedule_replay_over_gloo(world, N, h, ghost_max, loss):
+def test_schedule_replay_over_gloo(world, N, h, ghost_max, loss, cps):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, N, h, ghost_max, loss)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, N, h, ghost_max, loss, cps)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -203,4 +214,5 @@ def test_schedule_replay_over_gloo(world, N, h, ghost_max, loss):
     n_exchanges = q.get(timeout=10)
     rounds = plan_rounds(h, ghost_max, N // world)
     # perturbed velocity + (forward rounds - the first, which lives off the widened smoothing) + warped image + backward rounds
-    assert n_exchanges == 1 + (len(rounds['fwd_width']) - 1) + (1 if loss == 'GMM' else 0) + len(rounds['bwd_width'])
+    # (SVFFD: no exchange of the perturbed velocity -- the control grid is whole everywhere)
+    assert n_exchanges == (0 if cps else 1) + (len(rounds['fwd_width']) - 1) + (1 if loss == 'GMM' else 0) + len(rounds['bwd_width'])
