@@ -394,7 +394,12 @@ def main():
                                              f'({dt:.2f} s each, {cores} threads)' + (f', scaled by voxel count x{scale:.0f} to {N}^3' if scale != 1 else '')}
         print(json.dumps(out), flush=True)
     if world > 1:
+        # tear down in order: engine (its streams drain), the library's RCCL communicator, then torch's process group
+        torch.cuda.synchronize(dev)
         dist.barrier()
+        if slab:
+            eng = None
+            comm.close()
         dist.destroy_process_group()
 
 
