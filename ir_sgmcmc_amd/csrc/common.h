@@ -82,6 +82,8 @@ __host__ __device__ inline int64_t win_voxels(const Vol& v) { return (int64_t)(v
 inline int pick_seg_len(int nz, int64_t tiles_per_layer, int min_len, int forced, int64_t want_blocks = 1024) {
     if (forced > 0) return forced;
     static const int64_t want_env = getenv("IRS_SEG_MIN_BLOCKS") ? atoll(getenv("IRS_SEG_MIN_BLOCKS")) : 0;
+    static const int min_env = getenv("IRS_SEG_MIN_LEN") ? atoi(getenv("IRS_SEG_MIN_LEN")) : 0;
+    if (min_env > 0) min_len = min_env;
     const int64_t want = want_env > 0 ? want_env : want_blocks;
     int len = 32;
     while (len > min_len && tiles_per_layer * ((nz + len - 1) / len) < want) len >>= 1;

@@ -245,20 +245,21 @@ struct Sched {
         o.out = out;
         ops.push_back(o);
     }
-    int comm(int kind, int what, int width) {  // EXCHANGE of buffer `what` / ALLREDUCE of reduction `what`; returns its id
+    int comm(int kind, int what, int width, int k = 0) {  // EXCHANGE of buffer `what` / ALLREDUCE of reduction `what`; returns its id
         irs_slab_op o;
         memset(&o, 0, sizeof(o));
         o.kind = kind;
         o.stage = what;
         o.width = width;
+        o.k = k;  // exchange: the squaring step that consumes the ghost planes (names the layout of a gradient buffer)
         o.id = next_id++;
         o.in0 = o.in1 = o.out = -1;
         ops.push_back(o);
         return o.id;
     }
-    int exchange(int buf, int width) {
+    int exchange(int buf, int width, int k = 0) {
         if (s.world == 1 || width <= 0) return -1;
-        return comm(IRS_OP_EXCHANGE, buf, width);
+        return comm(IRS_OP_EXCHANGE, buf, width, k);
     }
     int allreduce(int which) { return s.world == 1 ? -1 : comm(IRS_OP_ALLREDUCE, which, 0); }
     void wait(int id) {
@@ -291,7 +292,7 @@ struct Sched {
     // one round: [exchange of `xbuf`, w planes] + steps ks[0..m) in execution order with ghost widths hs[]: the interiors while
     // the exchange is in flight, the boundary strips when the ghost planes have arrived
     void round(bool backward, int xbuf, int w, const int* ks, const int* hs, int m) {
-        const int id = exchange(xbuf, w);
+        const int id = exchange(xbuf, w, ks[0]);
         const bool split = id >= 0;
         Vol in[kMaxSteps], bd[kMaxSteps];
         int r = 0;
@@ -445,9 +446,7 @@ struct Exec {
             case IRS_SB_GRAD_B: {
                 // the layout of a gradient buffer is that of the adjoint step that READS it next
                 float* raw = id == IRS_SB_GRAD_A ? c->gA : c->gB;
-                bool a = false;
-                for (int k = 0; k < n; ++k)
-                    if (grad_raw(c, k, true) == raw && cur_bwd_k == k) a = (bwd_lay(c, k) & 2) != 0;
+                const bool a = cur_bwd_k >= 0 && cur_bwd_k < n && (bwd_lay(c, cur_bwd_k) & 2) != 0;
                 *kind = a ? F_AOS3 : F_PLANAR3;
                 return a ? aos(raw, v) : planar(raw, v);
             }
@@ -468,13 +467,7 @@ struct Exec {
             if (o.kind == IRS_OP_LAUNCH) {
                 if (launch(o)) return 1;
             } else if (o.kind == IRS_OP_EXCHANGE) {
-                // the adjoint step that follows names the layout of a gradient buffer
-                cur_bwd_k = -1;
-                for (int j = i + 1; j < n_ops; ++j)
-                    if (ops[j].kind == IRS_OP_LAUNCH) {
-                        if (ops[j].stage == IRS_SG_EXP_BWD) cur_bwd_k = ops[j].k;
-                        break;
-                    }
+                cur_bwd_k = o.k;  // the adjoint step that consumes the ghost planes names the layout of a gradient buffer
                 if (exchange(o)) return 1;
             } else if (o.kind == IRS_OP_ALLREDUCE) {
                 if (allreduce(o)) return 1;

@@ -134,12 +134,14 @@ def _launch(world, *args):
     return q.get(timeout=10)
 
 
-@pytest.mark.parametrize('data_loss,C,N,world,ghost_max', [('GMM', 1, 32, 2, 4), ('SSD', 2, 24, 2, 2), ('GMM', 1, 48, 3, 4),
-                                                           ('SSD', 1, 40, 2, 1)])
-def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max):
-    dv, dd, ds, st = _launch(world, data_loss, C, N, True, 9.0, 'RegLoss_LogNormal', ghost_max)
+@pytest.mark.parametrize('data_loss,C,N,world,ghost_max,amp', [
+    ('GMM', 1, 32, 2, 4, 9.0), ('SSD', 2, 24, 2, 2, 9.0), ('GMM', 1, 48, 3, 4, 9.0), ('SSD', 1, 40, 2, 1, 9.0),
+    ('GMM', 1, 30, 3, 8, 16.0),   # thin slabs (10 planes) under a displacement of several voxels: late steps are all boundary, no interior
+])
+def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max, amp):
+    dv, dd, ds, st = _launch(world, data_loss, C, N, True, amp, 'RegLoss_LogNormal', ghost_max)
     from tests._report import check
-    name = f'slab/{data_loss}_C{C}_N{N}_ranks{world}_g{ghost_max}'
+    name = f'slab/{data_loss}_C{C}_N{N}_ranks{world}_g{ghost_max}_amp{amp:g}'
     check(name, 'v_new (rel to max)', dv, 0.0, 1e-5)
     check(name, 'displacement [voxels]', dd, 0.0, 1e-5)
     check(name, 'loss terms (rel)', ds, 0.0, 1e-6)
