@@ -79,13 +79,17 @@ struct irs_ctx {
     irs_comm* comm = nullptr;      // not owned
     hipStream_t cs = nullptr;      // communication stream (owned)
     hipEvent_t sev[24];            // 0..15 rotating producer / receive events of the exchanges, 16.. pairs of the all-reduces
-    unsigned* used_dev = nullptr;  // [no_steps] ghost widths the current transition was planned with (device copy for validation)
+    unsigned* plan_hint = nullptr; // pinned, TWO slots of kHintWords: the all-reduced bounds of transition t land in slot t % 2.  The
+                                   // plan of transition t reads slot t % 2 = the bounds of t - 2, a transition every rank has
+                                   // seen FINISH (the host waits for it): every rank plans from the same numbers.  (The single
+                                   // `hint` above is read whenever -- fine for launch decisions, fatal for exchange widths.)
     double* hsum = nullptr;        // pinned: host copy of small reductions in exact mode
     int pred[32];                  // host: ghost-width plan source (bounds of the last exact transition); -1 = none
     bool have_pred = false;
     uint64_t slab_exchanged_bytes = 0;  // bookkeeping for tests / reports
     uint64_t slab_exchanges = 0;
     uint64_t slab_exact = 0;           // transitions run in measuring mode
+    uint64_t slab_mispredictions = 0;  // transitions found to have run with too narrow a plan (reported as errors)
     int last_nf = 0, last_nb = 0;      // exchange rounds of the last transition
 };
 

@@ -197,7 +197,7 @@ __global__ void validate_widths_kernel(const unsigned* __restrict__ dmax, Used u
         for (int i = 0; i < C * 4; ++i) m = fmaxf(m, __uint_as_float(dmax[k * C * 4 + i]));
         if (!(m >= 0.0f) || (int)floorf(m) + 1 > used.h[k]) bad = 1;
     }
-    if (bad) flags[0] += 1;
+    flags[0] = bad;  // (per transition: the slot of the plan hints this transition publishes into)
 }
 
 // ================================================================================================
@@ -641,8 +641,10 @@ struct Exec {
             case IRS_SG_FINALIZE: {
                 Used used;
                 for (int k = 0; k < kMaxSteps; ++k) used.h[k] = plan && k < n ? plan->h[k] : 0;
-                hipLaunchKernelGGL(validate_widths_kernel, dim3(1), dim3(64), 0, st, c->dmax, used, n, c->C, c->hint + (kHintWords - 8));
-                launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, c->dmax, c->hint, 4 * c->C * (n + 1), 0u, 0, true, st);
+                hipLaunchKernelGGL(validate_widths_kernel, dim3(1), dim3(64), 0, st, c->dmax, used, n, c->C,
+                                   c->plan_hint + (c->n_enqueued % 2) * kHintWords + (kHintWords - 8));
+                launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, c->dmax, c->plan_hint + (c->n_enqueued % 2) * kHintWords,
+                                4 * c->C * (n + 1), 0u, 0, true, st);
                 c->dmax_clean = true;
                 break;
             }
@@ -660,9 +662,9 @@ int ghost_width_from_bound(float m, bool safety) {
     return (int)floorf(safety ? 1.25f * m + 0.25f : m) + 1;
 }
 
-// global bound (all chains, all axes) of d_k as the host last saw it
-float hint_bound(const irs_ctx* c, int k) {
-    const volatile unsigned* h = c->hint + (size_t)k * c->C * 4;
+// global bound (all chains, all axes) of d_k in a slot of the plan hints
+float hint_bound(const irs_ctx* c, const unsigned* slot, int k) {
+    const volatile unsigned* h = slot + (size_t)k * c->C * 4;
     float m = 0.0f;
     for (int i = 0; i < c->C * 4; ++i) {
         const unsigned bits = h[i];
@@ -740,6 +742,7 @@ void slab_release(irs_ctx* c) {
     for (int i = 0; i < 24; ++i)
         if (c->sev[i]) (void)hipEventDestroy(c->sev[i]);
     if (c->cs) (void)hipStreamDestroy(c->cs);
+    if (c->plan_hint) (void)hipHostFree(c->plan_hint);
 }
 }  // namespace irs
 
@@ -788,6 +791,9 @@ int irs_slab_create(const irs_config* cfg, const irs_slab_config* scfg, irs_comm
     if (create_ctx(cfg, &s, &c)) return 1;
     c->comm = comm;
     hipError_t e = hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->plan_hint, sizeof(unsigned) * 2 * kHintWords, hipHostMallocDefault);
+    if (e == hipSuccess)
+        for (int i = 0; i < 2 * kHintWords; ++i) c->plan_hint[i] = (i % kHintWords) < kHintWords - 8 ? 0x7f800000u : 0u;  // +inf: nothing known; flags clear
     for (int i = 0; i < 24 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->sev[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         irs_destroy(c);
@@ -814,7 +820,8 @@ int irs_slab_status_get(irs_ctx* c, irs_slab_status* out, void* stream) {
     out->exact_transitions = c->slab_exact;
     out->exchanges = c->slab_exchanges;
     out->exchanged_bytes = c->slab_exchanged_bytes;
-    out->mispredictions = c->hint[kHintWords - 8];
+    // (all enqueued transitions have finished: both slots are final)
+    out->mispredictions = c->slab_mispredictions + c->plan_hint[kHintWords - 8] + c->plan_hint[kHintWords + kHintWords - 8];
     out->last_fwd_rounds = c->last_nf;
     out->last_bwd_rounds = c->last_nb;
     return 0;
@@ -825,13 +832,22 @@ static bool plan_widths(irs_ctx* c, Plan& plan) {
     const int n = c->cfg.no_steps;
     plan.n = n;
     if (!c->have_pred || env_int("IRS_SLAB_EXACT", 0) != 0) return false;
-    const bool fresh = c->n_enqueued >= 2;  // the hint holds the all-reduced bounds of a finished transition
+    // Every rank must arrive at the SAME widths (they size the messages both sides of a link post): the source is the
+    // all-reduced bounds of transition t - 2, which the caller has just waited for (slot t % 2 of the plan hints; the
+    // finalize kernel of t - 1 writes the other slot).  Transition 1 plans from the widths transition 0 measured.
+    const bool fresh = c->n_enqueued >= 2;
+    const unsigned* slot = c->plan_hint + (c->n_enqueued % 2) * kHintWords;
     for (int k = 0; k < n; ++k) {
-        const int hh = fresh ? ghost_width_from_bound(hint_bound(c, k), true) : c->pred[k];
+        const int hh = fresh ? ghost_width_from_bound(hint_bound(c, slot, k), true) : c->pred[k];
         if (hh < 1) return false;
         plan.h[k] = hh;
     }
+    // the launch heuristics (which variants to launch) read the same snapshot
+    if (fresh) memcpy(c->hint, slot, sizeof(unsigned) * 4 * c->C * (n + 1));
     plan.h[0] = 1;  // |d_0| = |v_s| / 2^n voxels (validated like the others)
+    const int forced = env_int("IRS_SLAB_FORCE_H", 0);  // test hook: a deliberately wrong plan (the validation must catch it)
+    if (forced > 0)
+        for (int k = 0; k < n; ++k) plan.h[k] = forced;
     return true;
 }
 
@@ -845,10 +861,17 @@ int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
     const int C = c->C, n = cfg.no_steps;
     const Views v = views(c);
     const irs_io io = shifted_io(c, io_in);
-    if (c->hint[kHintWords - 8]) return fail("irs_slab_transition: an earlier transition ran with ghost zones narrower than its displacement needed (results invalid)");
-    {   // bounded run-ahead, as irs_transition: the width plan below reads bounds at most two transitions old
-        const int depth = env_int("IRS_RUN_AHEAD", 2);
-        if (depth > 0 && depth <= 3 && c->n_enqueued >= (uint64_t)depth) HIP_TRY(hipEventSynchronize(c->ra_ev[(c->n_enqueued - depth) % 4]));
+    // the host runs at most two transitions ahead: the width plan below reads the bounds of transition t - 2, which must have
+    // FINISHED on this rank (not an option here, unlike IRS_RUN_AHEAD of the fused path)
+    if (c->n_enqueued >= 2) {
+        HIP_TRY(hipEventSynchronize(c->ra_ev[(c->n_enqueued - 2) % 4]));
+        // ... and so has its validation: every rank reads the same verdict about the same transition at the same call, so a
+        // misprediction stops ALL ranks here instead of leaving some of them waiting for messages that never come
+        if (c->plan_hint[(c->n_enqueued % 2) * kHintWords + (kHintWords - 8)]) {
+            c->slab_mispredictions += 1;
+            return fail("irs_slab_transition: transition %llu ran with ghost zones narrower than its displacement needed (results invalid from there on)",
+                        (unsigned long long)(c->n_enqueued - 2));
+        }
     }
     Plan plan;
     const bool planned = plan_widths(c, plan);

@@ -105,7 +105,7 @@ def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max, cps=
         cfg, fixed, moving, v0, noise = _setup(N, C, data_loss, vd=vd, amp=amp, reg=reg, with_noise=N < 128, cps=cps)
         eng, v, d, s = _run_slab(cfg, fixed, moving, v0, noise, comm, ghost_max=ghost_max)
         assert (eng.a, eng.b) == ((rank * N) // world, ((rank + 1) * N) // world)
-        assert eng.hi - eng.lo < N  # slab-local arrays
+        assert eng.hi - eng.lo <= N and (eng.hi - eng.lo < N or eng.margin >= min(eng.a, N - eng.b))  # slab-local arrays
         st = eng.status()
         assert st['exchanges'] > 0 and st['mispredictions'] == 0 and st['exact_transitions'] == 1, st
         v_full, d_full = (v.cpu() if cps else eng.gather(v)), eng.gather(d)  # (SVFFD: the control grid is whole on every rank)
@@ -116,9 +116,12 @@ def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max, cps=
             ds = max(abs(a[k][c] - b[k][c]) / max(abs(b[k][c]), 1e-30) for a, b in zip(s, s_ref)
                      for k in ('alpha', 'data_term', 'reg_term') for c in range(C))
             q.put((dv, dd, ds, st))
-    finally:
-        dist.barrier()
-        dist.destroy_process_group()
+    except BaseException:  # leave at once: the peers then fail on their next message instead of waiting for this rank
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _launch(world, *args):
@@ -129,14 +132,17 @@ def _launch(world, *args):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(600)
-        assert p.exitcode == 0
+        p.join(150)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:  # a rank that is still waiting for a peer that died: do not wait with it
+        p.kill()
+    assert not alive and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     return q.get(timeout=10)
 
 
 @pytest.mark.parametrize('data_loss,C,N,world,ghost_max,amp', [
     ('GMM', 1, 32, 2, 4, 9.0), ('SSD', 2, 24, 2, 2, 9.0), ('GMM', 1, 48, 3, 4, 9.0), ('SSD', 1, 40, 2, 1, 9.0),
-    ('GMM', 1, 30, 3, 8, 16.0),   # thin slabs (10 planes) under a displacement of several voxels: late steps are all boundary, no interior
+    ('GMM', 1, 30, 3, 6, 12.0),   # thin slabs (10 planes) under a displacement of several voxels: late steps are all boundary, no interior
 ])
 def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max, amp):
     dv, dd, ds, st = _launch(world, data_loss, C, N, True, amp, 'RegLoss_LogNormal', ghost_max)
@@ -189,3 +195,24 @@ def test_rccl_transport_single_rank():
         comm.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_misprediction_is_reported(monkeypatch):
+    """A plan with ghost zones narrower than the displacement needs (forced here) must not pass silently: the device-side
+    validation flags the transition and a later call returns the error -- at the same call on every rank (the verdict about
+    transition t is read when t + 2 is planned, after t has finished everywhere)."""
+    from ir_sgmcmc_amd._lib import IrsError
+    from ir_sgmcmc_amd.slab import SlabEngine
+    cfg, fixed, moving, v0, noise = _setup(24, 1, 'GMM', amp=20.0, with_noise=False)  # several voxels of displacement
+    eng = SlabEngine(cfg, DEV)
+    fd, md = eng.prepare(fixed, moving)
+    eng.gmm_init(fd, md)
+    v = eng.local_v(v0)
+    eng.transition(fd, md, v)                      # measures: fine
+    monkeypatch.setenv('IRS_SLAB_FORCE_H', '1')    # from now on: plan one plane per step whatever the bounds say
+    eng.transition(fd, md, v)                      # runs with the wrong plan; flagged on the device
+    eng.transition(fd, md, v)
+    with pytest.raises(IrsError, match='narrower than its displacement'):
+        eng.transition(fd, md, v)                  # the verdict about the first wrong transition arrives here
+        eng.transition(fd, md, v)
+    assert eng.status()['mispredictions'] >= 1
