@@ -181,6 +181,7 @@ def main():
                     help='N > 1: ONE chain split into z-slabs with ghost-plane exchange over RCCL (strong scaling, default) or '
                          'independent chains per rank (weak scaling)')
     ap.add_argument('--ghost-max', type=int, default=0, help='slab mode: widest ghost zone of one exchange (0 = library default)')
+    ap.add_argument('--watchdog', type=int, default=420, help='N > 1: seconds after which a run that has not finished dumps its stacks and exits (0 = off)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the `also` workloads (SSD, displaced start, 128^3, sustained run)')
     ap.add_argument('--cpu-size', type=int, default=128)
@@ -189,6 +190,11 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    if args.gpus > 1 and args.watchdog > 0:
+        # a multi-rank run that stops making progress (a transport that hangs instead of failing) must end with a diagnosis,
+        # not sit there until somebody's outer time limit: dump every thread's stack and leave
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True, file=sys.stderr)
 
     import torch
     import torch.distributed as dist
