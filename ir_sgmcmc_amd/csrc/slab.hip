@@ -293,7 +293,10 @@ struct Sched {
     // the exchange is in flight, the boundary strips when the ghost planes have arrived
     void round(bool backward, int xbuf, int w, const int* ks, const int* hs, int m) {
         const int id = exchange(xbuf, w, ks[0]);
-        const bool split = id >= 0;
+        // IRS_SLAB_SPLIT=0 (measurements): no interior / boundary split -- every step one launch after the ghost planes have arrived
+        static const bool want_split = env_int("IRS_SLAB_SPLIT", 1) != 0;
+        const bool split = id >= 0 && want_split;
+        if (id >= 0 && !want_split) wait(id);
         Vol in[kMaxSteps], bd[kMaxSteps];
         int r = 0;
         for (int i = 0; i < m; ++i) {
