@@ -742,9 +742,17 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     const float* d_last = c->steps + (int64_t)(cfg.no_steps - 1) * field;
     if (io->transformation || io->displacement) launch_svf_outputs(d_last, io->transformation, io->displacement, C, vol, lin, st);
 
-    // regulariser energy -> loss terms, coefficients, hyper-parameter step
-    launch_reg_energy(vs, c->energy_partials, C, volv, st);
-    launch_reg_scalar(c->state, c->energy_partials, energy_blocks(volv), c->dcfg, st);
+    // regulariser energy -> loss terms, coefficients, hyper-parameter step.  For the L2 family the coefficient (w / 2) does not
+    // depend on the energy, so the update kernel produces the energy as a by-product of its stencil and the scalar stage runs
+    // after it (same values in, same order of the hyper-parameter step: the update still sees the w of this transition)
+    const int upd_blocks = sgld_update_blocks_per_chain(volv, C);
+    const bool energy_in_update = (cfg.reg_loss == IRS_REG_L2 || cfg.reg_loss == IRS_REG_LOGNORMAL_L2) &&
+                                  (int64_t)upd_blocks * C <= (int64_t)kMaxPartialBlocks * IRS_MAX_CHAINS &&
+                                  env_int("IRS_ENERGY_IN_UPDATE", 1) != 0;
+    if (!energy_in_update) {
+        launch_reg_energy(vs, c->energy_partials, C, volv, st);
+        launch_reg_scalar(c->state, c->energy_partials, energy_blocks(volv), c->dcfg, st);
+    }
 
     // per chain, serially (trainer.py:316-327): VD factor -> GMM step -> data term with the UPDATED mixture
     const int sb = stats_blocks(vol);
@@ -811,10 +819,13 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
         launch_scale_channels(g0, scaled, s[0], s[1], s[2], C, vol, st);
         const int G[3] = {volv.D, volv.H, volv.W};
         ffd_adjoint(scaled, c->tmpB, c->tmpA, C, vol, G, c->spl, st);
-        launch_sgld_update(io->v, io->sigma, c->tmpB, vs, c->state, cfg.lr, 1.0f, 1.0f, 1.0f, io->grad_v, C, volv, st);
+        launch_sgld_update(io->v, io->sigma, c->tmpB, vs, c->state, cfg.lr, 1.0f, 1.0f, 1.0f, io->grad_v, C, volv, st,
+                           energy_in_update ? c->energy_partials : nullptr, energy_in_update);
     } else {
-        launch_sgld_update(io->v, io->sigma, g0, vs, c->state, cfg.lr, s[0], s[1], s[2], io->grad_v, C, volv, st);
+        launch_sgld_update(io->v, io->sigma, g0, vs, c->state, cfg.lr, s[0], s[1], s[2], io->grad_v, C, volv, st,
+                           energy_in_update ? c->energy_partials : nullptr, energy_in_update);
     }
+    if (energy_in_update) launch_reg_scalar(c->state, c->energy_partials, upd_blocks, c->dcfg, st);
     launch_finalize(c->state, c->nll_partials, c->nll_blocks, c->dcfg, true, use_lds_exp() ? c->dmax : nullptr, c->hint,
                     4 * C * (cfg.no_steps + 1), skipped_r2, kHintWords - 7, true, st);
     c->dmax_clean = use_lds_exp();

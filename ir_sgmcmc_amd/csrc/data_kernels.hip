@@ -147,8 +147,9 @@ void launch_reduce_partials(const double* partials, int nblocks, int nvals, doub
 // The Sobolev backward is the identity (straight-through), so nothing else sits between v_s and v.
 // ------------------------------------------------------------------------------------------------
 void launch_sgld_update(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
-                        float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st) {
-    launch_sgld_update_march(v, sigma, g_d0, v_s, dev_state, lr, s0, s1, s2, grad_out, C, vol, st);
+                        float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st,
+                        double* energy_partials, bool coef_from_w) {
+    launch_sgld_update_march(v, sigma, g_d0, v_s, dev_state, lr, s0, s1, s2, grad_out, C, vol, st, energy_partials, coef_from_w);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -94,15 +94,20 @@ void launch_reg_energy(const float* v, double* partials, int C, Vol vol, hipStre
 void launch_reduce_partials(const double* partials, int nblocks, int nvals, double* out, hipStream_t st);
 // out[j] = sum_b partials[b * ncols + j]
 void launch_reduce_cols(const double* partials, int nblocks, int ncols, double* out, hipStream_t st);
+// energy_partials (optional, [C][sgld_update_blocks_per_chain]): regulariser energy of v_s as a by-product; coef_from_w: the
+// regulariser coefficient is w / 2 from the state (L2 family) instead of the one reg_scalar_kernel left in the state
 void launch_sgld_update(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
-                        float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st);
+                        float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st,
+                        double* energy_partials = nullptr, bool coef_from_w = false);
+int sgld_update_blocks_per_chain(Vol vol, int C);
 void launch_gradient_operator(const float* v, float* nabla, int transformation, int C, Vol vol, hipStream_t st);
 void launch_log_det_jacobian(const float* t, float* log_det, long long* nan_count, int C, Vol vol, hipStream_t st);
 void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, int blocks,
                         Vol vol, hipStream_t st);  // stencil_kernels.hip
 void launch_reg_energy_march(const float* v, double* partials, int blocks, int C, Vol vol, hipStream_t st);
 void launch_sgld_update_march(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
-                              float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st);
+                              float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st,
+                              double* energy_partials = nullptr, bool coef_from_w = false);
 int stats_blocks(Vol vol);
 int energy_blocks(Vol vol);
 

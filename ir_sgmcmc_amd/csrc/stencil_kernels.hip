@@ -850,13 +850,20 @@ void launch_reg_energy_march(const float* v, double* partials, int blocks, int C
 // ------------------------------------------------------------------------------------------------
 constexpr int UPX = QTX + 2, UPY = QTY + 2, UPN = UPX * UPY, UNS = 4;
 
+// `energy_partials` (optional, [C][tiles per chain]): the regulariser energy sum (forward difference)^2 of v_s as a by-product -- the
+// stencil above is built from exactly those differences and weights.  Used for the regularisers whose coefficient does not depend
+// on the energy (RegLoss_L2, RegLoss_LogNormal_L2: coef = w / 2, `coef_from_w`), where the energy is only needed AFTER the update
+// (loss term, Adam step on log w): one kernel and one pass over v_s less per transition.
 __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __restrict__ v, const float* __restrict__ sigma,
                                                                      const float* __restrict__ g, const float* __restrict__ v_s,
                                                                      const DevState* __restrict__ state, float lr, float s0,
                                                                      float s1, float s2, float* __restrict__ grad_out, Vol vol,
-                                                                     int seg_len, int nseg, int ntx, int nty) {
+                                                                     int seg_len, int nseg, int ntx, int nty,
+                                                                     double* __restrict__ energy_partials, int coef_from_w) {
     constexpr int NIT = (UPN + kStBlock - 1) / kStBlock;
     __shared__ float F[UNS * 3 * UPN];
+    __shared__ double esm[kStBlock / kWave];
+    double eacc[1] = {0.0};
     const int tile = blockIdx.x;
     const int chain = tile / (ntx * nty * nseg);
     const int t_ = tile % (ntx * nty * nseg);
@@ -868,7 +875,7 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
     const int lx = threadIdx.x % QTX, ly = threadIdx.x / QTX;
     const int x = ox + lx, y = oy + ly;
     const bool col_in = x < vol.W && y < vol.H;
-    const float coef2 = 2.0f * (float)state->coef[chain];
+    const float coef2 = coef_from_w ? (float)exp(state->st.reg_param[0]) : 2.0f * (float)state->coef[chain];  // 2 coef; L2 family: coef = w / 2
     const float sc[3] = {s0, s1, s2};
     // weights of the two difference terms touching a position: w(q) = 2 for the last (replicated) difference q = n - 2
     auto wm = [](int pos, int n) { return pos >= 1 ? (pos - 1 == n - 2 ? 2.0f : 1.0f) : 0.0f; };
@@ -922,12 +929,14 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
             for (int c = 0; c < 3; ++c) {
                 const float* __restrict__ P = F + (s0_ * 3 + c) * UPN;
                 const float v0 = P[ci];
+                const float dxp = P[ci + 1] - v0, dyp = P[ci + UPX] - v0, dzp = F[(sp * 3 + c) * UPN + ci] - v0;  // forward differences
                 float rx = wxm * (v0 - P[ci - 1]);
-                rx -= wxp * (P[ci + 1] - v0);
+                rx -= wxp * dxp;
                 float ry = wym * (v0 - P[ci - UPX]);
-                ry -= wyp * (P[ci + UPX] - v0);
+                ry -= wyp * dyp;
                 float rz = wzm * (v0 - F[(sm * 3 + c) * UPN + ci]);
-                rz -= wzp * (F[(sp * 3 + c) * UPN + ci] - v0);
+                rz -= wzp * dzp;
+                if (energy_partials) eacc[0] += (double)(wxp * dxp * dxp + wyp * dyp * dyp + wzp * dzp * dzp);
                 const float lap = rx + ry + rz;
                 const int64_t base = cb + c * vol.V + pl;
                 const float gr = ldg_off(g + base, own) * sc[c] + coef2 * lap;
@@ -939,16 +948,31 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
             }
         }
     }
+    if (energy_partials) {  // (uniform branch: every thread of the block arrives)
+        block_sum<1>(eacc, esm);
+        if (threadIdx.x == 0) energy_partials[blockIdx.x] = eacc[0];  // blockIdx.x = chain * tiles_per_chain + tile: [C][tiles]
+    }
+}
+
+static int update_seg_len(Vol vol, int C) {
+    static const int seg_env = getenv("IRS_UPDATE_SEG") ? atoi(getenv("IRS_UPDATE_SEG")) : 0;
+    return pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY) * C, 8, seg_env);
+}
+
+int sgld_update_blocks_per_chain(Vol vol, int C) {
+    const int seg_len = update_seg_len(vol, C);
+    return ((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY) * ((vol.nz + seg_len - 1) / seg_len);
 }
 
 void launch_sgld_update_march(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
-                              float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st) {
-    static const int seg_env = getenv("IRS_UPDATE_SEG") ? atoi(getenv("IRS_UPDATE_SEG")) : 0;
-    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY) * C, 8, seg_env);
+                              float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st,
+                              double* energy_partials, bool coef_from_w) {
+    const int seg_len = update_seg_len(vol, C);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + QTY - 1) / QTY;
     hipLaunchKernelGGL(sgld_update_march_kernel, dim3((unsigned)(ntx * nty * nseg * C)), dim3(kStBlock), 0, st, v, sigma, g_d0,
-                       v_s, (const DevState*)dev_state, lr, s0, s1, s2, grad_out, vol, seg_len, nseg, ntx, nty);
+                       v_s, (const DevState*)dev_state, lr, s0, s1, s2, grad_out, vol, seg_len, nseg, ntx, nty, energy_partials,
+                       coef_from_w ? 1 : 0);
 }
 
 }  // namespace irs
