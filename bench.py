@@ -69,17 +69,22 @@ def cpu_baseline(n, reps, loss):
     cores = max(1, min(avail, int(os.environ.get('IRS_CPU_THREADS', '16'))))  # a 1-GPU box owns a 16-core share
     torch.set_num_threads(cores)
     print(f'[bench] cpu baseline: oracle at {n}^3 on {cores} threads ...', file=sys.stderr, flush=True)
-    dims = (n,) * 3
-    cfg = OracleConfig(dims=dims, data_loss='GMM' if loss == 'gmm' else 'SSD', virtual_decimation=(loss == 'gmm'))
-    f1, m1 = synthetic_pair(dims, seed=0)
-    fixed = {k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'}
-    moving = {k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'}
-    ch = OracleChain(cfg)
-    ch.init_gmm(fixed, moving)
-    g = torch.Generator().manual_seed(0)
-    eps = torch.randn(1, 3, *dims, generator=g)
-    unif = torch.rand(1, 3, *dims, generator=g)
-    ch.transition(fixed, moving, eps, unif)  # warm-up (thread pool, allocator)
+    def setup(m):
+        dims = (m,) * 3
+        cfg = OracleConfig(dims=dims, data_loss='GMM' if loss == 'gmm' else 'SSD', virtual_decimation=(loss == 'gmm'))
+        f1, m1 = synthetic_pair(dims, seed=0)
+        fixed = {k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'}
+        moving = {k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'}
+        ch = OracleChain(cfg)
+        ch.init_gmm(fixed, moving)
+        g = torch.Generator().manual_seed(0)
+        return ch, fixed, moving, torch.randn(1, 3, *dims, generator=g), torch.rand(1, 3, *dims, generator=g)
+
+    # warm-up (thread pool, allocator): at the measured size when that is cheap, else at 64^3
+    ch, fixed, moving, eps, unif = setup(n if n <= 128 else 64)
+    ch.transition(fixed, moving, eps, unif)
+    if n > 128:
+        ch, fixed, moving, eps, unif = setup(n)
     t0 = time.perf_counter()
     for i in range(reps):
         ch.transition(fixed, moving, eps, unif)
@@ -184,8 +189,8 @@ def main():
     ap.add_argument('--watchdog', type=int, default=420, help='N > 1: seconds after which a run that has not finished dumps its stacks and exits (0 = off)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the `also` workloads (SSD, displaced start, 128^3, sustained run)')
-    ap.add_argument('--cpu-size', type=int, default=128)
-    ap.add_argument('--cpu-reps', type=int, default=2)
+    ap.add_argument('--cpu-size', type=int, default=256, help='edge of the CPU-baseline volume (capped at --size); 256: one transition takes ~25 s on 16 cores')
+    ap.add_argument('--cpu-reps', type=int, default=1)
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -396,7 +401,7 @@ def main():
             dt, cores = cpu_baseline(n_cpu, args.cpu_reps, args.loss)
             scale = (N / n_cpu) ** 3
             out['cpu_baseline'] = {'value': 1.0 / (dt * scale), 'unit': 'transitions/s', 'cores': cores, 'kind': 'port',
-                                   'sample': f'{args.cpu_reps} transitions of the torch-CPU oracle at {n_cpu}^3 '
+                                   'sample': f'{args.cpu_reps} transition(s) of the torch-CPU oracle at {n_cpu}^3 '
                                              f'({dt:.2f} s each, {cores} threads)' + (f', scaled by voxel count x{scale:.0f} to {N}^3' if scale != 1 else '')}
         print(json.dumps(out), flush=True)
     if world > 1:
