@@ -11,18 +11,24 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o k -- python3 "$REPO/tools/slab_probe.py" --size "$N" --worlds "$W" --steps 30 > "$OUT/probe.log" 2>&1
 cd "$REPO"
 python3 - "$OUT" <<'PY'
-import csv, glob, sys, json
+import csv, glob, sys, json, collections
 out = sys.argv[1]
 f = glob.glob(out + '/trace/**/k_kernel_trace.csv', recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
-rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# the probe runs the fused engine first (5 + 30 transitions), then the slab rank (5 + 30): split at the largest gap
-ts = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows]
-gaps = sorted(((ts[i + 1][0] - ts[i][1], i) for i in range(len(ts) - 1)), reverse=True)
-cut = gaps[0][1] + 1
-for name, part in (('first_phase', ts[:cut]), ('second_phase', ts[cut:])):
+ts = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f)))
+# the probe runs the fused engine first, then the slab rank (whose transitions carry validate_widths_kernel); every
+# transition ends with finalize_kernel
+fin = [i for i, t in enumerate(ts) if 'finalize_kernel' in t[2]]
+first_slab = next(i for i, t in enumerate(ts) if 'validate_widths' in t[2])
+def last(fins, n):
+    part = ts[fins[-n - 1] + 1:fins[-1] + 1]
     busy = sum(e - s for s, e, _ in part)
-    span = part[-1][1] - part[0][0]
-    print(json.dumps({'phase': name, 'kernels': len(part), 'busy_ms': busy / 1e6, 'span_ms': span / 1e6, 'busy_frac': busy / span}))
+    return part, {'kernels_per_transition': len(part) / n, 'busy_ms': busy / n / 1e6, 'span_ms': (part[-1][1] - part[0][0]) / n / 1e6}
+n = 20
+_, fused = last([i for i in fin if i < first_slab], n)
+part, slab = last([i for i in fin if i > first_slab], n)
+per = collections.Counter()
+for s, e, name in part:
+    per[name.split('(')[0].replace('void irs::', '').replace('irs::', '')] += (e - s) / n / 1e3
+print(json.dumps({'fused': fused, 'slab_rank': slab, 'slab_rank_us_by_kernel': {k: round(v, 1) for k, v in per.most_common(16)}}))
 PY
 tail -n 3 "$OUT/probe.log"
