@@ -137,6 +137,23 @@ __device__ __forceinline__ int xcd_swizzle_runs(int id, int total, int run) {
     return g * group + (w & 7) * run + (w >> 3);
 }
 
+// The stencil kernels' 3-D grids (tile x, tile y, segment): the dispatcher walks them x fastest and deals the workgroups round-
+// robin over the XCDs, so x-adjacent tiles -- which share the cache lines their halo columns straddle -- meet in eight different
+// L2s.  Logical block after the remap: IRS_SWZ_STENCIL_ROWS x-rows of tiles form one run on one XCD (0: no remap).
+#ifndef IRS_SWZ_STENCIL_ROWS
+#define IRS_SWZ_STENCIL_ROWS 1
+#endif
+struct Blk3 {
+    int x, y, z;
+};
+__device__ __forceinline__ Blk3 swizzled_block() {
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+    const int id = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);
+    const int t = xcd_swizzle_runs(id, gx * gy * (int)gridDim.z, gx * IRS_SWZ_STENCIL_ROWS);
+    const int q = t / gx;
+    return {t - q * gx, q % gy, q / gy};
+}
+
 // identity-grid tables: linspace(-1, 1, n) per axis as torch's CPU kernel computes it
 // (utils/util.py:263-278).  x <-> W, y <-> H, z <-> D.
 struct Lin {

@@ -50,8 +50,9 @@ __global__ __launch_bounds__(kStBlock) void sobolev_march_kernel(const float* __
     __shared__ float P2[NY];  // then y-filtered, tile rows only
     __shared__ float red[kStBlock / kWave];
 
-    const int plane = blockIdx.z / nseg, seg = blockIdx.z % nseg;
-    const int ox = blockIdx.x * SMX, oy = blockIdx.y * SMY;
+    const Blk3 blk = swizzled_block();
+    const int plane = blk.z / nseg, seg = blk.z % nseg;
+    const int ox = blk.x * SMX, oy = blk.y * SMY;
     const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
     const float* __restrict__ src = in + (int64_t)plane * vol.V;
     float* __restrict__ dst = out + (int64_t)plane * vol.V;
@@ -214,8 +215,9 @@ __global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __
     __shared__ float LA[AN];
     __shared__ float LW[NS * BN];
 
-    const int chain = blockIdx.z / nseg, seg = blockIdx.z % nseg;
-    const int ox = blockIdx.x * LMX, oy = blockIdx.y * LMY;
+    const Blk3 blk = swizzled_block();
+    const int chain = blk.z / nseg, seg = blk.z % nseg;
+    const int ox = blk.x * LMX, oy = blk.y * LMY;
     const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
     const int64_t HW = (int64_t)vol.H * vol.W;
     const float* __restrict__ src = im + (int64_t)chain * vol.V;
@@ -432,8 +434,9 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
     __shared__ float LG[NS2 * BN];
     __shared__ double red[kStBlock / kWave];
 
-    const int seg = blockIdx.z;
-    const int ox = blockIdx.x * LMX, oy = blockIdx.y * LMY;
+    const Blk3 blk = swizzled_block();
+    const int seg = blk.z;
+    const int ox = blk.x * LMX, oy = blk.y * LMY;
     const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
     const int64_t HW = (int64_t)vol.H * vol.W;
     const float n = (float)(NT * NT * NT);
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
         if (threadIdx.x == 0) {
             double t = 0.0;
             for (int w = 0; w < kStBlock / kWave; ++w) t += red[w];
-            nll_out[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+            nll_out[(blk.z * gridDim.y + blk.y) * gridDim.x + blk.x] = t;  // slot of the logical tile: same partial layout as unswizzled
         }
     }
 }
@@ -662,7 +665,8 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
     const int K = state->K;
     const bool gmm = state->mode == IRS_DATA_GMM_LCC;
     const int total = ntx * nty * nseg;
-    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    for (int tile_ = blockIdx.x; tile_ < total; tile_ += gridDim.x) {
+        const int tile = xcd_swizzle_runs(tile_, total, ntx * IRS_SWZ_STENCIL_ROWS);  // x-neighbouring tiles on one XCD
         const int ox = (tile % ntx) * QTX, oy = ((tile / ntx) % nty) * TTY, seg = tile / (ntx * nty);
         const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
         unsigned off[NIT];
@@ -771,7 +775,8 @@ __global__ __launch_bounds__(kStBlock) void reg_energy_march_kernel(const float*
     const int lx = threadIdx.x % QTX, ly = threadIdx.x / QTX;
     double acc[1] = {0.0};
     const int total = ntx * nty * nseg;
-    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    for (int tile_ = blockIdx.x; tile_ < total; tile_ += gridDim.x) {
+        const int tile = xcd_swizzle_runs(tile_, total, ntx * IRS_SWZ_STENCIL_ROWS);
         const int ox = (tile % ntx) * QTX, oy = ((tile / ntx) % nty) * QTY, seg = tile / (ntx * nty);
         const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
         const int x = ox + lx, y = oy + ly;
@@ -864,7 +869,7 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
     __shared__ float F[UNS * 3 * UPN];
     __shared__ double esm[kStBlock / kWave];
     double eacc[1] = {0.0};
-    const int tile = blockIdx.x;
+    const int tile = xcd_swizzle_runs((int)blockIdx.x, (int)gridDim.x, ntx * IRS_SWZ_STENCIL_ROWS);  // x-neighbouring tiles on one XCD
     const int chain = tile / (ntx * nty * nseg);
     const int t_ = tile % (ntx * nty * nseg);
     const int ox = (t_ % ntx) * QTX, oy = ((t_ / ntx) % nty) * QTY, seg = t_ / (ntx * nty);
@@ -950,7 +955,7 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
     }
     if (energy_partials) {  // (uniform branch: every thread of the block arrives)
         block_sum<1>(eacc, esm);
-        if (threadIdx.x == 0) energy_partials[blockIdx.x] = eacc[0];  // blockIdx.x = chain * tiles_per_chain + tile: [C][tiles]
+        if (threadIdx.x == 0) energy_partials[tile] = eacc[0];  // tile = chain * tiles_per_chain + tile in chain: [C][tiles]
     }
 }
 
