@@ -21,7 +21,7 @@ DEV = 'cuda:0'
 T = 3  # transitions: the first measures the ghost widths (exact mode), the second and third run from predicted widths
 
 
-def _setup(N, C, data_loss, seed=0, vd=True, amp=9.0, reg='RegLoss_LogNormal', with_noise=True, cps=None):
+def _setup(N, C, data_loss, seed=0, vd=True, amp=9.0, reg='RegLoss_LogNormal', with_noise=True, cps=None, transitions=T):
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from ir_sgmcmc_amd.engine import EngineConfig
     from oracle import ops as O
@@ -35,7 +35,7 @@ def _setup(N, C, data_loss, seed=0, vd=True, amp=9.0, reg='RegLoss_LogNormal', w
     v0 = O.separable_conv3d_replicate(amp * torch.randn(C, 3, *dv, generator=g), O.sobolev_kernel_1d(3, 0.5)).contiguous()
     # without injected noise every rank draws the in-kernel Philox noise of ITS planes of the same field
     noise = [(torch.randn(C, 3, *dv, generator=g), torch.rand(C, 3, N, N, N, generator=g)) if with_noise else (None, None)
-             for _ in range(T)]
+             for _ in range(transitions)]
     return cfg, fixed, moving, v0, noise
 
 
@@ -94,7 +94,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max, cps=None):
+def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max, cps=None, transitions=T):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -102,7 +102,7 @@ def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max, cps=
         torch.cuda.set_device(0)
         comm = SlabComm.rehearsal(DEV)
         comm.selftest()
-        cfg, fixed, moving, v0, noise = _setup(N, C, data_loss, vd=vd, amp=amp, reg=reg, with_noise=N < 128, cps=cps)
+        cfg, fixed, moving, v0, noise = _setup(N, C, data_loss, vd=vd, amp=amp, reg=reg, with_noise=N < 128, cps=cps, transitions=transitions)
         eng, v, d, s = _run_slab(cfg, fixed, moving, v0, noise, comm, ghost_max=ghost_max)
         assert (eng.a, eng.b) == ((rank * N) // world, ((rank + 1) * N) // world)
         assert eng.hi - eng.lo <= N and (eng.hi - eng.lo < N or eng.margin >= min(eng.a, N - eng.b))  # slab-local arrays
@@ -153,6 +153,18 @@ def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max, amp
     check(name, 'loss terms (rel)', ds, 0.0, 1e-6)
     # communication-avoiding rounds: 12 squaring steps in fewer forward exchanges than steps
     assert st['last_fwd_rounds'] < 12 or ghost_max == 1, st
+
+
+def test_slab_long_run_replans_every_transition():
+    """40 consecutive transitions on two ranks: after the first (measuring) transition every plan comes from the bounds of
+    two transitions earlier, while the field keeps moving (lr 0.4, Langevin noise on); no misprediction, no second exact
+    transition, and the chain stays on the fused engine's trajectory."""
+    dv, dd, ds, st = _launch(2, 'GMM', 1, 32, True, 4.0, 'RegLoss_LogNormal', 4, None, 40)
+    from tests._report import check
+    name = 'slab/GMM_C1_N32_ranks2_g4_40_transitions'
+    check(name, 'v_new (rel to max)', dv, 0.0, 1e-4)
+    check(name, 'displacement [voxels]', dd, 0.0, 1e-4)
+    check(name, 'loss terms (rel)', ds, 0.0, 1e-5)
 
 
 @pytest.mark.parametrize('data_loss,C,N,world,cps', [('GMM', 1, 32, 2, (4, 4, 4)), ('SSD', 2, 36, 3, (2, 2, 2))])
