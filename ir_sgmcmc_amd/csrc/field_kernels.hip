@@ -247,8 +247,38 @@ __global__ __launch_bounds__(kBlock) void svf_outputs_kernel(const float* __rest
     }
 }
 
+// four x-consecutive voxels per thread (one 16-byte access per stream and lane): W % 4 == 0, 16-byte aligned bases
+__global__ __launch_bounds__(kBlock) void svf_outputs_x4_kernel(const float* __restrict__ d, float* __restrict__ transf,
+                                                                float* __restrict__ disp, Vol vol, Lin lin, Scale3 sc) {
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int chain = blockIdx.z / vol.nz, z = vol.z0 + blockIdx.z - chain * vol.nz;
+    if (x >= vol.W || y >= vol.H) return;
+    const int64_t vox = ((int64_t)z * vol.H + y) * vol.W + x, cb = (int64_t)chain * 3 * vol.V;
+    const float4 lx = *reinterpret_cast<const float4*>(lin.x + x);
+    const float ly = lin.y[y], lz = lin.z[z];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float4 dv = *reinterpret_cast<const float4*>(d + cb + c * vol.V + vox);
+        const float4 id = c == 0 ? lx : make_float4(c == 1 ? ly : lz, c == 1 ? ly : lz, c == 1 ? ly : lz, c == 1 ? ly : lz);
+        if (transf)
+            *reinterpret_cast<float4*>(transf + cb + c * vol.V + vox) =
+                make_float4(__fadd_rn(id.x, dv.x), __fadd_rn(id.y, dv.y), __fadd_rn(id.z, dv.z), __fadd_rn(id.w, dv.w));
+        if (disp)
+            *reinterpret_cast<float4*>(disp + cb + c * vol.V + vox) =
+                make_float4(__fmul_rn(__fmul_rn(dv.x, sc.nm1[c]), 0.5f), __fmul_rn(__fmul_rn(dv.y, sc.nm1[c]), 0.5f),
+                            __fmul_rn(__fmul_rn(dv.z, sc.nm1[c]), 0.5f), __fmul_rn(__fmul_rn(dv.w, sc.nm1[c]), 0.5f));
+    }
+}
+
 void launch_svf_outputs(const float* d, float* transformation, float* displacement, int C, Vol vol, Lin lin,
                         hipStream_t st) {
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    if (vol.W % 4 == 0 && vol.W >= 128 && al16(d) && al16(transformation) && al16(displacement) && al16(lin.x)) {
+        const dim3 g4((unsigned)((vol.W / 4 + 63) / 64), (unsigned)((vol.H + 3) / 4), (unsigned)(vol.nz * C));
+        hipLaunchKernelGGL(svf_outputs_x4_kernel, g4, dim3(kBlock), 0, st, d, transformation, displacement, vol, lin,
+                           make_scale(vol, 0));
+        return;
+    }
     const dim3 grid = vox_grid(vol, C);
     hipLaunchKernelGGL(svf_outputs_kernel, grid, dim3(kBlock), 0, st, d, transformation, displacement, vol, lin,
                        make_scale(vol, 0));
