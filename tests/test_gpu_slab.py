@@ -188,6 +188,16 @@ def test_config4_256_cubed_ssd_two_slabs():
     check('slab/config4_256_ssd_ranks2', 'loss terms (rel)', ds, 0.0, 1e-6)
 
 
+def test_bench_workload_256_cubed_gmm_four_slabs():
+    """The workload bench.py times (256^3, GMM / LCC with virtual decimation, RegLoss_L2, in-kernel noise) as one chain in FOUR
+    z-slabs of 64 planes (middle ranks with two neighbours, ghost exchanges in both directions) vs the fused engine."""
+    dv, dd, ds, st = _launch(4, 'GMM', 1, 256, True, 3.0, 'RegLoss_L2', 4)
+    from tests._report import check
+    check('slab/bench_256_gmm_ranks4', 'v_new (rel to max)', dv, 0.0, 1e-5)
+    check('slab/bench_256_gmm_ranks4', 'displacement [voxels]', dd, 0.0, 2e-5)
+    check('slab/bench_256_gmm_ranks4', 'loss terms (rel)', ds, 0.0, 1e-6)
+
+
 def test_rccl_transport_single_rank():
     """the RCCL leaf: librccl is bound at run time, a one-rank communicator initialises on this device and carries the
     all-reduces of a slab transition (two ranks on one device are refused by RCCL, so the multi-rank exchanges run on a node)"""
