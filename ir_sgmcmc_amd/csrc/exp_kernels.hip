@@ -973,6 +973,21 @@ struct MarchF {
     static constexpr int PITCH = (IRS_FWD_PITCH_ALIGN > 1 && R == 1) ? (PX + IRS_FWD_PITCH_ALIGN - 1) / IRS_FWD_PITCH_ALIGN * IRS_FWD_PITCH_ALIGN : PX;  // the radius-2 ring stays below 64 KB
     static constexpr int PNP = PITCH * PY;
 };
+#ifdef IRS_FWD_TRACE
+// timing experiment (tools/fwd_phase_trace.py; build with tools/build_variant.sh trace -DIRS_FWD_TRACE): clock64 stamps of ONE
+// wave of one workgroup at six points of the marching loop.  The stamps serialise the wave's LDS / scalar-memory queue, so the
+// build is for reading proportions, not for timing the kernel.
+__device__ unsigned long long g_fwd_trace[8 * 64];
+extern "C" int irs_debug_fwd_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_trace), sizeof(g_fwd_trace)) == hipSuccess ? 0 : 1;
+}
+#define IRS_TR(slot)                                                                           \
+    do {                                                                                       \
+        if (trace_on && trace_it < 64) g_fwd_trace[trace_it * 8 + (slot)] = clock64();         \
+    } while (0)
+#else
+#define IRS_TR(slot)
+#endif
 template <bool PRESCALE, int R>
 __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din, float* __restrict__ dout, const Vol vol,
                                                    const Lin lin, const Scale3L sc, const unsigned* __restrict__ dmax_in,
@@ -1054,15 +1069,27 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
 
     float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
     const int sbase = z0 - R, slast = z1 - 1 + R;
+#ifdef IRS_FWD_TRACE
+    const bool trace_on = R == 1 && !PRESCALE && tile_id == (int)(tiles.x * tiles.y * tiles.z) / 2 + 3 && threadIdx.x == 64;
+    int trace_it = 0;
+#endif
     prefetch(sbase);
     for (int sb = sbase; sb <= slast; sb += NS) {
 #pragma unroll
         for (int PH = 0; PH < NS; ++PH) {
             const int s = sb + PH;
             if (s > slast) break;
+#ifdef IRS_FWD_TRACE
+            IRS_TR(0);
+            __builtin_amdgcn_s_waitcnt(0);  // the loads of plane s have arrived
+            IRS_TR(1);
+#endif
             commit(PH);
+            IRS_TR(2);
             if (s + 1 <= slast) prefetch(s + 1);
+            IRS_TR(3);
             __syncthreads();
+            IRS_TR(4);
             const int zo = s - R;
             if (zo >= z0 && zo < z1) {
                 const float linz = lin.z[zo];
@@ -1138,6 +1165,10 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                 m2 = fmaxf(m2, fabsf(r2));
                 }
             }
+#ifdef IRS_FWD_TRACE
+            IRS_TR(5);
+            ++trace_it;
+#endif
         }
     }
     if (dmax_out) {
