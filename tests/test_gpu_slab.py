@@ -25,16 +25,17 @@ def _setup(N, C, data_loss, seed=0, vd=True, amp=9.0, reg='RegLoss_LogNormal', w
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from ir_sgmcmc_amd.engine import EngineConfig
     from oracle import ops as O
-    cfg = EngineConfig(dims=(N, N, N), no_chains=C, data_loss=data_loss, virtual_decimation=vd, lcc_s=1,
+    dims = (N, N, N) if isinstance(N, int) else tuple(N)  # (D, H, W): the slabs cut D
+    cfg = EngineConfig(dims=dims, no_chains=C, data_loss=data_loss, virtual_decimation=vd, lcc_s=1,
                        reg_loss=reg, reg_learnable=(reg == 'RegLoss_LogNormal'), seed=seed, cps=cps, lr=0.01 if cps else 0.4)
-    f1, m1 = synthetic_pair((N, N, N), seed=3)
+    f1, m1 = synthetic_pair(dims, seed=3)
     fixed = {k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'}
     moving = {k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'}
     g = torch.Generator().manual_seed(17)
     dv = cfg.dims_v  # the control grid for SVFFD_3D, the image grid otherwise
     v0 = O.separable_conv3d_replicate(amp * torch.randn(C, 3, *dv, generator=g), O.sobolev_kernel_1d(3, 0.5)).contiguous()
     # without injected noise every rank draws the in-kernel Philox noise of ITS planes of the same field
-    noise = [(torch.randn(C, 3, *dv, generator=g), torch.rand(C, 3, N, N, N, generator=g)) if with_noise else (None, None)
+    noise = [(torch.randn(C, 3, *dv, generator=g), torch.rand(C, 3, *dims, generator=g)) if with_noise else (None, None)
              for _ in range(transitions)]
     return cfg, fixed, moving, v0, noise
 
@@ -102,10 +103,11 @@ def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max, cps=
         torch.cuda.set_device(0)
         comm = SlabComm.rehearsal(DEV)
         comm.selftest()
-        cfg, fixed, moving, v0, noise = _setup(N, C, data_loss, vd=vd, amp=amp, reg=reg, with_noise=N < 128, cps=cps, transitions=transitions)
+        D = N if isinstance(N, int) else N[0]
+        cfg, fixed, moving, v0, noise = _setup(N, C, data_loss, vd=vd, amp=amp, reg=reg, with_noise=D < 128, cps=cps, transitions=transitions)
         eng, v, d, s = _run_slab(cfg, fixed, moving, v0, noise, comm, ghost_max=ghost_max)
-        assert (eng.a, eng.b) == ((rank * N) // world, ((rank + 1) * N) // world)
-        assert eng.hi - eng.lo <= N and (eng.hi - eng.lo < N or eng.margin >= min(eng.a, N - eng.b))  # slab-local arrays
+        assert (eng.a, eng.b) == ((rank * D) // world, ((rank + 1) * D) // world)
+        assert eng.hi - eng.lo <= D and (eng.hi - eng.lo < D or eng.margin >= min(eng.a, D - eng.b))  # slab-local arrays
         st = eng.status()
         assert st['exchanges'] > 0 and st['mispredictions'] == 0 and st['exact_transitions'] == 1, st
         v_full, d_full = (v.cpu() if cps else eng.gather(v)), eng.gather(d)  # (SVFFD: the control grid is whole on every rank)
@@ -143,11 +145,12 @@ def _launch(world, *args):
 @pytest.mark.parametrize('data_loss,C,N,world,ghost_max,amp', [
     ('GMM', 1, 32, 2, 4, 9.0), ('SSD', 2, 24, 2, 2, 9.0), ('GMM', 1, 48, 3, 4, 9.0), ('SSD', 1, 40, 2, 1, 9.0),
     ('GMM', 1, 30, 3, 6, 12.0),   # thin slabs (10 planes) under a displacement of several voxels: late steps are all boundary, no interior
+    ('GMM', 1, (38, 21, 45), 2, 4, 9.0),   # D != H != W, none a multiple of a tile edge: ragged tiles inside slab windows
 ])
 def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max, amp):
     dv, dd, ds, st = _launch(world, data_loss, C, N, True, amp, 'RegLoss_LogNormal', ghost_max)
     from tests._report import check
-    name = f'slab/{data_loss}_C{C}_N{N}_ranks{world}_g{ghost_max}_amp{amp:g}'
+    name = f'slab/{data_loss}_C{C}_N{N if isinstance(N, int) else "x".join(map(str, N))}_ranks{world}_g{ghost_max}_amp{amp:g}'
     check(name, 'v_new (rel to max)', dv, 0.0, 1e-5)
     check(name, 'displacement [voxels]', dd, 0.0, 1e-5)
     check(name, 'loss terms (rel)', ds, 0.0, 1e-6)

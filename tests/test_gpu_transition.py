@@ -108,25 +108,29 @@ def test_transition_matches_reference_fixture(name):
             v.copy_(ref('v_new').to(DEV))
 
 
-@pytest.mark.parametrize('variant', ['ssd_l2', 'ssd_vd_lognormal', 'gmm_nosobolev_c3', 'steps1', 'steps2', 'steps5_c2'])
+@pytest.mark.parametrize('variant', ['ssd_l2', 'ssd_vd_lognormal', 'gmm_nosobolev_c3', 'steps1', 'steps2', 'steps5_c2',
+                                     'noncubic_gmm', 'noncubic_ssd_c2'])
 def test_transition_matches_oracle_builder_variants(variant):
-    """Configurations without a reference counterpart (SSD is builder-defined) or not covered by a fixture."""
+    """Configurations without a reference counterpart (SSD is builder-defined) or not covered by a fixture; the non-cubic ones
+    (D != H != W, none a multiple of a tile edge) put ragged tiles and segments under every kernel of the composition."""
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     N = 20
+    dims = {'noncubic_gmm': (18, 26, 34), 'noncubic_ssd_c2': (33, 20, 17)}.get(variant, (N, N, N))
     kw = dict(ssd_l2=dict(data_loss='SSD', virtual_decimation=False, ssd_sigma=0.05),
               ssd_vd_lognormal=dict(data_loss='SSD', virtual_decimation=True, reg_loss='RegLoss_LogNormal',
                                     reg_learnable=True, no_chains=2),
               gmm_nosobolev_c3=dict(no_chains=3, sobolev_s=None, uniform_noise=None, lcc_s=2, lr=0.02),
               # few squaring steps: the first / last / only step of the chain has its own field layouts in the fused path
-              steps1=dict(no_steps=1, lr=0.05), steps2=dict(no_steps=2, lr=0.05), steps5_c2=dict(no_steps=5, no_chains=2, lr=0.05))[variant]
-    oc = OracleConfig(dims=(N, N, N), **kw)
+              steps1=dict(no_steps=1, lr=0.05), steps2=dict(no_steps=2, lr=0.05), steps5_c2=dict(no_steps=5, no_chains=2, lr=0.05),
+              noncubic_gmm=dict(), noncubic_ssd_c2=dict(data_loss='SSD', virtual_decimation=True, no_chains=2))[variant]
+    oc = OracleConfig(dims=dims, **kw)
     C = oc.no_chains
-    f1, m1 = synthetic_pair((N, N, N), seed=3)
+    f1, m1 = synthetic_pair(dims, seed=3)
     fixed = {k: v.unsqueeze(0).expand(C, *v.shape).contiguous() for k, v in f1.items() if k != 'seg'}
     moving = {k: v.unsqueeze(0).expand(C, *v.shape).contiguous() for k, v in m1.items() if k != 'seg'}
     gen = torch.Generator().manual_seed(11)
     from oracle import ops as O
-    v0 = O.separable_conv3d_replicate(6.0 * torch.randn(C, 3, N, N, N, generator=gen), O.sobolev_kernel_1d(2, 0.5)).contiguous()
+    v0 = O.separable_conv3d_replicate(6.0 * torch.randn(C, 3, *dims, generator=gen), O.sobolev_kernel_1d(2, 0.5)).contiguous()
     orc = OracleChain(oc, v0=v0)
     orc.init_gmm(fixed, moving)
 
@@ -140,8 +144,8 @@ def test_transition_matches_oracle_builder_variants(variant):
     v = v0.to(DEV).contiguous()
     out = outputs_for(cfg)
     for it in range(3):
-        eps = torch.randn(C, 3, N, N, N, generator=gen)
-        unif = torch.rand(C, 3, N, N, N, generator=gen) if oc.uniform_noise is not None else None
+        eps = torch.randn(C, 3, *dims, generator=gen)
+        unif = torch.rand(C, 3, *dims, generator=gen) if oc.uniform_noise is not None else None
         o = orc.transition(fixed, moving, eps, unif)
         eng.transition(fixed_d, moving_d, v, None, eps.to(DEV), unif.to(DEV) if unif is not None else None, out)
         sc = eng.scalars()
