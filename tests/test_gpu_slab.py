@@ -146,6 +146,7 @@ def _launch(world, *args):
     ('GMM', 1, 32, 2, 4, 9.0), ('SSD', 2, 24, 2, 2, 9.0), ('GMM', 1, 48, 3, 4, 9.0), ('SSD', 1, 40, 2, 1, 9.0),
     ('GMM', 1, 30, 3, 6, 12.0),   # thin slabs (10 planes) under a displacement of several voxels: late steps are all boundary, no interior
     ('GMM', 1, (38, 21, 45), 2, 4, 9.0),   # D != H != W, none a multiple of a tile edge: ragged tiles inside slab windows
+    ('GMM', 2, 28, 2, 4, 9.0),             # two chains: the mixture's statistics are all-reduced and stepped per chain, serially
 ])
 def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max, amp):
     dv, dd, ds, st = _launch(world, data_loss, C, N, True, amp, 'RegLoss_LogNormal', ghost_max)

@@ -109,20 +109,22 @@ def test_transition_matches_reference_fixture(name):
 
 
 @pytest.mark.parametrize('variant', ['ssd_l2', 'ssd_vd_lognormal', 'gmm_nosobolev_c3', 'steps1', 'steps2', 'steps5_c2',
-                                     'noncubic_gmm', 'noncubic_ssd_c2'])
+                                     'noncubic_gmm', 'noncubic_ssd_c2', 'tiny_gmm'])
 def test_transition_matches_oracle_builder_variants(variant):
     """Configurations without a reference counterpart (SSD is builder-defined) or not covered by a fixture; the non-cubic ones
     (D != H != W, none a multiple of a tile edge) put ragged tiles and segments under every kernel of the composition."""
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     N = 20
-    dims = {'noncubic_gmm': (18, 26, 34), 'noncubic_ssd_c2': (33, 20, 17)}.get(variant, (N, N, N))
+    # tiny_gmm: a volume smaller than any tile or marching segment
+    dims = {'noncubic_gmm': (18, 26, 34), 'noncubic_ssd_c2': (33, 20, 17), 'tiny_gmm': (8, 9, 10)}.get(variant, (N, N, N))
     kw = dict(ssd_l2=dict(data_loss='SSD', virtual_decimation=False, ssd_sigma=0.05),
               ssd_vd_lognormal=dict(data_loss='SSD', virtual_decimation=True, reg_loss='RegLoss_LogNormal',
                                     reg_learnable=True, no_chains=2),
               gmm_nosobolev_c3=dict(no_chains=3, sobolev_s=None, uniform_noise=None, lcc_s=2, lr=0.02),
               # few squaring steps: the first / last / only step of the chain has its own field layouts in the fused path
               steps1=dict(no_steps=1, lr=0.05), steps2=dict(no_steps=2, lr=0.05), steps5_c2=dict(no_steps=5, no_chains=2, lr=0.05),
-              noncubic_gmm=dict(), noncubic_ssd_c2=dict(data_loss='SSD', virtual_decimation=True, no_chains=2))[variant]
+              noncubic_gmm=dict(), noncubic_ssd_c2=dict(data_loss='SSD', virtual_decimation=True, no_chains=2),
+              tiny_gmm=dict(lr=0.05))[variant]
     oc = OracleConfig(dims=dims, **kw)
     C = oc.no_chains
     f1, m1 = synthetic_pair(dims, seed=3)
@@ -130,7 +132,8 @@ def test_transition_matches_oracle_builder_variants(variant):
     moving = {k: v.unsqueeze(0).expand(C, *v.shape).contiguous() for k, v in m1.items() if k != 'seg'}
     gen = torch.Generator().manual_seed(11)
     from oracle import ops as O
-    v0 = O.separable_conv3d_replicate(6.0 * torch.randn(C, 3, *dims, generator=gen), O.sobolev_kernel_1d(2, 0.5)).contiguous()
+    amp = 1.5 if variant == 'tiny_gmm' else 6.0  # (6 voxels would fold an 8-voxel volume several times over)
+    v0 = O.separable_conv3d_replicate(amp * torch.randn(C, 3, *dims, generator=gen), O.sobolev_kernel_1d(2, 0.5)).contiguous()
     orc = OracleChain(oc, v0=v0)
     orc.init_gmm(fixed, moving)
 
