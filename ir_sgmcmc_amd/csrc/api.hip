@@ -697,10 +697,10 @@ int irs_gmm_init(irs_ctx* c, const irs_io* io, const float* v_sample, int warm_u
     if (forward_pass(c, io, c->tmpB, false, false, c->vs, c->warped, c->z, nullptr, 1, st, 0)) return 1;
     launch_masked_moments(c->z, io->mask, c->stat_partials, c->vol, st);
     launch_gmm_init_from_moments(c->state, c->stat_partials, stats_blocks(c->vol), c->dcfg, st);
-    launch_stats(c->cfg.virtual_decimation, c->z, io->mask, c->state, c->stat_partials, c->vol, st);
+    launch_stats(c->cfg.virtual_decimation, c->z, io->mask, c->state, c->stat_partials, c->vol, st, c->dcfg.K);
     launch_chain_scalar(c->state, c->stat_partials, stats_blocks(c->vol), 0, 1, c->dcfg, st);  // alpha, fixed below
     for (int i = 0; i < warm_up; ++i) {
-        launch_stats(0, c->z, io->mask, c->state, c->stat_partials, c->vol, st);
+        launch_stats(0, c->z, io->mask, c->state, c->stat_partials, c->vol, st, c->dcfg.K);
         launch_chain_scalar(c->state, c->stat_partials, stats_blocks(c->vol), 0, 2, c->dcfg, st);
     }
     LAUNCH_CHECK();
@@ -759,7 +759,7 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     for (int ch = 0; ch < C; ++ch) {
         const uint8_t* mask = io->mask + (io->mask_chains == 1 ? 0 : (int64_t)ch * vol.V);
         const float* zc = z + (int64_t)ch * vol.V;
-        launch_stats(cfg.virtual_decimation, zc, mask, c->state, c->stat_partials, vol, st);
+        launch_stats(cfg.virtual_decimation, zc, mask, c->state, c->stat_partials, vol, st, c->dcfg.K);
         launch_chain_scalar(c->state, c->stat_partials, sb, ch, 3, c->dcfg, st);
         const float* f = cfg.data_loss == IRS_DATA_GMM_LCC ? c->fhat + (c->fhat_chains == 1 ? 0 : (int64_t)ch * vol.V) : nullptr;
         launch_data_bwd(cfg.data_loss, f, 0, zc, c->sigM + (int64_t)ch * vol.V, mask, 0, nullptr, c->state, ch,

@@ -40,7 +40,9 @@ struct MixEval {
     float x;    // VD-rescaled residual: sum_k r_k (z / sigma_k)^2   (utils/util.py:330-347, closed form)
 };
 
-template <bool WANT_RESP>
+// KMAX: compile-time bound of the component loops (the caller knows K <= KMAX): the arrays of a K = 4 mixture then take 4
+// registers each instead of IRS_MAX_COMPONENTS
+template <bool WANT_RESP, int KMAX = IRS_MAX_COMPONENTS>
 __device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict__ s, float* resp, float* q) {
     MixEval e;
     if (s->mode == IRS_DATA_SSD) {
@@ -51,10 +53,10 @@ __device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict_
         return e;
     }
     const int K = s->K;
-    float t[IRS_MAX_COMPONENTS], qq[IRS_MAX_COMPONENTS];
+    float t[KMAX], qq[KMAX];
     float m = -3.0e38f;
 #pragma unroll
-    for (int k = 0; k < IRS_MAX_COMPONENTS; ++k) {
+    for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
             const float u = z * s->inv_sigma[k];
             qq[k] = u * u;
@@ -64,7 +66,7 @@ __device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict_
     }
     float sum = 0.0f;
 #pragma unroll
-    for (int k = 0; k < IRS_MAX_COMPONENTS; ++k) {
+    for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
             t[k] = __expf(t[k] - m);
             sum += t[k];
@@ -75,7 +77,7 @@ __device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict_
     e.x = 0.0f;
     e.gz = 0.0f;
 #pragma unroll
-    for (int k = 0; k < IRS_MAX_COMPONENTS; ++k) {
+    for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
             const float r = t[k] * inv;
             e.x += r * qq[k];

@@ -441,6 +441,7 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
     const int64_t HW = (int64_t)vol.H * vol.W;
     const float n = (float)(NT * NT * NT);
     const float alpha = EXPLICIT_GZ ? 1.0f : (float)state->sc.alpha[chain];
+    const bool k_le4 = state->K <= 4;
 
     // stage A elements
     unsigned aoff[NITA];
@@ -527,7 +528,8 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
                 } else {
                     gzv = 0.0f;
                     if (pm[it]) {
-                        const MixEval e = mix_eval<false>(zz, state, nullptr, nullptr);
+                        // (uniform branch: the component loops of a K <= 4 mixture are half as long)
+                        const MixEval e = k_le4 ? mix_eval<false, 4>(zz, state, nullptr, nullptr) : mix_eval<false>(zz, state, nullptr, nullptr);
                         gzv = alpha * e.gz;
                         if (acentre[it] && pin >= z0 && pin < z1) nll += (double)e.nll;
                     }
@@ -650,16 +652,20 @@ void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* s
 constexpr int QTX = 64, QTY = 4, QPX = QTX + 1, QPN = QPX * (QTY + 1);  // reg_energy_march_kernel: one output per thread
 constexpr int TTY = IRS_STATS_TY, TPN = QPX * (TTY + 1), QROWS = kStBlock / QTX, QNOUT = TTY / QROWS;
 
+// KMAX >= K (the host knows K): accumulators and mixture temporaries sized for it -- 13 fp64 sums instead of 21 for K <= 4
+// (the partial layout stays [kStatVals]: slots of components >= KMAX are written as zeros)
+template <int KMAX>
 __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __restrict__ z, const uint8_t* __restrict__ mask,
                                                                const DevState* __restrict__ state, int want_vd,
                                                                double* __restrict__ partials, Vol vol, int seg_len, int nseg,
                                                                int ntx, int nty) {
     constexpr int NIT = (TPN + kStBlock - 1) / kStBlock;
+    constexpr int NACC = 5 + 2 * KMAX;  // n, sum x^2, 3 lag-1 products, KMAX dNLL/dlog_std, KMAX responsibility sums
     __shared__ float X[TPN];
-    __shared__ double smem[kStatVals * (kStBlock / kWave)];
-    double acc[kStatVals];
+    __shared__ double smem[NACC * (kStBlock / kWave)];
+    double acc[NACC];
 #pragma unroll
-    for (int j = 0; j < kStatVals; ++j) acc[j] = 0.0;
+    for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
     const int64_t HW = (int64_t)vol.H * vol.W;
     const int lx = threadIdx.x % QTX, ly = threadIdx.x / QTX;
     const int K = state->K;
@@ -705,21 +711,21 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
                 float xv = 0.0f;
                 if (valid[it] && pm[it]) {
                     if (owned[it] && inseg) {
-                        float resp[IRS_MAX_COMPONENTS], q[IRS_MAX_COMPONENTS];
-                        const MixEval e = mix_eval<true>(pz[it], state, resp, q);
+                        float resp[KMAX], q[KMAX];
+                        const MixEval e = mix_eval<true, KMAX>(pz[it], state, resp, q);
                         xv = e.x;
                         acc[0] += 1.0;
                         acc[1] += (double)(e.x * e.x);
                         if (gmm) {
 #pragma unroll
-                            for (int k = 0; k < IRS_MAX_COMPONENTS; ++k)
+                            for (int k = 0; k < KMAX; ++k)
                                 if (k < K) {
                                     acc[5 + k] += (double)(resp[k] * (1.0f - q[k]));
-                                    acc[5 + IRS_MAX_COMPONENTS + k] += (double)resp[k];
+                                    acc[5 + KMAX + k] += (double)resp[k];
                                 }
                         }
                     } else {
-                        xv = mix_eval<false>(pz[it], state, nullptr, nullptr).x;
+                        xv = mix_eval<false, KMAX>(pz[it], state, nullptr, nullptr).x;
                     }
                 }
                 if (i < TPN) X[i] = xv;
@@ -743,20 +749,31 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
             __syncthreads();
         }
     }
-    block_sum<kStatVals>(acc, smem);
-    if (threadIdx.x == 0)
+    block_sum<NACC>(acc, smem);
+    if (threadIdx.x == 0) {
+        double* __restrict__ p = partials + (int64_t)blockIdx.x * kStatVals;
 #pragma unroll
-        for (int j = 0; j < kStatVals; ++j) partials[(int64_t)blockIdx.x * kStatVals + j] = acc[j];
+        for (int j = 0; j < 5; ++j) p[j] = acc[j];
+#pragma unroll
+        for (int k = 0; k < IRS_MAX_COMPONENTS; ++k) {
+            p[5 + k] = k < KMAX ? acc[5 + (k < KMAX ? k : 0)] : 0.0;
+            p[5 + IRS_MAX_COMPONENTS + k] = k < KMAX ? acc[5 + KMAX + (k < KMAX ? k : 0)] : 0.0;
+        }
+    }
 }
 
 void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, int blocks,
-                        Vol vol, hipStream_t st) {
+                        Vol vol, int K, hipStream_t st) {
     static const int seg_env = getenv("IRS_STATS_SEG") ? atoi(getenv("IRS_STATS_SEG")) : 0;
     const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + TTY - 1) / TTY), 8, seg_env, 2048);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + TTY - 1) / TTY;
-    hipLaunchKernelGGL(stats_march_kernel, dim3(blocks), dim3(kStBlock), 0, st, z, mask, (const DevState*)dev_state, want_vd,
-                       partials, vol, seg_len, nseg, ntx, nty);
+    if (K >= 1 && K <= 4)
+        hipLaunchKernelGGL(stats_march_kernel<4>, dim3(blocks), dim3(kStBlock), 0, st, z, mask, (const DevState*)dev_state, want_vd,
+                           partials, vol, seg_len, nseg, ntx, nty);
+    else
+        hipLaunchKernelGGL(stats_march_kernel<IRS_MAX_COMPONENTS>, dim3(blocks), dim3(kStBlock), 0, st, z, mask,
+                           (const DevState*)dev_state, want_vd, partials, vol, seg_len, nseg, ntx, nty);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -109,7 +109,7 @@ def test_transition_matches_reference_fixture(name):
 
 
 @pytest.mark.parametrize('variant', ['ssd_l2', 'ssd_vd_lognormal', 'gmm_nosobolev_c3', 'steps1', 'steps2', 'steps5_c2',
-                                     'noncubic_gmm', 'noncubic_ssd_c2', 'tiny_gmm'])
+                                     'noncubic_gmm', 'noncubic_ssd_c2', 'tiny_gmm', 'gmm_k2', 'gmm_k6'])
 def test_transition_matches_oracle_builder_variants(variant):
     """Configurations without a reference counterpart (SSD is builder-defined) or not covered by a fixture; the non-cubic ones
     (D != H != W, none a multiple of a tile edge) put ragged tiles and segments under every kernel of the composition."""
@@ -124,7 +124,9 @@ def test_transition_matches_oracle_builder_variants(variant):
               # few squaring steps: the first / last / only step of the chain has its own field layouts in the fused path
               steps1=dict(no_steps=1, lr=0.05), steps2=dict(no_steps=2, lr=0.05), steps5_c2=dict(no_steps=5, no_chains=2, lr=0.05),
               noncubic_gmm=dict(), noncubic_ssd_c2=dict(data_loss='SSD', virtual_decimation=True, no_chains=2),
-              tiny_gmm=dict(lr=0.05))[variant]
+              tiny_gmm=dict(lr=0.05),
+              # other numbers of mixture components: K <= 4 and K > 4 run different builds of the statistics kernel
+              gmm_k2=dict(gmm_components=2), gmm_k6=dict(gmm_components=6, no_chains=2))[variant]
     oc = OracleConfig(dims=dims, **kw)
     C = oc.no_chains
     f1, m1 = synthetic_pair(dims, seed=3)
@@ -143,7 +145,7 @@ def test_transition_matches_oracle_builder_variants(variant):
     eng.gmm_init(fixed_d, moving_d)
     st = eng.state()
     if oc.data_loss == 'GMM':
-        assert np.allclose(list(st.gmm_log_std)[:4], orc.log_std.detach().numpy(), atol=2e-4)
+        assert np.allclose(list(st.gmm_log_std)[:oc.gmm_components], orc.log_std.detach().numpy(), atol=2e-4)
     v = v0.to(DEV).contiguous()
     out = outputs_for(cfg)
     for it in range(3):
