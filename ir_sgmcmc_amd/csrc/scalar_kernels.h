@@ -13,6 +13,7 @@ struct DevState {
     // mixture constants derived from st (refreshed whenever the parameters change)
     float A[IRS_MAX_COMPONENTS];          // log pi_k - log sigma_k - 0.5 log(2 pi)
     float inv_sigma[IRS_MAX_COMPONENTS];  // exp(-log sigma_k)
+    float inv_var[IRS_MAX_COMPONENTS];    // inv_sigma_k^2
     int K;
     int mode;  // IRS_DATA_*
     float ssd_inv_sigma;
@@ -53,14 +54,14 @@ __device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict_
         return e;
     }
     const int K = s->K;
+    const float z2 = z * z;
     float t[KMAX], qq[KMAX];
     float m = -3.0e38f;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
-            const float u = z * s->inv_sigma[k];
-            qq[k] = u * u;
-            t[k] = s->A[k] - 0.5f * qq[k];
+            qq[k] = z2 * s->inv_var[k];  // (z / sigma_k)^2 with the square of z shared by the components
+            t[k] = fmaf(-0.5f, qq[k], s->A[k]);
             m = fmaxf(m, t[k]);
         }
     }
@@ -75,19 +76,20 @@ __device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict_
     const float inv = __builtin_amdgcn_rcpf(sum);  // sum in [1, K]; 1 ulp
     e.nll = -(m + __logf(sum));
     e.x = 0.0f;
-    e.gz = 0.0f;
+    float gs = 0.0f;  // sum_k r_k / sigma_k^2
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
             const float r = t[k] * inv;
             e.x += r * qq[k];
-            e.gz += r * z * s->inv_sigma[k] * s->inv_sigma[k];
+            gs += r * s->inv_var[k];
             if (WANT_RESP) {
                 resp[k] = r;
                 q[k] = qq[k];
             }
         }
     }
+    e.gz = z * gs;
     return e;
 }
 

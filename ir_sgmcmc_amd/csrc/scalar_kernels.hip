@@ -37,6 +37,7 @@ __device__ void refresh_derived(DevState* s, const DevCfg& cfg) {
         const float lp = s->st.gmm_logits[k] + 1e-2f - lse;
         s->A[k] = (lp - s->st.gmm_log_std[k]) - 0.91893853320467274178f;
         s->inv_sigma[k] = expf(-1.0f * s->st.gmm_log_std[k]);
+        s->inv_var[k] = s->inv_sigma[k] * s->inv_sigma[k];
     }
 }
 
