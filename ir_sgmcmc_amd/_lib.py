@@ -148,6 +148,7 @@ SIGNATURES = {
     'irs_slab_status_get': [_P, C.POINTER(IrsSlabStatus), _P],
     'irs_slab_trace': [C.POINTER(IrsConfig), C.POINTER(IrsSlabConfig), _I, _I, _I32P, C.POINTER(IrsSlabOp), _I, _I32P],
     'irs_slab_plan_rounds': [_I32P, _I, _I, _I, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P],
+    'irs_option_set': [_P, C.c_char_p, _I],
     'irs_last_error': [],
     'irs_version': [],
 }
@@ -179,6 +180,11 @@ def load(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def option_set(name, value, ctx=None):
+    """irs_option_set: a tuning / test switch by name, on one context or (ctx None) process-wide"""
+    check(load().irs_option_set(ctx, name.encode(), int(value)))
 
 
 def check(rc):

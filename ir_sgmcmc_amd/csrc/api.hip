@@ -25,6 +25,69 @@ int fail(const char* fmt, ...) {
 }
 }  // namespace irs
 
+namespace irs {
+
+static int env_or(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+static Knobs knobs_from_env() {
+    Knobs k;
+    k.predict_variants = env_or("IRS_PREDICT_VARIANTS", k.predict_variants);
+    k.run_ahead = env_or("IRS_RUN_AHEAD", k.run_ahead);
+    k.fuse_warp_bwd = env_or("IRS_FUSE_WARP_BWD", k.fuse_warp_bwd);
+    k.energy_in_update = env_or("IRS_ENERGY_IN_UPDATE", k.energy_in_update);
+    k.fuse_noise = env_or("IRS_FUSE_NOISE", k.fuse_noise);
+    k.fuse_stats = env_or("IRS_FUSE_STATS", k.fuse_stats);
+    k.recover = env_or("IRS_RECOVER", k.recover);
+    k.coarse_box = env_or("IRS_COARSE_BOX", k.coarse_box);
+    const char* tile = getenv("IRS_SOBOLEV_TILE");
+    if (tile && *tile) k.sobolev_tile = tile[0] == 'b' ? 2 : (tile[0] == 's' ? 1 : atoi(tile));
+    k.march_seg = env_or("IRS_MARCH_SEG", k.march_seg);
+    k.march_seg_fwd = env_or("IRS_MARCH_SEG_FWD", k.march_seg_fwd);
+    k.swz_run = env_or("IRS_SWZ_RUN", k.swz_run);
+    k.seg_min_blocks = env_or("IRS_SEG_MIN_BLOCKS", k.seg_min_blocks);
+    k.seg_min_len = env_or("IRS_SEG_MIN_LEN", k.seg_min_len);
+    k.sobolev_seg = env_or("IRS_SOBOLEV_SEG", k.sobolev_seg);
+    k.lcc_seg = env_or("IRS_LCC_SEG", k.lcc_seg);
+    k.stats_seg = env_or("IRS_STATS_SEG", k.stats_seg);
+    k.update_seg = env_or("IRS_UPDATE_SEG", k.update_seg);
+    k.slab_split = env_or("IRS_SLAB_SPLIT", k.slab_split);
+    k.slab_exact = env_or("IRS_SLAB_EXACT", k.slab_exact);
+    k.slab_force_h = env_or("IRS_SLAB_FORCE_H", k.slab_force_h);
+    return k;
+}
+
+Knobs& global_knobs() {
+    static Knobs k = knobs_from_env();  // the only place the library reads IRS_* tuning variables, once per process
+    return k;
+}
+
+int knob_set(Knobs& k, const char* name, int value) {
+    struct Entry {
+        const char* name;
+        int Knobs::*field;
+    };
+    static const Entry table[] = {
+        {"predict_variants", &Knobs::predict_variants}, {"run_ahead", &Knobs::run_ahead}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd},
+        {"energy_in_update", &Knobs::energy_in_update}, {"fuse_noise", &Knobs::fuse_noise}, {"fuse_stats", &Knobs::fuse_stats},
+        {"recover", &Knobs::recover}, {"coarse_box", &Knobs::coarse_box}, {"sobolev_tile", &Knobs::sobolev_tile},
+        {"march_seg", &Knobs::march_seg}, {"march_seg_fwd", &Knobs::march_seg_fwd}, {"swz_run", &Knobs::swz_run},
+        {"seg_min_blocks", &Knobs::seg_min_blocks}, {"seg_min_len", &Knobs::seg_min_len}, {"sobolev_seg", &Knobs::sobolev_seg},
+        {"lcc_seg", &Knobs::lcc_seg}, {"stats_seg", &Knobs::stats_seg}, {"update_seg", &Knobs::update_seg},
+        {"slab_split", &Knobs::slab_split}, {"slab_exact", &Knobs::slab_exact}, {"slab_force_h", &Knobs::slab_force_h},
+    };
+    if (!name) return fail("irs_option_set: null name");
+    for (const Entry& e : table)
+        if (!strcmp(e.name, name)) {
+            k.*(e.field) = value;
+            return 0;
+        }
+    return fail("irs_option_set: unknown option '%s'", name);
+}
+}  // namespace irs
+
 namespace {
 
 bool dims_ok(int C, int D, int H, int W) {
@@ -59,6 +122,8 @@ const char* irs_last_error(void) { return irs::g_err; }
 const char* irs_version(void) { return "ir-sgmcmc-amd 0.1 (gfx950)"; }
 size_t irs_reduce_scratch_doubles(void) { return (size_t)kMaxPartialBlocks * IRS_MAX_CHAINS; }
 
+int irs_option_set(irs_ctx* ctx, const char* name, int value) { return knob_set(ctx ? ctx->kn : global_knobs(), name, value); }
+
 // ================================================================================================
 // stateless operators
 // ================================================================================================
@@ -86,21 +151,12 @@ int irs_perturb_smooth(const float* v, const float* sigma, const float* eps, flo
         launch_perturb(v, sigma, eps, (float)sqrt(2.0 * (double)tau), out, C, vol, seed, iteration, nullptr, st);
         src = out;
     }
-    if (env_int("IRS_SOBOLEV_FUSED", 1)) {
-        if (src == out) {  // the fused kernel cannot run in place
-            HIP_TRY(hipMemcpyAsync(tmp, out, bytes, hipMemcpyDeviceToDevice, st));
-            src = tmp;
-        }
-        launch_sobolev_march(src, out, taps, C * 3, vol, nullptr, 12, st);
-        LAUNCH_CHECK();
-        return 0;
+    if (src == out) {  // the marching kernel cannot run in place
+        HIP_TRY(hipMemcpyAsync(tmp, out, bytes, hipMemcpyDeviceToDevice, st));
+        src = tmp;
     }
-    launch_conv_axis(src, tmp, taps, 2, C * 3, vol, st);   // z
-    launch_conv_axis(tmp, out, taps, 1, C * 3, vol, st);   // y
-    // x pass needs a third buffer: out -> tmp would leave the result in tmp; run x into tmp then copy back
-    launch_conv_axis(out, tmp, taps, 0, C * 3, vol, st);   // x
+    launch_sobolev_march(src, out, taps, C * 3, vol, nullptr, 12, st);
     LAUNCH_CHECK();
-    HIP_TRY(hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -114,8 +170,7 @@ int irs_svf_exp_fwd(const float* v, float* steps, float* transformation, float* 
     const int64_t field = (int64_t)C * 3 * vol.V;
     for (int k = 0; k < no_steps; ++k) {
         const float* in = k == 0 ? v : steps + (int64_t)(k - 1) * field;
-        if (use_lds_exp()) launch_exp_step_fwd_march(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, nullptr, nullptr, false, 0, st);
-        else launch_exp_step_fwd(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, st);
+        launch_exp_step_fwd_march(in, steps + (int64_t)k * field, k == 0, no_steps, C, vol, lin, nullptr, nullptr, false, 0, st);
     }
     if (transformation || displacement)
         launch_svf_outputs(steps + (int64_t)(no_steps - 1) * field, transformation, displacement, C, vol, lin, st);
@@ -160,20 +215,14 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
         cmm = sc.cmm;
     }
     if (C > IRS_MAX_CHAINS || no_steps > 32) return fail("irs_svf_exp_bwd: at most %d chains / 32 steps", IRS_MAX_CHAINS);
-    const bool lds = use_lds_exp();
-    if (lds) HIP_TRY(hipMemsetAsync(dmax, 0, sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32, st));
+    HIP_TRY(hipMemsetAsync(dmax, 0, sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32, st));
     for (int k = no_steps - 1; k >= 0; --k) {
         float* out = bufs[cur];
         const float* dk = k == 0 ? v : steps + (int64_t)(k - 1) * field;
-        if (lds) {
-            launch_field_absmax(dk, k == 0, no_steps, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, C, vol, st);
-            const int rad = env_int("IRS_EXP_GATHER", 2);
-            if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, rad, false, nullptr, 0, nullptr, st);
-            launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, rad, nullptr, 0, cmm, st);
-        } else {
-            HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
-            launch_exp_step_bwd(G, dk, out, k == 0, no_steps, C, vol, lin, st);
-        }
+        // every variant is launched (radius-1 / radius-2 gather, any-radius fixed-point scatter); the device picks by max|d_k|
+        launch_field_absmax(dk, k == 0, no_steps, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, C, vol, st);
+        launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, false, nullptr, 0, nullptr, st);
+        launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, 2, nullptr, 0, cmm, st);
         G = out;
         cur ^= 1;
     }
@@ -401,6 +450,7 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     irs_ctx* c = new (std::nothrow) irs_ctx();
     if (!c) return fail("irs_create: out of host memory");
     memset((void*)c, 0, sizeof(*c));
+    c->kn = global_knobs();
     c->cfg = *cfg;
     c->C = C;
     c->vol = make_vol(D, H, W);
@@ -635,20 +685,13 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     float* first = cfg.sobolev_s > 0 ? c->tmpA : vs;
     if (with_noise) launch_perturb(v, io->sigma, io->eps, (float)sqrt(2.0 * (double)cfg.lr), first, C, c->volv, cfg.seed, 0, it, st);
     else HIP_TRY(hipMemcpyAsync(first, v, (size_t)C * 3 * c->volv.V * sizeof(float), hipMemcpyDeviceToDevice, st));
-    const bool lds = use_lds_exp();
     // (the finalize kernel of a transition leaves the bound scratch cleared for the next one)
-    if (lds && !c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (cfg.no_steps + 1), st));
+    if (!c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (cfg.no_steps + 1), st));
     c->dmax_clean = false;
     bool have_dmax0 = false;
     if (cfg.sobolev_s > 0) {
-        if (env_int("IRS_SOBOLEV_FUSED", 1)) {
-            have_dmax0 = lds && !c->ffd;
-            launch_sobolev_march(c->tmpA, vs, c->sob, C * 3, c->volv, have_dmax0 ? c->dmax : nullptr, cfg.no_steps, st);
-        } else {
-            launch_conv_axis(c->tmpA, c->tmpB, c->sob, 2, C * 3, c->volv, st);
-            launch_conv_axis(c->tmpB, c->tmpA, c->sob, 1, C * 3, c->volv, st);
-            launch_conv_axis(c->tmpA, vs, c->sob, 0, C * 3, c->volv, st);
-        }
+        have_dmax0 = !c->ffd;
+        launch_sobolev_march(c->tmpA, vs, c->sob, C * 3, c->volv, have_dmax0 ? c->dmax : nullptr, cfg.no_steps, st);
     }
     // 2. dense velocity
     const float* dense = vs;
@@ -661,20 +704,18 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     if (timed) HIP_TRY(hipEventRecord(c->ev[1], st));
     const int64_t field = (int64_t)c->C * 3 * c->vol.V;
     const Lin lin = c->lin.lin();
-    if (lds && !have_dmax0) launch_field_absmax(dense, true, cfg.no_steps, c->dmax, C, c->vol, st);  // bound of d_0
+    if (!have_dmax0) launch_field_absmax(dense, true, cfg.no_steps, c->dmax, C, c->vol, st);  // bound of d_0
     for (int k = 0; k < cfg.no_steps; ++k) {
         const float* in = k == 0 ? dense : c->steps + (int64_t)(k - 1) * field;
         float* out = c->steps + (int64_t)k * field;
-        if (lds)
-            launch_exp_step_fwd_march(in, out, k == 0, cfg.no_steps, C, c->vol, lin, c->dmax + (int64_t)k * c->C * 4,
-                                      c->dmax + (int64_t)(k + 1) * c->C * 4, predicted_small(c, k), fwd_lay(c, k), st);
-        else launch_exp_step_fwd(in, out, k == 0, cfg.no_steps, C, c->vol, lin, st);
+        launch_exp_step_fwd_march(in, out, k == 0, cfg.no_steps, C, c->vol, lin, c->dmax + (int64_t)k * c->C * 4,
+                                  c->dmax + (int64_t)(k + 1) * c->C * 4, predicted_small(c, k), fwd_lay(c, k), st);
     }
     if (timed) HIP_TRY(hipEventRecord(c->ev[2], st));
     const float* d_last = c->steps + (int64_t)(cfg.no_steps - 1) * field;
     // 4. warp (+ jitter) and residual
     const float alpha = with_jitter ? cfg.uniform_alpha : 0.0f;
-    launch_warp_fwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif, alpha, warped, gradm, aos_enabled() ? 1 : 0, C, c->vol, lin,
+    launch_warp_fwd(io->moving_im, io->moving_chains == 1 ? 0 : c->vol.V, d_last, io->unif, alpha, warped, gradm, 1, C, c->vol, lin,
                     cfg.seed, 0, it, st);
     if (cfg.data_loss == IRS_DATA_GMM_LCC)
         launch_lcc_fwd_march(c->fhat, c->fhat_chains == 1 ? 0 : c->vol.V, warped, z, c->sigM, cfg.lcc_s, C, c->vol, st);
@@ -724,7 +765,7 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     // transitions would predict from a state twenty transitions old, and while the displacement is still growing (burn-in)
     // that mispredicts into the slow always-correct fallbacks.  Two queued transitions keep the device busy all the same.
     {
-        const int depth = env_int("IRS_RUN_AHEAD", 2);
+        const int depth = c->kn.run_ahead;
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cap);
         if (depth > 0 && depth <= 3 && cap == hipStreamCaptureStatusNone && c->n_enqueued >= (uint64_t)depth)
@@ -736,7 +777,7 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     if (timed) HIP_TRY(hipEventRecord(c->ev[0], st));
     // fused backward warp: the forward warp also writes d(warped)/d(d_last) into gA, and the first adjoint squaring step
     // multiplies it with g_warped while staging (kernels.h: gscale); only on the LDS path, which owns every variant of it
-    const bool fuse_warp_bwd = use_lds_exp() && env_int("IRS_FUSE_WARP_BWD", 1) != 0;
+    const bool fuse_warp_bwd = c->kn.fuse_warp_bwd != 0;
     if (forward_pass(c, io, io->v, true, cfg.uniform_alpha > 0.0f, vs, warped, z, fuse_warp_bwd ? c->gA : nullptr, C, st, timed)) return 1;
     const int64_t field = (int64_t)C * 3 * vol.V;
     const float* d_last = c->steps + (int64_t)(cfg.no_steps - 1) * field;
@@ -748,7 +789,7 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     const int upd_blocks = sgld_update_blocks_per_chain(volv, C);
     const bool energy_in_update = (cfg.reg_loss == IRS_REG_L2 || cfg.reg_loss == IRS_REG_LOGNORMAL_L2) &&
                                   (int64_t)upd_blocks * C <= (int64_t)kMaxPartialBlocks * IRS_MAX_CHAINS &&
-                                  env_int("IRS_ENERGY_IN_UPDATE", 1) != 0;
+                                  c->kn.energy_in_update != 0;
     if (!energy_in_update) {
         launch_reg_energy(vs, c->energy_partials, C, volv, st);
         launch_reg_scalar(c->state, c->energy_partials, energy_blocks(volv), c->dcfg, st);
@@ -782,30 +823,23 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
         for (int k = cfg.no_steps - 1; k >= 0; --k) {
             float* out = bufs[cur];
             const float* dk = k == 0 ? dense : c->steps + (int64_t)(k - 1) * field;
-            const bool lds = use_lds_exp();
-            if (!lds) HIP_TRY(hipMemsetAsync(out, 0, (size_t)field * sizeof(float), st));
             if (timed) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k], st));
-            if (lds) {
-                const unsigned* dm = c->dmax + (int64_t)k * C * 4;
-                const int rad = env_int("IRS_EXP_GATHER", 2);  // largest gather radius to launch (0: scatter only)
-                // fused backward warp: gA holds d(warped)/d(d_last); the first step scales it by g_warped while staging
-                const float* gscale = fuse_warp_bwd && k == cfg.no_steps - 1 ? c->gM : nullptr;
-                // timed mode: the end event of step k closes right after the radius-1 kernel, so that exp_bwd_kernel_ms is
-                // the time of the dominant kernel alone (as rocprofv3 reports it), not of the idle variants after it
-                // the any-radius LDS-scatter kernel is launched only when the bound of d_k, as last seen by the host, is near
-                // 2 voxels; otherwise the (rarely selected) radius-2 kernel owns everything above one voxel -- through its
-                // generic in-kernel fallback if the bound exceeds its ring after all
-                const bool skip_any = rad >= 2 && predicted_below(c, k, 1.5f);
-                const bool skip_r2 = rad >= 2 && skip_any && k < 32 && predicted_tiny(c, k);
-                if (skip_r2) skipped_r2 |= 1u << k;
-                // with the fused backward warp the first step's incoming gradient is the interleaved d(warped)/d(d_n)
-                const int lay = bwd_lay(c, k) | (gscale && aos_enabled() ? 2 : 0);
-                if (rad) launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, skip_r2 ? 1 : rad, skip_any, gscale, lay,
-                                                   timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
-                if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, rad, gscale, lay, c->cmm, st);
-            }
-            else launch_exp_step_bwd(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, st);
-            if (timed && !(lds && env_int("IRS_EXP_GATHER", 2))) HIP_TRY(hipEventRecord(c->ev_bwd[2 * k + 1], st));
+            const unsigned* dm = c->dmax + (int64_t)k * C * 4;
+            // fused backward warp: gA holds d(warped)/d(d_last); the first step scales it by g_warped while staging
+            const float* gscale = fuse_warp_bwd && k == cfg.no_steps - 1 ? c->gM : nullptr;
+            // timed mode: the end event of step k closes right after the radius-1 kernel, so that exp_bwd_kernel_ms is
+            // the time of the dominant kernel alone (as rocprofv3 reports it), not of the idle variants after it
+            // the any-radius LDS-scatter kernel is launched only when the bound of d_k, as last seen by the host, is near
+            // 2 voxels; otherwise the (rarely selected) radius-2 kernel owns everything above one voxel -- through its
+            // generic in-kernel fallback if the bound exceeds its ring after all
+            const bool skip_any = predicted_below(c, k, 1.5f);
+            const bool skip_r2 = skip_any && k < 32 && predicted_tiny(c, k);
+            if (skip_r2) skipped_r2 |= 1u << k;
+            // with the fused backward warp the first step's incoming gradient is the interleaved d(warped)/d(d_n)
+            const int lay = bwd_lay(c, k) | (gscale ? 2 : 0);
+            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, skip_r2 ? 1 : 2, skip_any, gscale, lay,
+                                      timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
+            if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, 2, gscale, lay, c->cmm, st);
             G = out;
             cur ^= 1;
         }
@@ -826,9 +860,9 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
                            energy_in_update ? c->energy_partials : nullptr, energy_in_update);
     }
     if (energy_in_update) launch_reg_scalar(c->state, c->energy_partials, upd_blocks, c->dcfg, st);
-    launch_finalize(c->state, c->nll_partials, c->nll_blocks, c->dcfg, true, use_lds_exp() ? c->dmax : nullptr, c->hint,
+    launch_finalize(c->state, c->nll_partials, c->nll_blocks, c->dcfg, true, c->dmax, c->hint,
                     4 * C * (cfg.no_steps + 1), skipped_r2, kHintWords - 7, true, st);
-    c->dmax_clean = use_lds_exp();
+    c->dmax_clean = true;
     LAUNCH_CHECK();
     if (timed) HIP_TRY(hipEventRecord(c->ev[5], st));
     HIP_TRY(hipEventRecord(c->ra_ev[c->n_enqueued % 4], st));

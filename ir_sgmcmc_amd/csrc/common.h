@@ -76,15 +76,37 @@ __device__ __forceinline__ void seg_range(const Vol& v, int seg, int seg_len, in
 // voxels a launch writes (sizes the partial-sum grids)
 __host__ __device__ inline int64_t win_voxels(const Vol& v) { return (int64_t)(v.nz + v.nzb) * v.H * v.W; }
 
+// Tuning / test switches.  The environment is read ONCE per process (first use); a context takes a copy when it is created
+// and nothing on the per-transition path calls getenv.  None of them selects other arithmetic: they pick launch shapes,
+// which (always-correct) kernel variants are launched, and test hooks.  irs_option_set changes one by name afterwards
+// (tests, tools/): on a context, or process-wide (the stateless operators and every context created later).
+struct Knobs {
+    int predict_variants = 1;  // IRS_PREDICT_VARIANTS  0: launch every variant; 1: production heuristic; 2: always predict small (tests)
+    int run_ahead = 2;         // IRS_RUN_AHEAD         transitions the host may run ahead of the device (1..3)
+    int fuse_warp_bwd = 1;     // IRS_FUSE_WARP_BWD     backward warp folded into the first adjoint step
+    int energy_in_update = 1;  // IRS_ENERGY_IN_UPDATE  regulariser energy as a by-product of the update kernel (L2 family)
+    int fuse_noise = 1;        // IRS_FUSE_NOISE        Langevin noise generated while the smoothing kernel stages its planes
+    int fuse_stats = 1;        // IRS_FUSE_STATS        mixture statistics of the first chain accumulated by the LCC map kernel
+    int recover = 1;           // IRS_RECOVER           keep the previous velocity and re-run a transition whose variant prediction failed
+    int coarse_box = 1;        // IRS_COARSE_BOX        any-radius adjoint: source boxes from the coarse displacement extrema
+    int sobolev_tile = 0;      // IRS_SOBOLEV_TILE      0: by size; 1: 32 x 16; 2: 64 x 32 ("small" / "big")
+    int march_seg = 0, march_seg_fwd = 0, swz_run = -1, seg_min_blocks = 0, seg_min_len = 0;  // IRS_MARCH_SEG, _FWD, IRS_SWZ_RUN, IRS_SEG_MIN_*
+    int sobolev_seg = 0, lcc_seg = 0, stats_seg = 0, update_seg = 0;                          // IRS_*_SEG
+    int slab_split = 1;        // IRS_SLAB_SPLIT        interior / boundary split around an exchange
+    int slab_exact = 0;        // IRS_SLAB_EXACT        every transition in measuring mode
+    int slab_force_h = 0;      // IRS_SLAB_FORCE_H      test hook: a deliberately wrong ghost-width plan
+};
+Knobs& global_knobs();                                   // api.hip; initialised from the environment on first use
+int knob_set(Knobs& k, const char* name, int value);     // 0 on success
+
 // Segment length of the z-marching kernels.  32 planes amortise the run-in of a segment (2R .. 4S extra planes) when the
 // launch still has enough workgroups to fill 256 CUs; smaller volumes trade run-in overhead for parallelism, down to
 // `min_len`.  `forced` (> 0) is the environment override of the kernel family.
 inline int pick_seg_len(int nz, int64_t tiles_per_layer, int min_len, int forced, int64_t want_blocks = 1024) {
     if (forced > 0) return forced;
-    static const int64_t want_env = getenv("IRS_SEG_MIN_BLOCKS") ? atoll(getenv("IRS_SEG_MIN_BLOCKS")) : 0;
-    static const int min_env = getenv("IRS_SEG_MIN_LEN") ? atoi(getenv("IRS_SEG_MIN_LEN")) : 0;
-    if (min_env > 0) min_len = min_env;
-    const int64_t want = want_env > 0 ? want_env : want_blocks;
+    const Knobs& kn = global_knobs();
+    if (kn.seg_min_len > 0) min_len = kn.seg_min_len;
+    const int64_t want = kn.seg_min_blocks > 0 ? kn.seg_min_blocks : want_blocks;
     int len = 32;
     while (len > min_len && tiles_per_layer * ((nz + len - 1) / len) < want) len >>= 1;
     return len < 1 ? 1 : len;

@@ -24,12 +24,6 @@ int fail(const char* fmt, ...);  // formats irs_last_error(), returns 1 (api.hip
         if (e_ != hipSuccess) return irs::fail("kernel launch failed: %s", hipGetErrorString(e_)); \
     } while (0)
 
-inline int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
-inline bool use_lds_exp() { return env_int("IRS_EXP_LDS", 1) != 0; }
 
 // z-slab decomposition (slab.hip): this rank owns the planes [a, b) of the volume and HOLDS the planes [lo, hi) (its slab
 // plus a ghost margin) of every array; everything else about the context is the single-GPU one.
@@ -73,12 +67,13 @@ struct irs_ctx {
     hipEvent_t ev_bwd[64];
     hipEvent_t ra_ev[4];     // end of the last transitions: bounds how far the host may run ahead of the device
     uint64_t n_enqueued = 0;
+    irs::Knobs kn;            // copy of the process-wide switches, taken by irs_create (irs_option_set changes it)
     bool dmax_clean = false;  // the bound scratch was cleared by the finalize kernel of the last transition
     // ---- z-slab decomposition (slab.hip)
     irs::SlabInfo sl;
     irs_comm* comm = nullptr;      // not owned
     hipStream_t cs = nullptr;      // communication stream (owned)
-    hipEvent_t sev[24];            // 0..15 rotating producer / receive events of the exchanges, 16.. pairs of the all-reduces
+    hipEvent_t sev[28];            // 0..15 rotating producer / receive events of the exchanges, 16.. one pair per KIND of all-reduce
     unsigned* plan_hint = nullptr; // pinned, TWO slots of kHintWords: the all-reduced bounds of transition t land in slot t % 2.  The
                                    // plan of transition t reads slot t % 2 = the bounds of t - 2, a transition every rank has
                                    // seen FINISH (the host waits for it): every rank plans from the same numbers.  (The single
@@ -101,7 +96,7 @@ constexpr int kHintWords = 4 * IRS_MAX_CHAINS * 32 + 8;  // dmax scratch + [flag
 // finish (never waited for: stale by a transition or two, and displacements move by O(lr) per transition).  Only a launch
 // decision: the kernels that remain are correct for any displacement, so a wrong guess costs time, not parity.
 inline bool predicted_below(const irs_ctx* c, int k, float bound) {
-    const int mode = env_int("IRS_PREDICT_VARIANTS", 1);  // 0: always launch every variant; 2: always predict small (tests)
+    const int mode = c->kn.predict_variants;
     if (mode == 2) return true;
     if (!mode || !c->hint) return false;
     const volatile unsigned* h = c->hint + (size_t)k * c->C * 4;
@@ -121,19 +116,14 @@ inline bool predicted_small(const irs_ctx* c, int k) { return predicted_below(c,
 // from the production heuristic only, with a 2.5x margin -- d_k moves by O(0.1) voxel per transition and the host is at most
 // two transitions behind -- and (b) VALIDATED on the device: finalize_kernel compares the bounds of the steps whose variant
 // was skipped with 1 and raises a sticky flag that the next irs_transition returns as an error.
-inline bool predicted_tiny(const irs_ctx* c, int k) { return env_int("IRS_PREDICT_VARIANTS", 1) == 1 && predicted_below(c, k, 0.4f); }
+inline bool predicted_tiny(const irs_ctx* c, int k) { return c->kn.predict_variants == 1 && predicted_below(c, k, 0.4f); }
 
 // Layouts of the INTERNAL fields of the fused path (exp_kernels.hip: Lay3; bits 1 displacement in, 2 gradient in, 4 out):
 // d_1 .. d_{n-1} and the gradients handed from one adjoint step to the next are interleaved ([V][3]); everything that crosses
 // into another kernel family -- the velocity in, d_n into the warp, the gradient into the first and out of the last adjoint
 // step -- stays planar like the reference's tensors.
-inline bool aos_enabled() { return use_lds_exp() && env_int("IRS_AOS", 1) != 0; }
-inline int fwd_lay(const irs_ctx* c, int k) {
-    if (!aos_enabled()) return 0;
-    return (k > 0 ? 1 : 0) | (k < c->cfg.no_steps - 1 ? 4 : 0);
-}
+inline int fwd_lay(const irs_ctx* c, int k) { return (k > 0 ? 1 : 0) | (k < c->cfg.no_steps - 1 ? 4 : 0); }
 inline int bwd_lay(const irs_ctx* c, int k) {
-    if (!aos_enabled()) return 0;
     return (k > 0 ? 1 : 0) | (k < c->cfg.no_steps - 1 ? 2 : 0) | (k > 0 ? 4 : 0);
 }
 

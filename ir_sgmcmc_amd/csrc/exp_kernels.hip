@@ -440,7 +440,7 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
     TileGrid tz;
     const dim3 grid = exp_grid(vol, C, &tz);
     const Scale3L sc = make_scale_l(vol, no_steps);
-    if (getenv("IRS_COARSE_BOX") && atoi(getenv("IRS_COARSE_BOX")) == 0) cmm = nullptr;  // parity test of the two source boxes
+    if (!global_knobs().coarse_box) cmm = nullptr;  // parity test of the two source boxes
     if (cmm) {  // coarse displacement extrema / gradient maxima (coarse_minmax_bytes(vol, C) of scratch)
         const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.D + kCell - 1) / kCell;
         const dim3 cg((unsigned)(((ncx + 7) / 8) * ncy * ncz), (unsigned)C);
@@ -482,16 +482,6 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #ifndef IRS_MARCH_WAVES
 #define IRS_MARCH_WAVES 4
 #endif
-// IRS_BWD_HZ=1: z weights of the gather formed once per source at commit time instead of by each of its nine in-plane
-// gatherers.  Correct (parity suite green) and 3 VALU instructions fewer per candidate, but
-// MEASURED SLOWER: 205.9 vs 200.2 us per launch at 256^3 (tools/build_variant.sh hz1 -DIRS_BWD_HZ=1; tools/sweep_lib.sh) --
-// the records grow from three ds_read_b64 (6 LDS cycles) to two ds_read_b128 (8) per candidate and from 28 to 36 cycles of
-// LDS store path per source, on a kernel whose LDS pipe is already ~50 % busy next to a 74 % busy VALU.
-// Kept as a build variant, off.
-#ifndef IRS_BWD_HZ
-#define IRS_BWD_HZ 0
-#endif
-
 // hat of (r + c) for a relative position r and a compile-time integer offset c.
 template <int R>
 __device__ __forceinline__ float rel_hat(float r, int c);
@@ -600,16 +590,10 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     // ring slot layout (9 floats per source, 8-byte fields so that the gather needs three ds_read_b64 per candidate):
     //   q_xy = (rx, ry)   q_zg = (rz, G2)   q_g = (G0, G1)   q_d = (d0, d1)   q_dz = d2
     // where r = clipped sampling position - the source's own coordinate (|r| <= max|d|): every hat weight of the
-    // gather is then a function of r plus a compile-time offset
-    // HZ (radius 1): the three z weights of a source -- hat(rz + 1), hat(rz), hat(rz - 1), its contributions to the output
-    // planes s - 1, s, s + 1 -- are formed ONCE when the source is committed instead of by each of its nine in-plane gatherers:
-    //   qa = (rx, ry, hz-, hz0)   qb = (G0, G1, G2, hz+)   (two ds_read_b128 per candidate, packed operands on even registers;
-    //   rz = hz+ - hz- exactly)
-    // and only the source plane being gathered and the one before it (own term) are kept: two slots, 34 KB with the d ring.
-    constexpr bool HZ = (R == 1) && (IRS_BWD_HZ != 0);
-    __shared__ float2 q_xy[HZ ? 1 : NP * PN], q_zg[HZ ? 1 : NP * PN], q_g[HZ ? 1 : NP * PN], q_d[NP * PN];
+    // gather is then a function of r plus a compile-time offset.  (Forming the three z weights of a source once, at commit
+    // time, instead of in each of its nine gatherers was built and measured slower -- wider LDS records: DESIGN.md section 4.)
+    __shared__ float2 q_xy[NP * PN], q_zg[NP * PN], q_g[NP * PN], q_d[NP * PN];
     __shared__ float q_dz[NP * PN];
-    __shared__ float4 qa[HZ ? 2 * PN : 1], qb[HZ ? 2 * PN : 1];
     // XCD-aware tile assignment: consecutive tiles (x fastest, then y, then z-segment, then chain) stay on one L2
     const int tile_ = xcd_swizzle_runs(tile_id, (int)(tiles.x * tiles.y * tiles.z), swz_run);
     const int tbx = tile_ % tiles.x, tby = (tile_ / tiles.x) % tiles.y, tbz = tile_ / (tiles.x * tiles.y);
@@ -698,7 +682,6 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
             if (gs_) pgs[it] = ld_off(gs_ + zo, g);
         }
     };
-    const int sbase_ = z0 - R;  // first source plane of the segment (slot parity of the two-slot records)
     auto commit = [&](int s, int slot) {  // registers -> ring slot (with the clipped sampling position)
         const bool zin = s >= 0 && s < vol.D;
         const float lz_ = zin ? lin.z[s] : 0.0f, fs_ = (float)s;
@@ -706,16 +689,10 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
             const int i = slot * PN + threadIdx.x + it * kMarchBlock;
-            const int iab = HZ ? ((s - sbase_) & 1) * PN + threadIdx.x + it * kMarchBlock : 0;
             if (!zin) {  // plane outside the volume: no source there (G = 0 removes it from every gather)
-                if (HZ) {
-                    qa[iab] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    qb[iab] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                } else {
-                    q_xy[i] = make_float2(0.0f, 0.0f);
-                    q_zg[i] = make_float2(0.0f, 0.0f);
-                    q_g[i] = make_float2(0.0f, 0.0f);
-                }
+                q_xy[i] = make_float2(0.0f, 0.0f);
+                q_zg[i] = make_float2(0.0f, 0.0f);
+                q_g[i] = make_float2(0.0f, 0.0f);
                 q_d[i] = make_float2(0.0f, 0.0f);
                 q_dz[i] = 0.0f;
                 continue;
@@ -733,15 +710,9 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
             const float gm_ = gs_ ? pgs[it] : 1.0f;
             const float g0 = sin_[it] ? pre[it][3] * gm_ : 0.0f, g1 = sin_[it] ? pre[it][4] * gm_ : 0.0f,
                         g2 = sin_[it] ? pre[it][5] * gm_ : 0.0f;
-            if (HZ) {
-                const float rz = p2 - fs_;
-                qa[iab] = make_float4(p0 - sfx[it], p1 - sfy[it], clamp01(-rz), hat01(rz));
-                qb[iab] = make_float4(g0, g1, g2, clamp01(rz));
-            } else {
-                q_xy[i] = make_float2(p0 - sfx[it], p1 - sfy[it]);
-                q_zg[i] = make_float2(p2 - fs_, g2);
-                q_g[i] = make_float2(g0, g1);
-            }
+            q_xy[i] = make_float2(p0 - sfx[it], p1 - sfy[it]);
+            q_zg[i] = make_float2(p2 - fs_, g2);
+            q_g[i] = make_float2(g0, g1);
             q_d[i] = make_float2(d0, d1);
             q_dz[i] = d2;
         }
@@ -772,20 +743,6 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                 for (int dy = 0; dy <= 2 * R; ++dy)
 #pragma unroll
                     for (int dx = 0; dx <= 2 * R; ++dx) {
-                        if (HZ) {
-                            const int ri = ((s - sbase_) & 1) * PN + (ly + dy) * PX + (lx + dx);
-                            const float4 A = qa[ri], B = qb[ri];
-                            const float hxy = rel_hat<R>(A.x, dx - R) * rel_hat<R>(A.y, dy - R);
-                            const float wz[3] = {hxy * A.z, hxy * A.w, hxy * B.w};  // output planes s - 1, s, s + 1
-#pragma unroll
-                            for (int oo = -1; oo <= 1; ++oo) {
-                                const int a = (PH + oo + NP) % NP;
-                                acc01[a].x = fmaf(wz[oo + 1], B.x, acc01[a].x);
-                                acc01[a].y = fmaf(wz[oo + 1], B.y, acc01[a].y);
-                                acc2[a] = fmaf(wz[oo + 1], B.z, acc2[a]);
-                            }
-                            continue;
-                        }
                         const int ri = PH * PN + (ly + dy) * PX + (lx + dx);
                         const float2 rxy = q_xy[ri], rzg = q_zg[ri], g01 = q_g[ri];
                         // weight of source (x + dx - R, y + dy - R, s) on output (x, y, s + oo): hat(r + offset) per axis.
@@ -810,24 +767,8 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                 if (zo >= z0 && zo < z1 && col_in) {
                     const int ci = a * PN + (ly + R) * PX + (lx + R);  // plane zo sits in slot (zo - sbase) % NP == a
                     // the sample this voxel took in the forward step: its clipped position is already in the ring
-                    float2 pc, zg;
-                    float G0, G1, G2;
-                    if (HZ) {
-                        const int cj = ((zo - sbase_) & 1) * PN + (ly + R) * PX + (lx + R);
-                        const float4 A = qa[cj], B = qb[cj];
-                        pc = make_float2(A.x, A.y);
-                        zg = make_float2(B.w - A.z, 0.0f);  // rz = max(0, rz) - max(0, -rz), exactly
-                        G0 = B.x;
-                        G1 = B.y;
-                        G2 = B.z;
-                    } else {
-                        pc = q_xy[ci];
-                        zg = q_zg[ci];
-                        const float2 Gc01 = q_g[ci];
-                        G0 = Gc01.x;
-                        G1 = Gc01.y;
-                        G2 = zg.y;
-                    }
+                    const float2 pc = q_xy[ci], zg = q_zg[ci], Gc01 = q_g[ci];
+                    const float G0 = Gc01.x, G1 = Gc01.y, G2 = zg.y;
                     const float fx0 = floorf(pc.x), fy0 = floorf(pc.y), fz0 = floorf(zg.x);  // of the RELATIVE position
                     const float wx1 = __fsub_rn(pc.x, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), pc.x);
                     const float wy1 = __fsub_rn(pc.y, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.0f), pc.y);
@@ -925,13 +866,13 @@ constexpr int kRareGrid = 512;  // persistent grid of the rarely selected varian
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
                                hipEvent_t after_primary, hipStream_t st) {
-    static const int seg_env = getenv("IRS_MARCH_SEG") ? atoi(getenv("IRS_MARCH_SEG")) : 0;
+    const int seg_env = global_knobs().march_seg;
     const int seg_len = pick_seg_len(vol.nz + vol.nzb, (int64_t)((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * C, 8, seg_env);
     const int nseg = vol_nseg(vol, seg_len);  // segments of both windows
     const dim3 tiles((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     const Scale3L sc = make_scale_l(vol, no_steps);
-    static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
+    const int swz_env = global_knobs().swz_run;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;  // 0/1: no remap; default: one x-row of tiles per XCD run
 #define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale, lay)
     const int rare = total < kRareGrid ? total : kRareGrid;
@@ -1216,13 +1157,13 @@ __global__ __launch_bounds__(kFwdBlock, R == 1 ? IRS_FWD_WAVES : 1) void exp_fwd
 
 void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
                                const unsigned* dmax_in, unsigned* dmax_out, bool only_r1, int lay, hipStream_t st) {
-    static const int seg_env = getenv("IRS_MARCH_SEG_FWD") ? atoi(getenv("IRS_MARCH_SEG_FWD")) : 0;
+    const int seg_env = global_knobs().march_seg_fwd;
     const int seg_len = pick_seg_len(vol.nz + vol.nzb, (int64_t)((vol.W + FTX - 1) / FTX) * ((vol.H + FTY - 1) / FTY) * C, 8, seg_env);
     const int nseg = vol_nseg(vol, seg_len);  // segments of both windows
     const dim3 tiles((vol.W + FTX - 1) / FTX, (vol.H + FTY - 1) / FTY, (unsigned)(nseg * C));
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     const Scale3L sc = make_scale_l(vol, no_steps);
-    static const int swz_env = getenv("IRS_SWZ_RUN") ? atoi(getenv("IRS_SWZ_RUN")) : -1;
+    const int swz_env = global_knobs().swz_run;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;
 #define IRS_FWM(P, RR, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), dim3(GRID), dim3(kFwdBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
     const int rare = total < kRareGrid ? total : kRareGrid;

@@ -1,6 +1,6 @@
 // gfx950 kernels for the velocity/displacement-field half of the SG-MCMC transition:
-//   SGLD perturbation + Sobolev smoothing   (reference utils/functions.py:76-109, utils/util.py:48-58,394-404)
-//   scaling and squaring forward / adjoint  (utils/transformation.py:63-76 and autograd through it)
+//   SGLD perturbation                       (reference utils/functions.py:76-84, utils/util.py:48-58)
+//   outputs of scaling and squaring         (utils/transformation.py:75-76; the steps themselves: exp_kernels.hip)
 //   trilinear / nearest warps               (utils/registration.py:17-30, utils/util.py:44-53)
 //   cubic B-spline FFD up-sampling / adjoint (utils/transformation.py:105-153)
 // All of it is HBM/L2-bound gather/stencil work on planar fp32 fields (C,3,D,H,W); no MFMA by design.
@@ -60,90 +60,13 @@ void launch_perturb(const float* v, const float* sigma, const float* eps, float 
                        npair);
 }
 
-// ------------------------------------------------------------------------------------------------
-// one axis of the separable Sobolev filter with replicate padding (utils/util.py:400-404):
-// out(p) = sum_t k[t] in(clamp(p + t - s)) along AXIS (0 = x/W, 1 = y/H, 2 = z/D)
-// ------------------------------------------------------------------------------------------------
-template <int AXIS>
-__global__ __launch_bounds__(kBlock) void conv_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                           Taps taps, Vol vol) {
-    IRS_VOXEL(vol, plane, x, y, z, vox);
-    const int64_t base = (int64_t)plane * vol.V;
-    const int pos = AXIS == 0 ? x : (AXIS == 1 ? y : z);
-    const int n = AXIS == 0 ? vol.W : (AXIS == 1 ? vol.H : vol.D);
-    const int64_t stride = AXIS == 0 ? 1 : (AXIS == 1 ? vol.W : (int64_t)vol.W * vol.H);
-    const float* row = in + base + vox - (int64_t)pos * stride;
-    float acc = 0.0f;
-    for (int t = 0; t <= 2 * taps.s; ++t) {
-        const int q = min(max(pos + t - taps.s, 0), n - 1);
-        acc = fmaf(taps.k[t], row[(int64_t)q * stride], acc);
-    }
-    out[base + vox] = acc;
-}
-
-void launch_conv_axis(const float* in, float* out, const Taps& taps, int axis, int CC, Vol vol, hipStream_t st) {
-    const dim3 grid = vox_grid(vol, CC);
-    if (axis == 0) hipLaunchKernelGGL(conv_axis_kernel<0>, grid, dim3(kBlock), 0, st, in, out, taps, vol);
-    else if (axis == 1) hipLaunchKernelGGL(conv_axis_kernel<1>, grid, dim3(kBlock), 0, st, in, out, taps, vol);
-    else hipLaunchKernelGGL(conv_axis_kernel<2>, grid, dim3(kBlock), 0, st, in, out, taps, vol);
-}
-
-// ------------------------------------------------------------------------------------------------
-// scaling and squaring, one step:  d_out = d + sample(d, id + d)        (utils/transformation.py:70-73)
-// PRESCALE: the input is the velocity in voxel units and d_0 = ((v * 2) / (n_c - 1)) / 2^steps is formed on load
-// (for the centre value and for every tap), so d_0 is never materialised.
-// ------------------------------------------------------------------------------------------------
+// per-channel constants of the coordinate transforms: x <-> W, y <-> H, z <-> D (the reference pairs channel c with shape[2 + c],
+// which is the same thing for the cubic volumes it supports)
 struct Scale3 {
-    float nm1[3];   // axis length - 1 for channel c: x <-> W, y <-> H, z <-> D (the reference pairs channel c with
-                    // shape[2 + c], which is the same thing for the cubic volumes it supports)
+    float nm1[3];   // axis length - 1 for channel c
     float rnm1[3];  // correctly rounded 1 / nm1 (common.h: exact_rcp, div_exact)
     float inv_pow;  // 1 / 2^no_steps
 };
-
-template <bool PRESCALE>
-__device__ __forceinline__ float ld(const float* p, int64_t i, float nm1, float rnm1, float inv_pow) {
-    const float v = p[i];
-    return PRESCALE ? prescale(v, nm1, rnm1, inv_pow) : v;
-}
-
-template <bool PRESCALE>
-__global__ __launch_bounds__(kBlock) void exp_step_fwd_kernel(const float* __restrict__ din, float* __restrict__ dout,
-                                                              Vol vol, Lin lin, Scale3 sc) {
-    IRS_VOXEL(vol, chain, x, y, z, vox);
-    const int64_t V = vol.V;
-    const float* c0 = din + (int64_t)chain * 3 * V;
-    const float* c1 = c0 + V;
-    const float* c2 = c1 + V;
-
-    const float d0 = ld<PRESCALE>(c0, vox, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
-    const float d1 = ld<PRESCALE>(c1, vox, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
-    const float d2 = ld<PRESCALE>(c2, vox, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
-
-    const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
-    const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
-    const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
-
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-#pragma unroll
-    for (int cz = 0; cz < 2; ++cz) {
-#pragma unroll
-        for (int cy = 0; cy < 2; ++cy) {
-            const int64_t rowoff = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W;
-#pragma unroll
-            for (int cx = 0; cx < 2; ++cx) {
-                const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
-                const int64_t idx = rowoff + (cx ? tx.i1 : tx.i0);
-                a0 = __fadd_rn(a0, __fmul_rn(ld<PRESCALE>(c0, idx, sc.nm1[0], sc.rnm1[0], sc.inv_pow), w));
-                a1 = __fadd_rn(a1, __fmul_rn(ld<PRESCALE>(c1, idx, sc.nm1[1], sc.rnm1[1], sc.inv_pow), w));
-                a2 = __fadd_rn(a2, __fmul_rn(ld<PRESCALE>(c2, idx, sc.nm1[2], sc.rnm1[2], sc.inv_pow), w));
-            }
-        }
-    }
-    float* o = dout + (int64_t)chain * 3 * V;
-    o[vox] = __fadd_rn(d0, a0);
-    o[vox + V] = __fadd_rn(d1, a1);
-    o[vox + 2 * V] = __fadd_rn(d2, a2);
-}
 
 static Scale3 make_scale(Vol vol, int no_steps) {
     Scale3 s;
@@ -153,82 +76,6 @@ static Scale3 make_scale(Vol vol, int no_steps) {
     for (int c = 0; c < 3; ++c) s.rnm1[c] = exact_rcp(s.nm1[c]);
     s.inv_pow = 1.0f / (float)(1 << no_steps);
     return s;
-}
-
-void launch_exp_step_fwd(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
-                         hipStream_t st) {
-    const dim3 grid = vox_grid(vol, C);
-    const Scale3 sc = make_scale(vol, no_steps);
-    if (prescale_in) hipLaunchKernelGGL(exp_step_fwd_kernel<true>, grid, dim3(kBlock), 0, st, din, dout, vol, lin, sc);
-    else hipLaunchKernelGGL(exp_step_fwd_kernel<false>, grid, dim3(kBlock), 0, st, din, dout, vol, lin, sc);
-}
-
-// ------------------------------------------------------------------------------------------------
-// adjoint of one squaring step.  Given G = dL/d(d_out):
-//   g(x)      += G(x)                                    (identity path)
-//   g(corner) += w(corner) * G(x)                        (input-gradient of grid_sample: trilinear scatter)
-//   g_j(x)    += gmul_j * sum_c G_c(x) * d(sample_c)/d(i_j)   (grid-gradient; grid = id + d)
-// gout must be zero on entry; every contribution is a float atomic (memory-side on gfx950).
-// ------------------------------------------------------------------------------------------------
-template <bool PRESCALE>
-__global__ __launch_bounds__(kBlock) void exp_step_bwd_kernel(const float* __restrict__ G, const float* __restrict__ dk,
-                                                              float* __restrict__ gout, Vol vol, Lin lin, Scale3 sc) {
-    IRS_VOXEL(vol, chain, x, y, z, vox);
-    const int64_t V = vol.V;
-    const int64_t cb = (int64_t)chain * 3 * V;
-    const float* c0 = dk + cb;
-    const float* c1 = c0 + V;
-    const float* c2 = c1 + V;
-    float* g0 = gout + cb;
-    float* g1 = g0 + V;
-    float* g2 = g1 + V;
-
-    const float G0 = G[cb + vox], G1 = G[cb + V + vox], G2 = G[cb + 2 * V + vox];
-    const float d0 = ld<PRESCALE>(c0, vox, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
-    const float d1 = ld<PRESCALE>(c1, vox, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
-    const float d2 = ld<PRESCALE>(c2, vox, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
-
-    const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
-    const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
-    const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
-
-    float gix = 0.0f, giy = 0.0f, giz = 0.0f;
-#pragma unroll
-    for (int cz = 0; cz < 2; ++cz) {
-#pragma unroll
-        for (int cy = 0; cy < 2; ++cy) {
-            const int64_t rowoff = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W;
-#pragma unroll
-            for (int cx = 0; cx < 2; ++cx) {
-                const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
-                const int64_t idx = rowoff + (cx ? tx.i1 : tx.i0);
-                const float v0 = ld<PRESCALE>(c0, idx, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
-                const float v1 = ld<PRESCALE>(c1, idx, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
-                const float v2 = ld<PRESCALE>(c2, idx, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
-                const float dot = v0 * G0 + v1 * G1 + v2 * G2;
-                gix += (cx ? dot : -dot) * (wy * wz);
-                giy += (cy ? dot : -dot) * (wx * wz);
-                giz += (cz ? dot : -dot) * (wx * wy);
-                const float w = wx * wy * wz;
-                if (w != 0.0f) {
-                    atomicAdd(g0 + idx, w * G0);
-                    atomicAdd(g1 + idx, w * G1);
-                    atomicAdd(g2 + idx, w * G2);
-                }
-            }
-        }
-    }
-    atomicAdd(g0 + vox, G0 + tx.gmul * gix);
-    atomicAdd(g1 + vox, G1 + ty.gmul * giy);
-    atomicAdd(g2 + vox, G2 + tz.gmul * giz);
-}
-
-void launch_exp_step_bwd(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
-                         Lin lin, hipStream_t st) {
-    const dim3 grid = vox_grid(vol, C);
-    const Scale3 sc = make_scale(vol, no_steps);
-    if (prescale_in) hipLaunchKernelGGL(exp_step_bwd_kernel<true>, grid, dim3(kBlock), 0, st, G, dk, gout, vol, lin, sc);
-    else hipLaunchKernelGGL(exp_step_bwd_kernel<false>, grid, dim3(kBlock), 0, st, G, dk, gout, vol, lin, sc);
 }
 
 // ------------------------------------------------------------------------------------------------

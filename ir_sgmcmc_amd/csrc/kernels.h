@@ -27,11 +27,6 @@ int cached_lin(int D, int H, int W, hipStream_t st, Lin* out);
 // ---- field_kernels.hip
 void launch_perturb(const float* v, const float* sigma, const float* eps, float amp, float* out, int C, Vol vol,
                     uint64_t seed, uint64_t iteration, const uint64_t* dev_iteration, hipStream_t st);
-void launch_conv_axis(const float* in, float* out, const Taps& taps, int axis, int CC, Vol vol, hipStream_t st);
-void launch_exp_step_fwd(const float* din, float* dout, bool prescale, int no_steps, int C, Vol vol, Lin lin,
-                         hipStream_t st);
-void launch_exp_step_bwd(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
-                         Lin lin, hipStream_t st);
 void launch_svf_outputs(const float* d, float* transformation, float* displacement, int C, Vol vol, Lin lin,
                         hipStream_t st);
 void launch_warp_fwd(const float* im, int64_t im_stride, const float* d, const float* unif, float alpha, float* out,

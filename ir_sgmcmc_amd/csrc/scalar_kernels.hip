@@ -96,37 +96,44 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
     // fp64 pow / exp / sqrt of sixteen serial updates on one lane were 20 us of every transition)
     const int K = cfg.K;
     const int t = threadIdx.x;
+    // every lane's inputs are staged in shared memory first and the new values are written after a barrier at uniform control
+    // flow: the logit lanes read all K logits, and nothing may overwrite them before every lane has read
+    __shared__ float old_ls[IRS_MAX_COMPONENTS], old_lg[IRS_MAX_COMPONENTS];
+    if (t < K) {
+        old_ls[t] = s->st.gmm_log_std[t];
+        old_lg[t] = s->st.gmm_logits[t];
+    }
+    __syncthreads();
+    float newv = 0.0f;
+    const int k = t < K ? t : t - K;
     if (t < 2 * K) {
         const double n = rs[0], alpha = alpha_s;
         const double* Gs = rs + 5;
         const double* Gl = rs + 5 + IRS_MAX_COMPONENTS;
-        const int k = t < K ? t : t - K;
-        float newv;
         if (t < K) {
             const double sp2 = (double)cfg.scale_prior_scale * (double)cfg.scale_prior_scale;
             // d/dlog_std_k [alpha NLL - log N(log_std; loc, scale)]
-            const double g_ls = alpha * Gs[k] + ((double)s->st.gmm_log_std[k] - (double)cfg.scale_prior_loc) / sp2;
-            newv = (float)adam_step_decay((double)s->st.gmm_log_std[k], g_ls, s->st.gmm_adam_m[0][k], s->st.gmm_adam_v[0][k],
+            const double g_ls = alpha * Gs[k] + ((double)old_ls[k] - (double)cfg.scale_prior_loc) / sp2;
+            newv = (float)adam_step_decay((double)old_ls[k], g_ls, s->st.gmm_adam_m[0][k], s->st.gmm_adam_v[0][k],
                                           s->st.gmm_adam_step[0], cfg.gmm_lr_log_std, cfg.gmm_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
         } else {
             // proportions pi = softmax(logits + 1e-2)
             double mx = -1e300, sum = 0.0, csum = 0.0;
-            for (int j = 0; j < K; ++j) mx = fmax(mx, (double)s->st.gmm_logits[j]);
+            for (int j = 0; j < K; ++j) mx = fmax(mx, (double)old_lg[j]);
             for (int j = 0; j < K; ++j) {
-                sum += exp((double)s->st.gmm_logits[j] - mx);
+                sum += exp((double)old_lg[j] - mx);
                 csum += (double)cfg.conc[j] - 1.0;
             }
-            const double pik = exp((double)s->st.gmm_logits[k] - mx) / sum;
+            const double pik = exp((double)old_lg[k] - mx) / sum;
             // d/dlogit_k [alpha NLL - log Dir(log pi)]
             const double g_lg = alpha * (-Gl[k] + pik * n) + (-((double)cfg.conc[k] - 1.0) + pik * csum);
-            newv = (float)adam_step_decay((double)s->st.gmm_logits[k], g_lg, s->st.gmm_adam_m[1][k], s->st.gmm_adam_v[1][k],
+            newv = (float)adam_step_decay((double)old_lg[k], g_lg, s->st.gmm_adam_m[1][k], s->st.gmm_adam_v[1][k],
                                           s->st.gmm_adam_step[1], cfg.gmm_lr_logits, cfg.gmm_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
         }
-        // every lane has read the old parameters (the logit lanes read all K of them) before any lane writes: one wavefront,
-        // and the writes below come after the reads above in program order for the whole wave
-        if (t < K) s->st.gmm_log_std[k] = newv;
-        else s->st.gmm_logits[k] = newv;
     }
+    __syncthreads();
+    if (t < K) s->st.gmm_log_std[k] = newv;
+    else if (t < 2 * K) s->st.gmm_logits[k] = newv;
     __syncthreads();
     if (t == 0) {
         s->st.gmm_adam_step[0] += 1;

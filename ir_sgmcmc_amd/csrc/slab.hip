@@ -213,6 +213,7 @@ struct Sched {
     std::vector<irs_slab_op> ops;
     int next_id = 0;
 
+    bool want_split_ = true;  // Knobs::slab_split (measurements): no interior / boundary split when false
     bool ffd;   // SVFFD_3D: v / noisy / v_s live on the control grid, whole on every rank; d_0 is the up-sampled DENSE field
     Vol volv;   // the velocity grid (control grid, or the image grid for SVF_3D)
 
@@ -294,7 +295,7 @@ struct Sched {
     void round(bool backward, int xbuf, int w, const int* ks, const int* hs, int m) {
         const int id = exchange(xbuf, w, ks[0]);
         // IRS_SLAB_SPLIT=0 (measurements): no interior / boundary split -- every step one launch after the ghost planes have arrived
-        static const bool want_split = env_int("IRS_SLAB_SPLIT", 1) != 0;
+        const bool want_split = want_split_;
         const bool split = id >= 0 && want_split;
         if (id >= 0 && !want_split) wait(id);
         Vol in[kMaxSteps], bd[kMaxSteps];
@@ -511,8 +512,9 @@ struct Exec {
             case IRS_AR_CPGRAD: buf = c->tmpB; count = (size_t)chains * 3 * c->volv.V; mx = 2; break;
             default: return fail("slab: unknown all-reduce %d", o.stage);
         }
-        // a dedicated event pair per reduction: these results are waited for much later than the exchanges in between
-        hipEvent_t prod = c->sev[16 + 2 * (o.stage % 4)], fin = c->sev[17 + 2 * (o.stage % 4)];
+        // a dedicated event pair per KIND of reduction: these results are waited for much later than the exchanges in between
+        const int slot = o.stage == IRS_AR_MOMENTS ? 5 : o.stage;  // kinds 0 .. 4 and 7
+        hipEvent_t prod = c->sev[16 + 2 * slot], fin = c->sev[17 + 2 * slot];
         HIP_TRY(hipEventRecord(prod, st));
         HIP_TRY(hipStreamWaitEvent(cs, prod, 0));
         if (comm_allreduce(c->comm, buf, count, mx, cs)) return 1;
@@ -742,7 +744,7 @@ irs_io shifted_io(const irs_ctx* c, const irs_io* io) {
 namespace irs {
 void slab_release(irs_ctx* c) {
     if (!c) return;
-    for (int i = 0; i < 24; ++i)
+    for (int i = 0; i < 28; ++i)
         if (c->sev[i]) (void)hipEventDestroy(c->sev[i]);
     if (c->cs) (void)hipStreamDestroy(c->cs);
     if (c->plan_hint) (void)hipHostFree(c->plan_hint);
@@ -781,7 +783,6 @@ int irs_slab_plan_layout(const irs_config* cfg, const irs_slab_config* scfg, int
 int irs_slab_create(const irs_config* cfg, const irs_slab_config* scfg, irs_comm* comm, irs_ctx** out) {
     if (!cfg || !out) return fail("irs_slab_create: null argument");
     const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
-    if (!use_lds_exp()) return fail("irs_slab_create: needs the LDS squaring kernels (IRS_EXP_LDS=1)");
     if (cfg->no_steps > kMaxSteps) return fail("irs_slab_create: at most %d squaring steps", kMaxSteps);
     SlabInfo s;
     if (plan_layout(cfg, scfg, rank, world, &s)) return 1;
@@ -797,7 +798,7 @@ int irs_slab_create(const irs_config* cfg, const irs_slab_config* scfg, irs_comm
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->plan_hint, sizeof(unsigned) * 2 * kHintWords, hipHostMallocDefault);
     if (e == hipSuccess)
         for (int i = 0; i < 2 * kHintWords; ++i) c->plan_hint[i] = (i % kHintWords) < kHintWords - 8 ? 0x7f800000u : 0u;  // +inf: nothing known; flags clear
-    for (int i = 0; i < 24 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->sev[i], hipEventDisableTiming);
+    for (int i = 0; i < 28 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->sev[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         irs_destroy(c);
         return fail("irs_slab_create: stream / event creation failed: %s", hipGetErrorString(e));
@@ -834,7 +835,7 @@ int irs_slab_status_get(irs_ctx* c, irs_slab_status* out, void* stream) {
 static bool plan_widths(irs_ctx* c, Plan& plan) {
     const int n = c->cfg.no_steps;
     plan.n = n;
-    if (!c->have_pred || env_int("IRS_SLAB_EXACT", 0) != 0) return false;
+    if (!c->have_pred || c->kn.slab_exact != 0) return false;
     // Every rank must arrive at the SAME widths (they size the messages both sides of a link post): the source is the
     // all-reduced bounds of transition t - 2, which the caller has just waited for (slot t % 2 of the plan hints; the
     // finalize kernel of t - 1 writes the other slot).  Transition 1 plans from the widths transition 0 measured.
@@ -848,7 +849,7 @@ static bool plan_widths(irs_ctx* c, Plan& plan) {
     // the launch heuristics (which variants to launch) read the same snapshot
     if (fresh) memcpy(c->hint, slot, sizeof(unsigned) * 4 * c->C * (n + 1));
     plan.h[0] = 1;  // |d_0| = |v_s| / 2^n voxels (validated like the others)
-    const int forced = env_int("IRS_SLAB_FORCE_H", 0);  // test hook: a deliberately wrong plan (the validation must catch it)
+    const int forced = c->kn.slab_force_h;  // test hook: a deliberately wrong plan (the validation must catch it)
     if (forced > 0)
         for (int k = 0; k < n; ++k) plan.h[k] = forced;
     return true;
@@ -886,6 +887,7 @@ int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
     ex.stats_vd = cfg.virtual_decimation;
     ex.stats_op = 3;
     Sched sch(s, cfg, C);
+    sch.want_split_ = c->kn.slab_split != 0;
     if (!c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));
     c->dmax_clean = false;
     int energy_ar = -1;

@@ -160,15 +160,15 @@ __global__ __launch_bounds__(kStBlock) void sobolev_march_kernel(const float* __
 
 void launch_sobolev_march(const float* in, float* out, const Taps& taps, int planes, Vol vol, unsigned* dmax0, int no_steps,
                           hipStream_t st) {
-    static const int seg_env = getenv("IRS_SOBOLEV_SEG") ? atoi(getenv("IRS_SOBOLEV_SEG")) : 0;
+    const int seg_env = global_knobs().sobolev_seg;
     const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + 31) / 32) * ((vol.H + 15) / 16) * planes, 8, seg_env);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const float inv_pow = 1.0f / (float)(1 << no_steps);
     // big tiles (64 x 32, eight outputs per thread: 1.33x halo work in the z pass, a quarter of the barriers per output)
     // when they still fill the GPU, 32 x 16 otherwise
     const int64_t big_blocks = (int64_t)((vol.W + 63) / 64) * ((vol.H + 31) / 32) * nseg * planes;
-    const char* force = getenv("IRS_SOBOLEV_TILE");  // "big" / "small": used by the parity test of the two shapes
-    const bool big = force ? force[0] == 'b' : big_blocks >= 512;
+    const int force = global_knobs().sobolev_tile;  // 1 small / 2 big: used by the parity test of the two shapes
+    const bool big = force ? force == 2 : big_blocks >= 512;
     const int tx = big ? 64 : 32, ty = big ? 32 : 16;
     const dim3 grid((vol.W + tx - 1) / tx, (vol.H + ty - 1) / ty, (unsigned)(nseg * planes));
 #define IRS_SOB(SS)                                                                                                        \
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __
 // the LCC kernels re-read 4S planes per segment; measured at 128^3: 8-plane segments (1.5x staging, 4x the workgroups)
 // still beat 16 and 32
 static int lcc_seg_len(Vol vol, int C) {
-    static const int seg_env = getenv("IRS_LCC_SEG") ? atoi(getenv("IRS_LCC_SEG")) : 0;
+    const int seg_env = global_knobs().lcc_seg;
     return pick_seg_len(vol.nz, (int64_t)((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * C, 8, seg_env, 2048);  // measured at 256^3: 2048 workgroups beat 1024
 }
 
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
 
 void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, int blocks,
                         Vol vol, int K, hipStream_t st) {
-    static const int seg_env = getenv("IRS_STATS_SEG") ? atoi(getenv("IRS_STATS_SEG")) : 0;
+    const int seg_env = global_knobs().stats_seg;
     const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + TTY - 1) / TTY), 8, seg_env, 2048);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + TTY - 1) / TTY;
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
 }
 
 static int update_seg_len(Vol vol, int C) {
-    static const int seg_env = getenv("IRS_UPDATE_SEG") ? atoi(getenv("IRS_UPDATE_SEG")) : 0;
+    const int seg_env = global_knobs().update_seg;
     return pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY) * C, 8, seg_env);
 }
 

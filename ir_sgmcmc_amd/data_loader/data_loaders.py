@@ -43,6 +43,8 @@ class BiobankDataLoader(SyntheticDataLoader):
         self.data_dir, self.dataset = data_dir, None
         from .datasets import BiobankDataset
         try:
+            if not data_dir:  # a config without data_dir (None / ''): the same explanatory error or fallback as a missing directory
+                raise FileNotFoundError('no data_dir given')
             self.dataset = BiobankDataset(dims, data_dir, save_dirs, sigma_v_init, u_v_init, cps=cps)
         except (FileNotFoundError, NotADirectoryError) as e:
             if not allow_synthetic_fallback:

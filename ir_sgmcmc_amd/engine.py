@@ -145,6 +145,10 @@ class TransitionEngine:
             except Exception:
                 pass
 
+    def option(self, name, value):
+        """a tuning / test switch of THIS context (include/irsgmcmc.h: irs_option_set)"""
+        L.option_set(name, value, self._ctx)
+
     # ---------------------------------------------------------------- small state
     @property
     def workspace_bytes(self):

@@ -46,7 +46,7 @@ def test_perturb_smooth(dims, s):
 
 
 @pytest.mark.parametrize('s', [1, 2, 3])
-def test_sobolev_tile_shapes(s, monkeypatch):
+def test_sobolev_tile_shapes(s):
     """The Sobolev kernel picks a 64x32 or a 32x16 column tile from the volume size; both must agree with the oracle (and
     with each other bit for bit -- same tap order) on a ragged volume that leaves every tile edge partially filled."""
     dims = (37, 45, 70)
@@ -55,10 +55,14 @@ def test_sobolev_tile_shapes(s, monkeypatch):
     k = G.sobolev_kernel_1d(s, 0.5)
     ref = O.separable_conv3d_replicate(v, k)
     outs = {}
-    for shape in ('small', 'big'):
-        monkeypatch.setenv('IRS_SOBOLEV_TILE', shape)
-        outs[shape] = G.perturb_smooth(dev(v), k)
-        assert maxdiff(outs[shape], ref) < 2e-6
+    from ir_sgmcmc_amd._lib import option_set
+    try:
+        for shape, code in (('small', 1), ('big', 2)):
+            option_set('sobolev_tile', code)   # process-wide switch of the stateless operator (irs_option_set)
+            outs[shape] = G.perturb_smooth(dev(v), k)
+            assert maxdiff(outs[shape], ref) < 2e-6
+    finally:
+        option_set('sobolev_tile', 0)
     assert torch.equal(outs['small'], outs['big'])
 
 
@@ -108,11 +112,11 @@ def test_svf_exp_backward(dims, amp, upstream):
     assert maxdiff(gv, gv_ref) < tol * float(gv_ref.abs().max())
 
 
-def test_svf_exp_backward_large_smooth_displacement(monkeypatch):
+def test_svf_exp_backward_large_smooth_displacement():
     """8-voxel smooth field on several tiles: the last adjoint steps run in the any-radius kernel, whose source boxes are
-    shrunk with the coarse displacement extrema.  Same result with the plain boxes (LDS float atomics: summation order only),
-    with the plain global-atomic kernels, and -- except at the few voxels whose sampling position sits within rounding of a
-    cell boundary, where the CPU and the GPU forward pass pick different cells -- with autograd through the oracle."""
+    shrunk with the coarse displacement extrema.  Same result with the plain boxes (fixed-point accumulation: only the
+    per-tile scale differs), and -- except at the few voxels whose sampling position sits within rounding of a cell boundary,
+    where the CPU and the GPU forward pass pick different cells -- with autograd through the oracle."""
     dims, amp = (40, 36, 44), 9.0
     v = smooth_field(1, dims, amp, 2).requires_grad_(True)
     g_last = smooth_field(1, dims, 1.0, 33)
@@ -123,11 +127,12 @@ def test_svf_exp_backward_large_smooth_displacement(monkeypatch):
     gv = G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last))
     assert torch.equal(gv, G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last)))   # integer accumulation: order-independent
     scale = float(gv_ref.abs().max())
-    monkeypatch.setenv('IRS_COARSE_BOX', '0')
-    assert maxdiff(gv, G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last))) < 2e-6 * scale
-    monkeypatch.delenv('IRS_COARSE_BOX')
-    monkeypatch.setenv('IRS_EXP_LDS', '0')
-    assert maxdiff(gv, G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last))) < 2e-6 * scale
+    from ir_sgmcmc_amd._lib import option_set
+    try:
+        option_set('coarse_box', 0)
+        assert maxdiff(gv, G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last))) < 2e-6 * scale
+    finally:
+        option_set('coarse_box', 1)
     bad = ((gv.cpu() - gv_ref).abs() > GRAD_RTOL * scale).sum()
     assert int(bad) <= 1e-3 * gv_ref.numel()
 

@@ -223,7 +223,7 @@ def test_rccl_transport_single_rank():
         dist.destroy_process_group()
 
 
-def test_misprediction_is_reported(monkeypatch):
+def test_misprediction_is_reported():
     """A plan with ghost zones narrower than the displacement needs (forced here) must not pass silently: the device-side
     validation flags the transition and a later call returns the error -- at the same call on every rank (the verdict about
     transition t is read when t + 2 is planned, after t has finished everywhere)."""
@@ -235,7 +235,7 @@ def test_misprediction_is_reported(monkeypatch):
     eng.gmm_init(fd, md)
     v = eng.local_v(v0)
     eng.transition(fd, md, v)                      # measures: fine
-    monkeypatch.setenv('IRS_SLAB_FORCE_H', '1')    # from now on: plan one plane per step whatever the bounds say
+    eng.option('slab_force_h', 1)                  # from now on: plan one plane per step whatever the bounds say
     eng.transition(fd, md, v)                      # runs with the wrong plan; flagged on the device
     eng.transition(fd, md, v)
     with pytest.raises(IrsError, match='narrower than its displacement'):

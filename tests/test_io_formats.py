@@ -124,6 +124,11 @@ def test_biobank_dataset_pipeline(tmp_path):
     dl = BiobankDataLoader(data_dir=str(tmp_path / 'nowhere'), dims=dims, allow_synthetic_fallback=True)
     (f, m, v), = list(dl)
     assert f['im'].shape == (1, 1, 8, 8, 8) and dl.im_spacing is None
+    # a config WITHOUT data_dir behaves the same: the explanatory error, or the fallback when asked for (not a raw TypeError)
+    with pytest.raises(FileNotFoundError, match='allow_synthetic_fallback'):
+        BiobankDataLoader(data_dir=None, dims=dims)
+    (f, m, v), = list(BiobankDataLoader(data_dir=None, dims=dims, allow_synthetic_fallback=True))
+    assert f['im'].shape == (1, 1, 8, 8, 8)
 
 
 def test_save_sample_layout(tmp_path):
