@@ -208,8 +208,20 @@ int irs_gmm_init(irs_ctx* ctx, const irs_io* io, const float* v_sample, int warm
 /* one SG-MCMC transition.  Asynchronous: nothing is allocated and the DEVICE is never waited for; the host, however, is
  * held back so that it runs at most two transitions ahead of the device (it waits on the end event of the transition before
  * the previous one -- the kernel-variant prediction reads bounds no older than that).  Under stream capture that wait is
- * skipped, so the call stays graph-capturable. */
+ * skipped, so the call stays graph-capturable.  Which variants of the squaring-step kernels get launched is predicted from
+ * the displacement bounds of earlier transitions; the device checks the prediction, and a transition that was launched
+ * without a variant it turned out to need leaves everything untouched and is re-run by a later call (irs_flush). */
 int irs_transition(irs_ctx* ctx, const irs_io* io, void* stream);
+
+/* Wait for everything enqueued on `stream` and complete the chain: a transition whose kernel-variant (or, on a slab, ghost-width)
+ * prediction turned out wrong is a NO-OP on the device -- no parameter, optimiser moment, Philox counter or velocity changes --
+ * and is re-run without predictions by the next irs_transition / irs_slab_transition call; this call re-runs the ones the last
+ * calls left behind (with the irs_io of the most recent call, whose buffers must still be alive).  irs_get_state and
+ * irs_get_scalars call it.  After it, v / state / scalars are those of a chain that never mispredicted.  blocking; collective
+ * on a slab context (every rank reaches the same verdicts at the same call). */
+int irs_flush(irs_ctx* ctx, void* stream);
+/* transitions re-run so far because a prediction failed (statistics) */
+int irs_recovered_transitions(const irs_ctx* ctx, uint64_t* out);
 
 /* timing hook for bench.py: the same transition with hipEvents recorded on `stream` around the stages; blocking.
  * All times in milliseconds for THIS call. */
@@ -323,7 +335,7 @@ enum {  /* launch stages */
     IRS_SG_PERTURB = 0, IRS_SG_COPY_V, IRS_SG_SMOOTH, IRS_SG_ENERGY, IRS_SG_EXP_FWD, IRS_SG_OUTPUTS, IRS_SG_WARP, IRS_SG_RESIDUAL,
     IRS_SG_STATS, IRS_SG_DATA_BWD, IRS_SG_WARP_BWD, IRS_SG_EXP_BWD, IRS_SG_UPDATE, IRS_SG_FFD_UP, IRS_SG_FFD_ADJ,
     IRS_SG_SCALARS = 32,  /* single-workgroup stages from here on (no output window) */
-    IRS_SG_CHAIN_SCALAR = 32, IRS_SG_REG_SCALAR, IRS_SG_FINALIZE
+    IRS_SG_CHAIN_SCALAR = 32, IRS_SG_REG_SCALAR, IRS_SG_FINALIZE, IRS_SG_VERDICT
 };
 enum {  /* buffers */
     IRS_SB_V = 0, IRS_SB_NOISY, IRS_SB_VS, IRS_SB_WARPED, IRS_SB_Z, IRS_SB_GM, IRS_SB_GRAD_A, IRS_SB_GRAD_B,

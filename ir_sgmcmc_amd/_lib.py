@@ -132,6 +132,8 @@ SIGNATURES = {
     'irs_get_scalars': [_P, C.POINTER(IrsScalars), _P],
     'irs_gmm_init': [_P, C.POINTER(IrsIO), _P, _I, _P],
     'irs_transition': [_P, C.POINTER(IrsIO), _P],
+    'irs_flush': [_P, _P],
+    'irs_recovered_transitions': [_P, C.POINTER(C.c_uint64)],
     'irs_transition_timed': [_P, C.POINTER(IrsIO), _P, C.POINTER(IrsTimings)],
     'irs_comm_unique_id': [C.POINTER(C.c_uint8 * IRS_COMM_ID_BYTES)],
     'irs_comm_create_rccl': [C.POINTER(C.c_uint8 * IRS_COMM_ID_BYTES), _I, _I, C.POINTER(_P)],

@@ -523,6 +523,8 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     const size_t o_sums = take(sizeof(double) * (kStatVals + 2 * IRS_MAX_CHAINS));
     const size_t o_dmax = take(sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32);
     const size_t o_cmm = take(coarse_minmax_bytes(c->vol, C));
+    const size_t o_tailc = take(sizeof(unsigned) * (1 + kTailMaxGroups));
+    const size_t o_tailr = take(sizeof(double) * kTailMaxGroups * kStatVals);
     const size_t o_state = take(sizeof(DevState));
     c->slab_bytes = off;
     if (hipMalloc((void**)&c->slab, off) != hipSuccess) {
@@ -530,6 +532,7 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
         return fail("irs_create: hipMalloc of %zu workspace bytes failed", off);
     }
     if (c->sl.on) (void)hipMemset(c->slab, 0, off);  // ghost planes nobody has written yet must hold finite values
+    else (void)hipMemset(c->slab + o_tailc, 0, sizeof(unsigned) * (1 + kTailMaxGroups));  // arrival counters of the tail reductions
     c->steps = (float*)(c->slab + o_steps);
     c->tmpA = (float*)(c->slab + o_tmpA);
     c->tmpB = (float*)(c->slab + o_tmpB);
@@ -551,6 +554,7 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     c->dmax = (unsigned*)(c->slab + o_dmax);
     c->cmm = (float*)(c->slab + o_cmm);
     c->state = (DevState*)(c->slab + o_state);
+    c->tail = TailScratch{(unsigned*)(c->slab + o_tailc), (double*)(c->slab + o_tailr)};
 
     if (ensure_lin_tables(c->lin, D, H, W, nullptr)) {
         (void)hipFree(c->slab);
@@ -636,6 +640,7 @@ int irs_set_fixed(irs_ctx* c, const float* fixed_im, int fixed_chains, void* str
 
 int irs_get_state(irs_ctx* c, irs_state* out, void* stream) {
     if (!c || !out) return fail("irs_get_state: null argument");
+    if (irs_flush(c, stream)) return 1;  // transitions that ended as no-ops are re-run first: the state is final
     HIP_TRY(hipMemcpyAsync(out, &c->state->st, sizeof(irs_state), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return 0;
@@ -652,6 +657,7 @@ int irs_set_state(irs_ctx* c, const irs_state* in, void* stream) {
 
 int irs_get_scalars(irs_ctx* c, irs_scalars* out, void* stream) {
     if (!c || !out) return fail("irs_get_scalars: null argument");
+    if (irs_flush(c, stream)) return 1;
     HIP_TRY(hipMemcpyAsync(out, &c->state->sc, sizeof(irs_scalars), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return 0;
@@ -748,9 +754,9 @@ int irs_gmm_init(irs_ctx* c, const irs_io* io, const float* v_sample, int warm_u
     return 0;
 }
 
-static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int timed) {
-    if (check_io(c, io, "irs_transition")) return 1;
-    if (!io->v) return fail("irs_transition: v is required");
+// One transition, enqueued.  `no_assumptions`: launch every kernel variant (nothing about max|d_k| is assumed, the transition
+// cannot end as a no-op) -- the mode of the re-runs after a failed prediction.
+static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int timed, bool no_assumptions) {
     const irs_config& cfg = c->cfg;
     const int C = c->C;
     const Vol vol = c->vol, volv = c->volv;
@@ -759,24 +765,34 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     float* warped = io->im_moving_warped ? io->im_moving_warped : c->warped;
     float* z = io->residuals ? io->residuals : c->z;
     const uint64_t* it = &c->state->st.iteration;
+    const int saved_mode = c->kn.predict_variants;
+    if (no_assumptions) c->kn.predict_variants = 0;
+    struct Restore {
+        irs_ctx* c;
+        int mode;
+        ~Restore() { c->kn.predict_variants = mode; }
+    } restore{c, saved_mode};
 
-    // Bounded run-ahead: the host may be at most IRS_RUN_AHEAD (default 2) transitions ahead of the device.  The variant
-    // prediction below reads bounds the device published at the end of an earlier transition; a host that has queued twenty
-    // transitions would predict from a state twenty transitions old, and while the displacement is still growing (burn-in)
-    // that mispredicts into the slow always-correct fallbacks.  Two queued transitions keep the device busy all the same.
-    {
-        const int depth = c->kn.run_ahead;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(st, &cap);
-        if (depth > 0 && depth <= 3 && cap == hipStreamCaptureStatusNone && c->n_enqueued >= (uint64_t)depth)
-            HIP_TRY(hipEventSynchronize(c->ra_ev[(c->n_enqueued - depth) % 4]));
+    // Which adjoint variants this transition launches, decided NOW from the bounds the host last saw (never waited for).  The
+    // any-radius LDS-scatter kernel is launched only when the bound of d_k is near 2 voxels; otherwise the (rarely selected)
+    // radius-2 kernel owns everything above one voxel -- through its generic in-kernel fallback if the bound exceeds its ring
+    // after all.  Below 0.4 voxel (2.5x margin) the radius-2 variant is not launched either: that one IS an assumption
+    // (max|d_k| < 1, the radius-1 gather has no fallback), so it goes into the verdict the device evaluates after the forward
+    // pass (scalar_kernels.h: Verdict): if it does not hold the transition is a no-op and is re-run (irs_transition below).
+    bool skip_any[32], skip_r2[32];
+    Verdict vd = no_verdict();
+    vd.bounds = c->dmax;
+    vd.n = cfg.no_steps;
+    vd.C = C;
+    for (int k = 0; k < cfg.no_steps && k < 32; ++k) {
+        skip_any[k] = predicted_below(c, k, 1.5f);
+        skip_r2[k] = skip_any[k] && predicted_tiny(c, k);
+        if (skip_r2[k]) vd.need_lt1 |= 1u << k;
     }
-    if (c->hint && c->hint[kHintWords - 7])
-        return fail("irs_transition: an earlier transition skipped a kernel variant its displacement then needed (results invalid); "
-                    "IRS_PREDICT_VARIANTS=0 launches every variant");
+
     if (timed) HIP_TRY(hipEventRecord(c->ev[0], st));
     // fused backward warp: the forward warp also writes d(warped)/d(d_last) into gA, and the first adjoint squaring step
-    // multiplies it with g_warped while staging (kernels.h: gscale); only on the LDS path, which owns every variant of it
+    // multiplies it with g_warped while staging (kernels.h: gscale)
     const bool fuse_warp_bwd = c->kn.fuse_warp_bwd != 0;
     if (forward_pass(c, io, io->v, true, cfg.uniform_alpha > 0.0f, vs, warped, z, fuse_warp_bwd ? c->gA : nullptr, C, st, timed)) return 1;
     const int64_t field = (int64_t)C * 3 * vol.V;
@@ -785,14 +801,15 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
 
     // regulariser energy -> loss terms, coefficients, hyper-parameter step.  For the L2 family the coefficient (w / 2) does not
     // depend on the energy, so the update kernel produces the energy as a by-product of its stencil and the scalar stage runs
-    // after it (same values in, same order of the hyper-parameter step: the update still sees the w of this transition)
+    // after it, inside the finalize launch (same values in, same order of the hyper-parameter step: the update still sees the
+    // w of this transition)
     const int upd_blocks = sgld_update_blocks_per_chain(volv, C);
     const bool energy_in_update = (cfg.reg_loss == IRS_REG_L2 || cfg.reg_loss == IRS_REG_LOGNORMAL_L2) &&
                                   (int64_t)upd_blocks * C <= (int64_t)kMaxPartialBlocks * IRS_MAX_CHAINS &&
                                   c->kn.energy_in_update != 0;
     if (!energy_in_update) {
         launch_reg_energy(vs, c->energy_partials, C, volv, st);
-        launch_reg_scalar(c->state, c->energy_partials, energy_blocks(volv), c->dcfg, st);
+        launch_reg_scalar(c->state, c->energy_partials, energy_blocks(volv), c->dcfg, st, vd);
     }
 
     // per chain, serially (trainer.py:316-327): VD factor -> GMM step -> data term with the UPDATED mixture
@@ -800,8 +817,10 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     for (int ch = 0; ch < C; ++ch) {
         const uint8_t* mask = io->mask + (io->mask_chains == 1 ? 0 : (int64_t)ch * vol.V);
         const float* zc = z + (int64_t)ch * vol.V;
-        launch_stats(cfg.virtual_decimation, zc, mask, c->state, c->stat_partials, vol, st, c->dcfg.K);
-        launch_chain_scalar(c->state, c->stat_partials, sb, ch, 3, c->dcfg, st);
+        // (the statistics kernel leaves its total in stat_sum: the scalar stage reads one row instead of reducing 2048)
+        const bool tailed = sb <= kTailGroup * kTailMaxGroups;
+        launch_stats(cfg.virtual_decimation, zc, mask, c->state, c->stat_partials, vol, st, c->dcfg.K, c->tail, c->stat_sum);
+        launch_chain_scalar(c->state, tailed ? c->stat_sum : c->stat_partials, tailed ? 1 : sb, ch, ch == 0 ? 7 : 3, c->dcfg, st, vd);  // chain 0: + the verdict
         const float* f = cfg.data_loss == IRS_DATA_GMM_LCC ? c->fhat + (c->fhat_chains == 1 ? 0 : (int64_t)ch * vol.V) : nullptr;
         launch_data_bwd(cfg.data_loss, f, 0, zc, c->sigM + (int64_t)ch * vol.V, mask, 0, nullptr, c->state, ch,
                         c->gM + (int64_t)ch * vol.V, c->nll_partials + (int64_t)ch * c->nll_blocks, cfg.lcc_s, 1, vol, st);
@@ -814,9 +833,8 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     if (timed) HIP_TRY(hipEventRecord(c->ev[3], st));
     const float* dense = c->ffd ? c->dense : vs;
     float* g0 = nullptr;
-    unsigned skipped_r2 = 0;  // steps whose radius-2 adjoint variant is not launched (validated by the finalize kernel)
     {
-        // exp_backward ping-pongs between two buffers; the incoming gradient sits in gA, so start writing into gB
+        // the adjoint ping-pongs between two buffers; the incoming gradient sits in gA, so start writing into gB
         const float* G = c->gA;
         float* bufs[2] = {c->gB, c->gA};
         int cur = 0;
@@ -827,19 +845,14 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
             const unsigned* dm = c->dmax + (int64_t)k * C * 4;
             // fused backward warp: gA holds d(warped)/d(d_last); the first step scales it by g_warped while staging
             const float* gscale = fuse_warp_bwd && k == cfg.no_steps - 1 ? c->gM : nullptr;
-            // timed mode: the end event of step k closes right after the radius-1 kernel, so that exp_bwd_kernel_ms is
-            // the time of the dominant kernel alone (as rocprofv3 reports it), not of the idle variants after it
-            // the any-radius LDS-scatter kernel is launched only when the bound of d_k, as last seen by the host, is near
-            // 2 voxels; otherwise the (rarely selected) radius-2 kernel owns everything above one voxel -- through its
-            // generic in-kernel fallback if the bound exceeds its ring after all
-            const bool skip_any = predicted_below(c, k, 1.5f);
-            const bool skip_r2 = skip_any && k < 32 && predicted_tiny(c, k);
-            if (skip_r2) skipped_r2 |= 1u << k;
             // with the fused backward warp the first step's incoming gradient is the interleaved d(warped)/d(d_n)
             const int lay = bwd_lay(c, k) | (gscale ? 2 : 0);
-            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, skip_r2 ? 1 : 2, skip_any, gscale, lay,
+            const bool sa = k < 32 && skip_any[k], s2 = k < 32 && skip_r2[k];
+            // timed mode: the end event of step k closes right after the radius-1 kernel, so that exp_bwd_kernel_ms is the time
+            // of the dominant kernel alone (as rocprofv3 reports it), not of the idle variants after it
+            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, s2 ? 1 : 2, sa, gscale, lay,
                                       timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
-            if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, 2, gscale, lay, c->cmm, st);
+            if (!sa) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, 2, gscale, lay, c->cmm, st);
             G = out;
             cur ^= 1;
         }
@@ -859,9 +872,8 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
         launch_sgld_update(io->v, io->sigma, g0, vs, c->state, cfg.lr, s[0], s[1], s[2], io->grad_v, C, volv, st,
                            energy_in_update ? c->energy_partials : nullptr, energy_in_update);
     }
-    if (energy_in_update) launch_reg_scalar(c->state, c->energy_partials, upd_blocks, c->dcfg, st);
-    launch_finalize(c->state, c->nll_partials, c->nll_blocks, c->dcfg, true, c->dmax, c->hint,
-                    4 * C * (cfg.no_steps + 1), skipped_r2, kHintWords - 7, true, st);
+    launch_finalize(c->state, c->nll_partials, c->nll_blocks, c->dcfg, true, c->dmax, c->hint, 4 * C * (cfg.no_steps + 1), vd,
+                    kHintWords - 7, true, st, energy_in_update ? c->energy_partials : nullptr, upd_blocks);
     c->dmax_clean = true;
     LAUNCH_CHECK();
     if (timed) HIP_TRY(hipEventRecord(c->ev[5], st));
@@ -870,6 +882,75 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
     return 0;
 }
 
+// failed (no-op) transitions the device has reported since the host last looked -> transitions to re-run
+static void poll_failures(irs_ctx* c) {
+    if (!c->hint) return;
+    const unsigned f = ((volatile unsigned*)c->hint)[kHintWords - 7];
+    if (f == c->fails_seen) return;
+    c->makeup += (uint64_t)(f - c->fails_seen);
+    c->fails_total += (uint64_t)(f - c->fails_seen);
+    c->fails_seen = f;
+    // the bounds that misled the prediction are still the ones the host sees: no assumptions for the next few transitions
+    c->force_all_until = c->n_enqueued + c->makeup + 3;
+}
+
+static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int timed) {
+    if (check_io(c, io, "irs_transition")) return 1;
+    if (!io->v) return fail("irs_transition: v is required");
+    // Bounded run-ahead: the host may be at most IRS_RUN_AHEAD (default 2) transitions ahead of the device.  The variant
+    // prediction reads bounds the device published at the end of an earlier transition; a host that has queued twenty
+    // transitions would predict from a state twenty transitions old, and while the displacement is still growing (burn-in)
+    // that mispredicts into the slow always-correct fallbacks.  Two queued transitions keep the device busy all the same.
+    {
+        const int depth = c->kn.run_ahead;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (depth > 0 && depth <= 3 && cap == hipStreamCaptureStatusNone && c->n_enqueued >= (uint64_t)depth)
+            HIP_TRY(hipEventSynchronize(c->ra_ev[(c->n_enqueued - depth) % 4]));
+    }
+    // A transition whose assumptions about max|d_k| failed was a no-op on the device (nothing changed, the Philox counter did
+    // not advance): it is re-run here, without assumptions, before the transition of this call -- the chain continues as if
+    // every variant had been launched all along (same noise, same order; with injected eps / unif the re-run uses THIS call's).
+    poll_failures(c);
+    if (c->makeup && !c->kn.recover)
+        return fail("irs_transition: an earlier transition skipped a kernel variant its displacement then needed and was dropped "
+                    "(recover = 0); predict_variants = 0 launches every variant");
+    while (c->makeup > 0) {
+        --c->makeup;
+        if (enqueue_transition(c, io, st, 0, true)) return 1;
+    }
+    c->last_io = *io;
+    c->have_last_io = true;
+    return enqueue_transition(c, io, st, timed, c->n_enqueued < c->force_all_until);
+}
+
+// wait for everything enqueued, then re-run what failed (with the io of the last call); afterwards state, scalars and v are final
+static int flush_impl(irs_ctx* c, hipStream_t st) {
+    for (int guard = 0; guard < 8; ++guard) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c->n_enqueued) HIP_TRY(hipEventSynchronize(c->ra_ev[(c->n_enqueued - 1) % 4]));
+        poll_failures(c);
+        if (!c->makeup) return 0;
+        if (!c->kn.recover || !c->have_last_io) return fail("irs_flush: %llu transition(s) were dropped after a failed variant prediction", (unsigned long long)c->makeup);
+        while (c->makeup > 0) {
+            --c->makeup;
+            if (enqueue_transition(c, &c->last_io, st, 0, true)) return 1;
+        }
+    }
+    return fail("irs_flush: transitions keep failing");
+}
+
+int irs_flush(irs_ctx* c, void* stream) {
+    if (!c) return fail("irs_flush: null argument");
+    if (c->sl.on) return irs::slab_flush(c, (hipStream_t)stream);
+    return flush_impl(c, (hipStream_t)stream);
+}
+
+int irs_recovered_transitions(const irs_ctx* c, uint64_t* out) {
+    if (!c || !out) return fail("irs_recovered_transitions: null argument");
+    *out = c->fails_total;
+    return 0;
+}
 
 int irs_transition(irs_ctx* c, const irs_io* io, void* stream) { return transition_impl(c, io, (hipStream_t)stream, 0); }
 

@@ -60,6 +60,7 @@ struct irs_ctx {
     unsigned* hint = nullptr;  // pinned host copy of dmax as of the last finished transition (written by finalize_kernel, read
                      // by the host WITHOUT synchronisation: a hint that only decides which variants are launched)
     irs::DevState* state;
+    irs::TailScratch tail;  // arrival counters + group rows of the in-kernel tail reductions (common.h)
     int fhat_chains;
     bool fixed_set;
     int nll_blocks;
@@ -69,6 +70,14 @@ struct irs_ctx {
     uint64_t n_enqueued = 0;
     irs::Knobs kn;            // copy of the process-wide switches, taken by irs_create (irs_option_set changes it)
     bool dmax_clean = false;  // the bound scratch was cleared by the finalize kernel of the last transition
+    // ---- recovery from failed variant / ghost-width predictions (scalar_kernels.h: Verdict)
+    unsigned fails_seen = 0;        // DevState::fails as of the last look
+    uint64_t makeup = 0;            // failed (no-op) transitions still to be re-run
+    uint64_t fails_total = 0;       // statistics
+    uint64_t force_all_until = 0;   // transitions enqueued before this count make no assumptions
+    uint64_t exact_until = 0;       // slab: transitions enqueued before this count measure their ghost widths
+    irs_io last_io;                 // the io of the last irs_transition call (irs_flush re-runs with it)
+    bool have_last_io = false;
     // ---- z-slab decomposition (slab.hip)
     irs::SlabInfo sl;
     irs_comm* comm = nullptr;      // not owned
@@ -97,7 +106,7 @@ constexpr int kHintWords = 4 * IRS_MAX_CHAINS * 32 + 8;  // dmax scratch + [flag
 // decision: the kernels that remain are correct for any displacement, so a wrong guess costs time, not parity.
 inline bool predicted_below(const irs_ctx* c, int k, float bound) {
     const int mode = c->kn.predict_variants;
-    if (mode == 2) return true;
+    if (mode == 2 || mode == 3) return true;
     if (!mode || !c->hint) return false;
     const volatile unsigned* h = c->hint + (size_t)k * c->C * 4;
     float m = 0.0f;
@@ -116,7 +125,9 @@ inline bool predicted_small(const irs_ctx* c, int k) { return predicted_below(c,
 // from the production heuristic only, with a 2.5x margin -- d_k moves by O(0.1) voxel per transition and the host is at most
 // two transitions behind -- and (b) VALIDATED on the device: finalize_kernel compares the bounds of the steps whose variant
 // was skipped with 1 and raises a sticky flag that the next irs_transition returns as an error.
-inline bool predicted_tiny(const irs_ctx* c, int k) { return c->kn.predict_variants == 1 && predicted_below(c, k, 0.4f); }
+inline bool predicted_tiny(const irs_ctx* c, int k) {
+    return c->kn.predict_variants == 3 || (c->kn.predict_variants == 1 && predicted_below(c, k, 0.4f));  // 3: test hook, always
+}
 
 // Layouts of the INTERNAL fields of the fused path (exp_kernels.hip: Lay3; bits 1 displacement in, 2 gradient in, 4 out):
 // d_1 .. d_{n-1} and the gradients handed from one adjoint step to the next are interleaved ([V][3]); everything that crosses
@@ -138,6 +149,7 @@ inline void prescale_factors(Vol vol, int no_steps, float s[3]) {
 int create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out);
 int check_io(const irs_ctx* c, const irs_io* io, const char* who);
 void slab_release(irs_ctx* c);  // slab.hip
+int slab_flush(irs_ctx* c, hipStream_t st);  // slab.hip
 // cubic B-spline FFD up-sampling / adjoint over the three axes (api.hip); the window arguments are for slab-local dense arrays
 int ffd_up(const float* v_cp, float* dense, float* tmp, int C, Vol vol, const int G[3], const SplineTaps spl[3], hipStream_t st,
            int w_lo = 0, int w_n = -1, int store_lo = 0, int store_n = -1);

@@ -2,6 +2,8 @@
 // reference's host-side scalar autograd (trainer.py:68-77, 316-339; optimizers/adam_rate_decay.py) so that a
 // whole transition runs without a host round trip (the reference syncs at trainer.py:308).
 #pragma once
+#include <string.h>
+
 #include "common.h"
 
 namespace irs {
@@ -20,7 +22,41 @@ struct DevState {
     irs_scalars sc;
     double coef[IRS_MAX_CHAINS];  // d(reg loss)/d(energy) per chain, consumed by the update kernel
     double moments[3];            // scratch: n, sum z, sum z^2 (GMM initialisation)
+    unsigned bad_now;             // verdict about the transition in flight (Verdict below), written by the first scalar stage
+    unsigned fails;               // transitions that ended as no-ops because an assumption about max|d_k| did not hold
 };
+
+// What the launch sequence of the transition in flight ASSUMED about the displacement bounds max|d_k| (decided on the host from
+// bounds of earlier transitions, never waited for).  Every kernel that modifies persistent state -- the mixture and regulariser
+// Adam steps, the velocity update, the Philox counter -- checks the assumptions against the bounds the forward pass has just
+// measured; if one does not hold the transition becomes a NO-OP (no parameter, moment, counter or velocity changes), the
+// failure is counted, and the host re-runs the transition without assumptions when it sees the count (api.hip / slab.hip).
+struct Verdict {
+    const unsigned* bounds;    // [steps + 1][C][4] max|d_k| per chain and axis (float bits); nullptr: nothing assumed
+    int n, C;                  // squaring steps, chains
+    unsigned need_lt1;         // bit k: step k only ran in a form that needs max|d_k| < 1 voxel (radius-1 kernels without fallback)
+    unsigned char width[32];   // slab: planned ghost width of step k (0: not planned) -- needs floor(max|d_k|) + 1 <= width
+};
+inline Verdict no_verdict() {
+    Verdict v;
+    memset(&v, 0, sizeof(v));
+    return v;
+}
+
+// uniform over the block; every thread must call (one barrier)
+__device__ __forceinline__ bool verdict_bad(const Verdict& v) {
+    int bad = 0;
+    if (v.bounds) {
+        const int per = 4 * v.C;
+        for (int i = threadIdx.x; i < v.n * per; i += blockDim.x) {
+            const int k = i / per;
+            const float m = __uint_as_float(v.bounds[i]);
+            if (k < 32 && ((v.need_lt1 >> k) & 1u) && !(m < 1.0f)) bad = 1;
+            if (k < 32 && v.width[k] && (!(m >= 0.0f) || (int)floorf(m) + 1 > (int)v.width[k])) bad = 1;
+        }
+    }
+    return __syncthreads_or(bad) != 0;
+}
 
 struct DevCfg {
     int K, mode, vd, C;
@@ -94,15 +130,18 @@ __device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict_
 }
 
 void launch_refresh_derived(DevState* s, DevCfg cfg, hipStream_t st);
-// op bit 0: recompute the VD factor alpha; bit 1: take one GMM Adam step (with the stored alpha)
+// op bit 0: recompute the VD factor alpha; bit 1: take one GMM Adam step (with the stored alpha); bit 2: evaluate the verdict
+// about the transition in flight into DevState::bad_now (the first scalar stage of a transition; the others read it)
 void launch_chain_scalar(DevState* s, const double* stat_partials, int nblocks, int chain, int op, DevCfg cfg,
-                         hipStream_t st);
-void launch_reg_scalar(DevState* s, const double* energy_partials, int nblocks, DevCfg cfg, hipStream_t st);
-// `skipped`: bit k set = the radius-2 adjoint variant of step k was not launched (ctx.h: predicted_tiny); a bound >= 1 voxel
-// on such a step raises hint[flag_word] (sticky).  `zero_bounds`: clear the bound scratch for the next transition.
+                         hipStream_t st, Verdict vd = no_verdict());
+void launch_reg_scalar(DevState* s, const double* energy_partials, int nblocks, DevCfg cfg, hipStream_t st,
+                       Verdict vd = no_verdict());
+// Publishes the bounds of this transition and the cumulative count of failed (no-op) transitions (hint[flag_word]) to pinned
+// host memory; advances the Philox counter unless the verdict is bad.  `zero_bounds`: clear the bound scratch for the next
+// transition.  `reg_partials` (optional): the regulariser scalar stage runs first, in the same launch (energy from the update).
 void launch_finalize(DevState* s, const double* nll_partials, int nblocks_per_chain, DevCfg cfg, bool advance,
-                     unsigned* bounds, unsigned* hint, int nbounds, unsigned skipped, int flag_word, bool zero_bounds,
-                     hipStream_t st);
+                     unsigned* bounds, unsigned* hint, int nbounds, Verdict vd, int flag_word, bool zero_bounds,
+                     hipStream_t st, const double* reg_partials = nullptr, int reg_blocks = 0);
 void launch_gmm_init_from_moments(DevState* s, const double* moment_partials, int nblocks, DevCfg cfg, hipStream_t st);
 
 }  // namespace irs

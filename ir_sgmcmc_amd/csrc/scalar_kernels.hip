@@ -66,8 +66,16 @@ void launch_refresh_derived(DevState* s, DevCfg cfg, hipStream_t st) {
 // per chain: VD factor (utils/util.py:446-485) and one _step_GMM (trainer.py:68-77)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const double* __restrict__ partials,
-                                                              int nblocks, int chain, int op, DevCfg cfg) {
+                                                              int nblocks, int chain, int op, DevCfg cfg, Verdict vd) {
     __shared__ double smem[kStatVals * (kBlock / kWave)];
+    // the first scalar stage of a transition evaluates the verdict (scalar_kernels.h); a bad one freezes every parameter
+    bool bad;
+    if (op & 4) {
+        bad = verdict_bad(vd);
+        if (threadIdx.x == 0) s->bad_now = bad ? 1u : 0u;
+    } else {
+        bad = vd.bounds != nullptr && s->bad_now != 0u;
+    }
     __shared__ double rs[kStatVals];
     __shared__ double alpha_s;
     double r[kStatVals];
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
         for (int j = 0; j < kStatVals; ++j) rs[j] = r[j];
     }
     __syncthreads();
-    if (!(cfg.mode == IRS_DATA_GMM_LCC && (op & 2))) return;
+    if (!(cfg.mode == IRS_DATA_GMM_LCC && (op & 2)) || bad) return;
     // one GMM Adam step (trainer.py:68-77), one lane per parameter: lanes 0 .. K-1 the log std, K .. 2K-1 the logits (the
     // fp64 pow / exp / sqrt of sixteen serial updates on one lane were 20 us of every transition)
     const int K = cfg.K;
@@ -143,16 +151,16 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
 }
 
 void launch_chain_scalar(DevState* s, const double* stat_partials, int nblocks, int chain, int op, DevCfg cfg,
-                         hipStream_t st) {
-    hipLaunchKernelGGL(chain_scalar_kernel, dim3(1), dim3(kBlock), 0, st, s, stat_partials, nblocks, chain, op, cfg);
+                         hipStream_t st, Verdict vd) {
+    hipLaunchKernelGGL(chain_scalar_kernel, dim3(1), dim3(kBlock), 0, st, s, stat_partials, nblocks, chain, op, cfg, vd);
 }
 
 // ------------------------------------------------------------------------------------------------
 // regulariser: energies -> loss terms, d(loss)/d(energy) coefficients, Adam step on its hyper-parameters
 // energy_partials: [C][nblocks]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void reg_scalar_kernel(DevState* s, const double* __restrict__ partials,
-                                                            int nblocks, DevCfg cfg) {
+// all threads of the block call; `bad`: the transition is a no-op, the hyper-parameters and their moments stay as they are
+__device__ void reg_scalar_body(DevState* s, const double* __restrict__ partials, int nblocks, const DevCfg& cfg, bool bad) {
     __shared__ double smem[kBlock / kWave];
     __shared__ double ysh[IRS_MAX_CHAINS];
     for (int c = 0; c < cfg.C; ++c) {
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void reg_scalar_kernel(DevState* s, const d
             s->coef[c] = 0.5 * w;
             g_lw += 0.5 * w * y - 0.5 * dof;
         }
-        if (cfg.reg_learnable) {
+        if (cfg.reg_learnable && !bad) {
             // minus LogPrecisionExpGammaPrior(log w): d/dx [shape log rate + (shape-1) x - rate e^x - lgamma + x]
             g_lw -= cfg.w_reg_prior_shape - cfg.w_reg_prior_rate * w;
             const int64_t st0 = s->st.reg_adam_step[0];
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void reg_scalar_kernel(DevState* s, const d
             g_loc += -u / sc;
             g_ls += 1.0 - u * u;
         }
-        if (cfg.reg_learnable) {
+        if (cfg.reg_learnable && !bad) {
             const double ps = (double)cfg.reg_scale_prior_scale;
             g_ls += (ls - (double)cfg.reg_scale_prior_loc) / (ps * ps);  // minus LogScaleNormalPrior(log_scale)
             const int64_t st0 = s->st.reg_adam_step[0], st1 = s->st.reg_adam_step[1];
@@ -234,29 +242,36 @@ __global__ __launch_bounds__(kBlock) void reg_scalar_kernel(DevState* s, const d
     }
 }
 
-void launch_reg_scalar(DevState* s, const double* energy_partials, int nblocks, DevCfg cfg, hipStream_t st) {
-    hipLaunchKernelGGL(reg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, s, energy_partials, nblocks, cfg);
+__global__ __launch_bounds__(kBlock) void reg_scalar_kernel(DevState* s, const double* __restrict__ partials, int nblocks,
+                                                            DevCfg cfg, Verdict vd) {
+    const bool bad = verdict_bad(vd);  // (this stage may run before the first chain's scalar stage)
+    reg_scalar_body(s, partials, nblocks, cfg, bad);
 }
 
-// data_term[c] = alpha_c * sum(-log p(z_c)) with the parameters in force for chain c; advance the Philox counter
+void launch_reg_scalar(DevState* s, const double* energy_partials, int nblocks, DevCfg cfg, hipStream_t st, Verdict vd) {
+    hipLaunchKernelGGL(reg_scalar_kernel, dim3(1), dim3(kBlock), 0, st, s, energy_partials, nblocks, cfg, vd);
+}
+
+// data_term[c] = alpha_c * sum(-log p(z_c)) with the parameters in force for chain c; advance the Philox counter; publish
+// the bounds and the count of failed transitions.  Optionally the regulariser scalar stage first (one launch less).
 __global__ __launch_bounds__(kBlock) void finalize_kernel(DevState* s, const double* __restrict__ partials,
                                                           int nblocks_per_chain, DevCfg cfg, int advance,
                                                           unsigned* __restrict__ bounds, unsigned* __restrict__ hint,
-                                                          int nbounds, unsigned skipped, int flag_word, int zero_bounds) {
+                                                          int nbounds, Verdict vd, int flag_word, int zero_bounds,
+                                                          const double* __restrict__ reg_partials, int reg_blocks) {
     __shared__ double smem[kBlock / kWave];
+    const bool bad = verdict_bad(vd);
+    if (reg_partials) {
+        reg_scalar_body(s, reg_partials, reg_blocks, cfg, bad);
+        __syncthreads();
+    }
     // publish the displacement bounds of this transition to pinned host memory (the host reads them unsynchronised, as a
     // hint for which kernel variants to launch next time)
     if (bounds && hint) {
-        unsigned bad = 0;
         for (int i = threadIdx.x; i < nbounds; i += kBlock) {
-            const unsigned b = bounds[i];
-            hint[i] = b;
-            // a step whose radius-2 adjoint variant was not launched must have stayed below one voxel
-            const int k = i / (4 * cfg.C);
-            if (k < 32 && ((skipped >> k) & 1u) && !(__uint_as_float(b) < 1.0f)) bad = 1;
+            hint[i] = bounds[i];
             if (zero_bounds) bounds[i] = 0u;
         }
-        if (bad) atomicAdd(hint + flag_word, 1u);
     }
     for (int c = 0; c < cfg.C; ++c) {
         double acc[1] = {0.0};
@@ -265,14 +280,18 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(DevState* s, const dou
         if (threadIdx.x == 0) s->sc.data_term[c] = s->sc.alpha[c] * acc[0];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && advance) s->st.iteration += 1;
+    if (threadIdx.x == 0) {
+        if (bad) s->fails += 1u;
+        else if (advance) s->st.iteration += 1;
+        if (hint) hint[flag_word] = s->fails;  // cumulative: the host compares it with the count it has already acted on
+    }
 }
 
 void launch_finalize(DevState* s, const double* nll_partials, int nblocks_per_chain, DevCfg cfg, bool advance,
-                     unsigned* bounds, unsigned* hint, int nbounds, unsigned skipped, int flag_word, bool zero_bounds,
-                     hipStream_t st) {
+                     unsigned* bounds, unsigned* hint, int nbounds, Verdict vd, int flag_word, bool zero_bounds,
+                     hipStream_t st, const double* reg_partials, int reg_blocks) {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, st, s, nll_partials, nblocks_per_chain, cfg,
-                       advance ? 1 : 0, bounds, hint, nbounds, skipped, flag_word, zero_bounds ? 1 : 0);
+                       advance ? 1 : 0, bounds, hint, nbounds, vd, flag_word, zero_bounds ? 1 : 0, reg_partials, reg_blocks);
 }
 
 // GMM.init_parameters (model/loss.py:61-65) from the unbiased std of the masked residuals (trainer.py:537-541)

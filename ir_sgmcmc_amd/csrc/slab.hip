@@ -184,22 +184,6 @@ int exchange_planes(irs_ctx* c, float* virt, int kind, int chains, int w, hipStr
     return 0;
 }
 
-// validation of the planned ghost widths against the (all-reduced) bounds of this transition; sticky flag in pinned memory
-struct Used {
-    int h[kMaxSteps];
-};
-__global__ void validate_widths_kernel(const unsigned* __restrict__ dmax, Used used, int n, int C, unsigned* __restrict__ flags) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned bad = 0;
-    for (int k = 0; k < n; ++k) {
-        if (used.h[k] <= 0) continue;  // measured on the fly: nothing planned to validate
-        float m = 0.0f;
-        for (int i = 0; i < C * 4; ++i) m = fmaxf(m, __uint_as_float(dmax[k * C * 4 + i]));
-        if (!(m >= 0.0f) || (int)floorf(m) + 1 > used.h[k]) bad = 1;
-    }
-    flags[0] = bad;  // (per transition: the slot of the plan hints this transition publishes into)
-}
-
 // ================================================================================================
 // The schedule of a transition as DATA: a pure-host builder emits a list of operations (launches with their output windows,
 // exchanges, all-reduces, the waits that tie the two streams together); the executor below interprets it on the GPU, and
@@ -383,17 +367,23 @@ struct Sched {
         const int n = cfg.no_steps, ls = cfg.data_loss == IRS_DATA_GMM_LCC ? cfg.lcc_s : 0;
         // bounds of every d_k, all-reduced: variant selection of the adjoint steps, the next plans, the validation of this one
         const int dmax_ar = allreduce(IRS_AR_DMAX);
+        // The first scalar stage evaluates the verdict about this transition's ghost-width plan from the all-reduced bounds
+        // (every rank arrives at the same one); the bounds travel on the communication stream ahead of the statistics.
+        if (!stats) {
+            wait(dmax_ar);
+            launch(IRS_SG_VERDICT, 0, W(0), -1, -1, 0, -1);
+        }
         for (int ch = 0; ch < chains; ++ch) {
             if (stats) {
                 launch(IRS_SG_STATS, ch, W(0), IRS_SB_Z, -1, cfg.virtual_decimation ? 1 : 0, -1);
                 wait(allreduce(IRS_AR_STATS));
+                if (ch == 0) wait(dmax_ar);
                 launch(IRS_SG_CHAIN_SCALAR, ch, W(0), -1, -1, 0, -1);
             }
             launch(IRS_SG_DATA_BWD, ch, W(0), IRS_SB_Z, -1, 2 * ls, IRS_SB_GM);
         }
         const int nll_ar = allreduce(IRS_AR_NLL);
         launch(IRS_SG_WARP_BWD, 0, W(0), IRS_SB_GM, step_buf_id(n - 1), 0, IRS_SB_GRAD_A);
-        wait(dmax_ar);
         for (int r = 0; r < p.nb; ++r) {
             int ks[kMaxSteps], hs[kMaxSteps], m = 0;
             for (int k = n - 1; k >= 0; --k)
@@ -464,6 +454,17 @@ struct Exec {
         }
     }
     int cur_bwd_k = -1;  // the adjoint step whose input buffer an exchange is about to carry
+    // the planned ghost widths as assumptions the device validates (scalar_kernels.h: Verdict); nothing planned -> nothing assumed
+    Verdict verdict() const {
+        Verdict vd = no_verdict();
+        if (!plan || !planned_) return vd;
+        vd.bounds = c->dmax;
+        vd.n = c->cfg.no_steps;
+        vd.C = c->C;
+        for (int k = 0; k < vd.n && k < 32; ++k) vd.width[k] = (unsigned char)(plan->h[k] > 255 ? 255 : plan->h[k]);
+        return vd;
+    }
+    bool planned_ = false;  // the widths come from a prediction (not measured by this transition)
 
     int run(const irs_slab_op* ops, int n_ops) {
         for (int i = 0; i < n_ops; ++i) {
@@ -594,12 +595,15 @@ struct Exec {
                 break;
             case IRS_SG_STATS: {
                 const uint8_t* mask = io.mask + (io.mask_chains == 1 ? 0 : (int64_t)o.k * c->vol.V);
-                launch_stats(stats_vd, z + (int64_t)o.k * c->vol.V, mask, c->state, c->stat_partials, w, st, c->dcfg.K);
-                launch_reduce_cols(c->stat_partials, stats_blocks(w), kStatVals, c->stat_sum, st);
+                // (the total is formed by the kernel's last blocks: no reduction launch)
+                launch_stats(stats_vd, z + (int64_t)o.k * c->vol.V, mask, c->state, c->stat_partials, w, st, c->dcfg.K, c->tail, c->stat_sum);
                 break;
             }
             case IRS_SG_CHAIN_SCALAR:
-                launch_chain_scalar(c->state, c->stat_sum, 1, o.k, stats_op, c->dcfg, st);
+                launch_chain_scalar(c->state, c->stat_sum, 1, o.k, stats_op | (o.k == 0 && in_transition ? 4 : 0), c->dcfg, st, in_transition ? verdict_always() : no_verdict());
+                break;
+            case IRS_SG_VERDICT:  // no statistics stage in this configuration: the verdict alone
+                launch_chain_scalar(c->state, c->stat_sum, 1, 0, 4, c->dcfg, st, verdict_always());
                 break;
             case IRS_SG_DATA_BWD: {
                 const int ch = o.k;
@@ -634,7 +638,7 @@ struct Exec {
                 break;
             }
             case IRS_SG_REG_SCALAR:
-                launch_reg_scalar(c->state, c->energy_sum, 1, c->dcfg, st);
+                launch_reg_scalar(c->state, c->energy_sum, 1, c->dcfg, st, verdict_always());
                 break;
             case IRS_SG_UPDATE: {
                 float sc3[3];
@@ -643,22 +647,30 @@ struct Exec {
                 else launch_sgld_update(io.v, io.sigma, planar(grad_raw(c, 0, false), v), vs, c->state, cfg.lr, sc3[0], sc3[1], sc3[2], io.grad_v, C, w, st);
                 break;
             }
-            case IRS_SG_FINALIZE: {
-                Used used;
-                for (int k = 0; k < kMaxSteps; ++k) used.h[k] = plan && k < n ? plan->h[k] : 0;
-                hipLaunchKernelGGL(validate_widths_kernel, dim3(1), dim3(64), 0, st, c->dmax, used, n, c->C,
-                                   c->plan_hint + (c->n_enqueued % 2) * kHintWords + (kHintWords - 8));
+            case IRS_SG_FINALIZE:
+                // bounds + the cumulative count of failed (no-op) transitions into the plan-hint slot of this transition
                 launch_finalize(c->state, c->nll_sum, 1, c->dcfg, true, c->dmax, c->plan_hint + (c->n_enqueued % 2) * kHintWords,
-                                4 * c->C * (n + 1), 0u, 0, true, st);
+                                4 * c->C * (n + 1), verdict_always(), kHintWords - 8, true, st);
                 c->dmax_clean = true;
                 break;
-            }
             default:
                 return fail("slab: unknown stage %d", o.stage);
         }
         return 0;
     }
     int stats_vd = 0, stats_op = 3;
+    bool in_transition = false;  // (the mixture initialisation runs the same stages without a verdict)
+    // the stages that read DevState::bad_now need it written by THIS transition: a transition without a plan passes an empty
+    // assumption set with valid bounds, whose verdict is "fine"
+    Verdict verdict_always() const {
+        Verdict vd = verdict();
+        if (!vd.bounds) {
+            vd.bounds = c->dmax;
+            vd.n = 0;
+            vd.C = c->C;
+        }
+        return vd;
+    }
 };
 
 // validation of the planned ghost widths against the (all-reduced) bounds of this transition; sticky flag in pinned memory
@@ -824,8 +836,9 @@ int irs_slab_status_get(irs_ctx* c, irs_slab_status* out, void* stream) {
     out->exact_transitions = c->slab_exact;
     out->exchanges = c->slab_exchanges;
     out->exchanged_bytes = c->slab_exchanged_bytes;
-    // (all enqueued transitions have finished: both slots are final)
-    out->mispredictions = c->slab_mispredictions + c->plan_hint[kHintWords - 8] + c->plan_hint[kHintWords + kHintWords - 8];
+    // (all enqueued transitions have finished: both slots are final; cumulative counts)
+    const unsigned f0 = c->plan_hint[kHintWords - 8], f1 = c->plan_hint[kHintWords + kHintWords - 8], fmax = f0 > f1 ? f0 : f1;
+    out->mispredictions = c->slab_mispredictions + (fmax > c->fails_seen ? fmax - c->fails_seen : 0);
     out->last_fwd_rounds = c->last_nf;
     out->last_bwd_rounds = c->last_nb;
     return 0;
@@ -855,30 +868,19 @@ static bool plan_widths(irs_ctx* c, Plan& plan) {
     return true;
 }
 
-int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
-    if (check_io(c, io_in, "irs_slab_transition")) return 1;
-    if (!c->sl.on) return fail("irs_slab_transition: not a slab context (irs_slab_create)");
-    if (!io_in->v) return fail("irs_slab_transition: v is required");
+}  // extern "C"
+
+namespace {
+
+// one transition of the slab, enqueued (planned from the bounds of t - 2, or measuring)
+int slab_transition_once(irs_ctx* c, const irs_io* io_in, hipStream_t st) {
     const irs_config& cfg = c->cfg;
     const SlabInfo& s = c->sl;
-    hipStream_t st = (hipStream_t)stream;
     const int C = c->C, n = cfg.no_steps;
     const Views v = views(c);
     const irs_io io = shifted_io(c, io_in);
-    // the host runs at most two transitions ahead: the width plan below reads the bounds of transition t - 2, which must have
-    // FINISHED on this rank (not an option here, unlike IRS_RUN_AHEAD of the fused path)
-    if (c->n_enqueued >= 2) {
-        HIP_TRY(hipEventSynchronize(c->ra_ev[(c->n_enqueued - 2) % 4]));
-        // ... and so has its validation: every rank reads the same verdict about the same transition at the same call, so a
-        // misprediction stops ALL ranks here instead of leaving some of them waiting for messages that never come
-        if (c->plan_hint[(c->n_enqueued % 2) * kHintWords + (kHintWords - 8)]) {
-            c->slab_mispredictions += 1;
-            return fail("irs_slab_transition: transition %llu ran with ghost zones narrower than its displacement needed (results invalid from there on)",
-                        (unsigned long long)(c->n_enqueued - 2));
-        }
-    }
     Plan plan;
-    const bool planned = plan_widths(c, plan);
+    const bool planned = c->n_enqueued >= c->exact_until && plan_widths(c, plan);
     if (planned && plan_rounds(plan, s.gmax, s.world > 1 ? s.min_slab : 1 << 30)) return 1;
 
     Exec ex{c, st, c->cs, io, io.v, io.curr_state ? io.curr_state : (c->ffd ? c->vs : planar(c->vs, v)), io.im_moving_warped ? io.im_moving_warped : planar(c->warped, v),
@@ -886,6 +888,8 @@ int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
     memset(ex.pending, 0, sizeof(ex.pending));
     ex.stats_vd = cfg.virtual_decimation;
     ex.stats_op = 3;
+    ex.in_transition = true;
+    ex.planned_ = planned;
     Sched sch(s, cfg, C);
     sch.want_split_ = c->kn.slab_split != 0;
     if (!c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));
@@ -916,6 +920,67 @@ int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
     HIP_TRY(hipEventRecord(c->ra_ev[c->n_enqueued % 4], st));
     ++c->n_enqueued;
     return 0;
+}
+
+// failed (no-op) transitions reported in a plan-hint slot (cumulative count; every rank reads the same number at the same call)
+void slab_poll(irs_ctx* c, int slot) {
+    const unsigned f = ((volatile unsigned*)c->plan_hint)[slot * kHintWords + (kHintWords - 8)];
+    if (f == c->fails_seen || (int)(f - c->fails_seen) < 0) return;
+    const uint64_t d = f - c->fails_seen;
+    c->makeup += d;
+    c->fails_total += d;
+    c->slab_mispredictions += d;
+    c->fails_seen = f;
+    // the bounds that misled the plan are still the newest every rank has seen: measure (exact mode) until the plan source --
+    // the bounds of transition t - 2 -- is one that was measured after the jump
+    c->exact_until = c->n_enqueued + c->makeup + 2;
+}
+
+}  // namespace
+
+namespace irs {
+int slab_flush(irs_ctx* c, hipStream_t st) {
+    for (int guard = 0; guard < 8; ++guard) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipStreamSynchronize(c->cs));
+        slab_poll(c, 0);  // everything enqueued has finished: both slots are final
+        slab_poll(c, 1);
+        if (!c->makeup) return 0;
+        if (!c->kn.recover || !c->have_last_io) return fail("irs_flush: %llu slab transition(s) were dropped after a failed ghost-width plan", (unsigned long long)c->makeup);
+        while (c->makeup > 0) {
+            --c->makeup;
+            if (slab_transition_once(c, &c->last_io, st)) return 1;
+        }
+    }
+    return fail("irs_flush: slab transitions keep failing");
+}
+}  // namespace irs
+
+extern "C" {
+
+int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
+    if (check_io(c, io_in, "irs_slab_transition")) return 1;
+    if (!c->sl.on) return fail("irs_slab_transition: not a slab context (irs_slab_create)");
+    if (!io_in->v) return fail("irs_slab_transition: v is required");
+    hipStream_t st = (hipStream_t)stream;
+    // the host runs at most two transitions ahead: the width plan reads the bounds of transition t - 2, which must have
+    // FINISHED on this rank (not an option here, unlike run_ahead of the fused path)
+    if (c->n_enqueued >= 2) {
+        HIP_TRY(hipEventSynchronize(c->ra_ev[(c->n_enqueued - 2) % 4]));
+        // ... and so has its verdict.  A transition whose ghost zones turned out narrower than its displacement needed was a
+        // no-op on the device (scalar_kernels.h: Verdict) -- on EVERY rank, the verdict comes from the all-reduced bounds -- and
+        // every rank reads the same count at the same call: all of them re-run it here, measuring instead of predicting.
+        slab_poll(c, (int)(c->n_enqueued % 2));
+    }
+    if (c->makeup && !c->kn.recover)
+        return fail("irs_slab_transition: a transition ran with ghost zones narrower than its displacement needed and was dropped (recover = 0)");
+    while (c->makeup > 0) {
+        --c->makeup;
+        if (slab_transition_once(c, io_in, st)) return 1;
+    }
+    c->last_io = *io_in;
+    c->have_last_io = true;
+    return slab_transition_once(c, io_in, st);
 }
 
 int irs_slab_gmm_init(irs_ctx* c, const irs_io* io_in, const float* v_sample, int warm_up, void* stream) {

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kStBlock) void sobolev_march_kernel(const float* __
 void launch_sobolev_march(const float* in, float* out, const Taps& taps, int planes, Vol vol, unsigned* dmax0, int no_steps,
                           hipStream_t st) {
     const int seg_env = global_knobs().sobolev_seg;
-    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + 31) / 32) * ((vol.H + 15) / 16) * planes, 8, seg_env);
+    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + 31) / 32) * ((vol.H + 15) / 16) * planes, 4, seg_env);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const float inv_pow = 1.0f / (float)(1 << no_steps);
     // big tiles (64 x 32, eight outputs per thread: 1.33x halo work in the z pass, a quarter of the barriers per output)
@@ -357,7 +357,8 @@ __global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __
 // still beat 16 and 32
 static int lcc_seg_len(Vol vol, int C) {
     const int seg_env = global_knobs().lcc_seg;
-    return pick_seg_len(vol.nz, (int64_t)((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * C, 8, seg_env, 2048);  // measured at 256^3: 2048 workgroups beat 1024
+    // measured at 256^3: 2048 workgroups beat 1024; at 128^3: 4-plane segments beat 8 (data stage 0.144 -> 0.132 ms)
+    return pick_seg_len(vol.nz, (int64_t)((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * C, 4, seg_env, 2048);
 }
 
 void launch_lcc_fwd_march(const float* fhat, int64_t fhat_stride, const float* im, float* z, float* sigma_out, int s, int C,
@@ -658,7 +659,7 @@ template <int KMAX>
 __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __restrict__ z, const uint8_t* __restrict__ mask,
                                                                const DevState* __restrict__ state, int want_vd,
                                                                double* __restrict__ partials, Vol vol, int seg_len, int nseg,
-                                                               int ntx, int nty) {
+                                                               int ntx, int nty, TailScratch tail, double* __restrict__ total_out) {
     constexpr int NIT = (TPN + kStBlock - 1) / kStBlock;
     constexpr int NACC = 5 + 2 * KMAX;  // n, sum x^2, 3 lag-1 products, KMAX dNLL/dlog_std, KMAX responsibility sums
     __shared__ float X[TPN];
@@ -760,20 +761,23 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
             p[5 + IRS_MAX_COMPONENTS + k] = k < KMAX ? acc[5 + KMAX + (k < KMAX ? k : 0)] : 0.0;
         }
     }
+    // the launch's total, summed in fixed order by the blocks that finish last: the scalar stage reads ONE row (common.h)
+    if (total_out) tail_reduce<kStatVals>(partials, (int)gridDim.x, (int)blockIdx.x, tail, total_out);
 }
 
 void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, int blocks,
-                        Vol vol, int K, hipStream_t st) {
+                        Vol vol, int K, hipStream_t st, TailScratch tail, double* total) {
+    if (blocks > kTailGroup * kTailMaxGroups) total = nullptr;
     const int seg_env = global_knobs().stats_seg;
-    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + TTY - 1) / TTY), 8, seg_env, 2048);
+    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + TTY - 1) / TTY), 4, seg_env, 2048);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + TTY - 1) / TTY;
     if (K >= 1 && K <= 4)
         hipLaunchKernelGGL(stats_march_kernel<4>, dim3(blocks), dim3(kStBlock), 0, st, z, mask, (const DevState*)dev_state, want_vd,
-                           partials, vol, seg_len, nseg, ntx, nty);
+                           partials, vol, seg_len, nseg, ntx, nty, tail, total);
     else
         hipLaunchKernelGGL(stats_march_kernel<IRS_MAX_COMPONENTS>, dim3(blocks), dim3(kStBlock), 0, st, z, mask,
-                           (const DevState*)dev_state, want_vd, partials, vol, seg_len, nseg, ntx, nty);
+                           (const DevState*)dev_state, want_vd, partials, vol, seg_len, nseg, ntx, nty, tail, total);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -898,6 +902,7 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
     const int x = ox + lx, y = oy + ly;
     const bool col_in = x < vol.W && y < vol.H;
     const float coef2 = coef_from_w ? (float)exp(state->st.reg_param[0]) : 2.0f * (float)state->coef[chain];  // 2 coef; L2 family: coef = w / 2
+    const bool frozen = state->bad_now != 0u;  // the transition turned out to be a no-op (scalar_kernels.h: Verdict): v stays
     const float sc[3] = {s0, s1, s2};
     // weights of the two difference terms touching a position: w(q) = 2 for the last (replicated) difference q = n - 2
     auto wm = [](int pos, int n) { return pos >= 1 ? (pos - 1 == n - 2 ? 2.0f : 1.0f) : 0.0f; };
@@ -966,7 +971,7 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
                 const float gs = sg * sg * gr;  // SGLD.backward: sigma^2 * grad == v.grad in the reference
                 float* __restrict__ vp = reinterpret_cast<float*>(reinterpret_cast<char*>(v + base) + own);
                 if (grad_out) *reinterpret_cast<float*>(reinterpret_cast<char*>(grad_out + base) + own) = gs;
-                *vp = *vp - lr * gs;
+                if (!frozen) *vp = *vp - lr * gs;
             }
         }
     }
@@ -978,7 +983,7 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
 
 static int update_seg_len(Vol vol, int C) {
     const int seg_env = global_knobs().update_seg;
-    return pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY) * C, 8, seg_env);
+    return pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY) * C, 4, seg_env);
 }
 
 int sgld_update_blocks_per_chain(Vol vol, int C) {

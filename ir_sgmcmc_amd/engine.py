@@ -149,6 +149,19 @@ class TransitionEngine:
         """a tuning / test switch of THIS context (include/irsgmcmc.h: irs_option_set)"""
         L.option_set(name, value, self._ctx)
 
+    @_on_device
+    def flush(self):
+        """irs_flush: wait for the enqueued transitions and re-run those that ended as no-ops because a kernel-variant (slab:
+        ghost-width) prediction failed; afterwards v / state / scalars are those of a chain that never mispredicted.  Call it
+        before reading `v` at the end of a run (state() and scalars() call it themselves)."""
+        L.check(self.lib.irs_flush(self._ctx, self._stream()))
+
+    @property
+    def recovered_transitions(self):
+        n = C.c_uint64()
+        L.check(self.lib.irs_recovered_transitions(self._ctx, C.byref(n)))
+        return int(n.value)
+
     # ---------------------------------------------------------------- small state
     @property
     def workspace_bytes(self):

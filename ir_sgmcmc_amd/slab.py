@@ -198,6 +198,7 @@ class SlabEngine(TransitionEngine):
 
     def gather(self, t_local):
         """assemble the full (C, ch, D, H, W) tensor from every rank's owned planes (checks / logging); collective, on the host"""
+        self.flush()  # transitions dropped by a failed ghost-width plan are re-run first (collective: same verdict on every rank)
         part = self.owned(t_local).cpu().contiguous()
         if self.world == 1:
             return part

@@ -333,6 +333,7 @@ class Trainer(VIMixin, BaseTrainer):
                 folder = self.config.save_dirs['checkpoints']
                 folder.mkdir(parents=True, exist_ok=True)
                 self.save_checkpoint(folder / f'checkpoint_{sample_no:07}.pt')
+        self.engine.flush()  # a transition dropped by a failed kernel-variant prediction is re-run before anything is saved
         self.displacement_mean = mean
         self.displacement_std = torch.sqrt(m2 / max(n_rec - 1, 1))
         if n_rec > 0 and cfg_trainer.get('save_outputs', True):
@@ -347,6 +348,7 @@ class Trainer(VIMixin, BaseTrainer):
             _, output, _ = self._SGLD_transition(fixed, moving, data_loss, reg_loss, like_reference=False)
             if 'seg' in moving:
                 self.registration_module(moving['seg'], output['transformation'])
+        self.engine.flush()
         torch.cuda.synchronize()
         self.MCMC_sampling_speed = self.no_chains * n_speed / (time.perf_counter() - start)
         log(f'\nMCMC sampling speed: {self.MCMC_sampling_speed:.2f} samples/sec')

@@ -56,9 +56,12 @@ def read_nifti(path, dtype=np.float32):
         raise ValueError(f'{path}: truncated image data')
     arr = np.frombuffer(raw, dtype=dt, count=n, offset=max(vox_offset, 352)).reshape(shape, order='F')
     arr = arr.astype(dtype)
-    if slope not in (0.0, 1.0) or inter != 0.0:
-        if slope == 0.0:
-            slope = 1.0
+    # nifti1.h: scl_slope == 0 means "no scaling"; nibabel -- the reference's writer -- stores NaN in both fields for the same
+    if not np.isfinite(slope) or slope == 0.0:
+        slope = 1.0
+    if not np.isfinite(inter):
+        inter = 0.0
+    if slope != 1.0 or inter != 0.0:
         arr = arr * dtype(slope) + dtype(inter)
     while arr.ndim > 3 and arr.shape[-1] == 1:
         arr = arr[..., 0]
@@ -79,13 +82,14 @@ def write_nifti(arr, path, spacing=(1.0, 1.0, 1.0)):
     spacing = [float(s) for s in np.asarray(spacing).reshape(-1)][:3]
     hdr = bytearray(352)
     struct.pack_into('<i', hdr, 0, 348)
+    hdr[38:39] = b'r'                              # regular
     dim = [arr.ndim] + list(arr.shape) + [1] * (7 - arr.ndim)
     struct.pack_into('<8h', hdr, 40, *dim)
     struct.pack_into('<hh', hdr, 70, _NIFTI_CODES[np.dtype(arr.dtype)], arr.dtype.itemsize * 8)
     pixdim = [1.0] + spacing + [1.0] * (7 - len(spacing))
     struct.pack_into('<8f', hdr, 76, *pixdim)
     struct.pack_into('<f', hdr, 108, 352.0)        # vox_offset
-    struct.pack_into('<ff', hdr, 112, 1.0, 0.0)    # scl_slope, scl_inter
+    struct.pack_into('<ff', hdr, 112, float('nan'), float('nan'))   # scl_slope, scl_inter: NaN = no scaling, as nibabel writes
     hdr[123] = 2                                   # xyzt_units: NIFTI_UNITS_MM
     struct.pack_into('<hh', hdr, 252, 0, 2)        # qform_code 0, sform_code 2 (aligned), as nibabel writes for an affine
     struct.pack_into('<4f', hdr, 280, 1.0, 0.0, 0.0, 0.0)   # srow_x .. srow_z = identity
@@ -133,14 +137,36 @@ def write_vtk_grid(grid, path):
 
 
 def read_vtk_vectors(path):
-    """Read back what write_vtk_field / write_vtk_grid wrote: -> (kind, dims, (3, nx, ny, nz) float32).  Test helper and a
-    minimal reader for the reference's own `.vtk` outputs when they are BINARY legacy files."""
+    """Legacy `.vtk` reader for what the reference writes and reads back (logger/logger.py:35-80, utils/util.py:94-111):
+    STRUCTURED_POINTS with point VECTORS, or STRUCTURED_GRID POINTS; ASCII (tvtk's default for a `.vtk` name) or BINARY
+    (big-endian, as the legacy format prescribes); float or double.  -> (kind, dims, (3, nx, ny, nz) float32)."""
     raw = open(path, 'rb').read()
-    head, _, _ = raw.partition(b'float\n')
-    lines = head.decode(errors='replace').split('\n')
-    kind = next(l.split()[1] for l in lines if l.startswith('DATASET'))
-    dims = tuple(int(t) for t in next(l for l in lines if l.startswith('DIMENSIONS')).split()[1:4])
+    lines, pos = [], 0
+    kind = dims = dtype = None
+    binary = False
+    while pos < len(raw):
+        end = raw.index(b'\n', pos) if b'\n' in raw[pos:] else len(raw)
+        line = raw[pos:end].decode(errors='replace').strip()
+        pos = end + 1
+        lines.append(line)
+        up = line.upper()
+        if up == 'BINARY':
+            binary = True
+        elif up.startswith('DATASET'):
+            kind = line.split()[1]
+        elif up.startswith('DIMENSIONS'):
+            dims = tuple(int(t) for t in line.split()[1:4])
+        elif up.startswith('VECTORS') or up.startswith('POINTS'):
+            dtype = line.split()[-1].lower()
+            break
+    if kind is None or dims is None or dtype not in ('float', 'double'):
+        raise ValueError(f'{path}: not a legacy VTK structured points / grid file with float or double vectors')
     n = dims[0] * dims[1] * dims[2]
-    off = len(head) + len(b'float\n')
-    vec = np.frombuffer(raw, dtype='>f4', count=3 * n, offset=off).reshape(dims[2], dims[1], dims[0], 3)
+    if binary:
+        vec = np.frombuffer(raw, dtype='>f4' if dtype == 'float' else '>f8', count=3 * n, offset=pos)
+    else:
+        vec = np.array(raw[pos:].split()[:3 * n], dtype=np.float64)
+        if vec.size != 3 * n:
+            raise ValueError(f'{path}: {vec.size} values for {n} points')
+    vec = vec.reshape(dims[2], dims[1], dims[0], 3)     # x runs fastest
     return kind, dims, np.ascontiguousarray(vec.transpose(3, 2, 1, 0).astype(np.float32))

@@ -76,10 +76,13 @@ class OracleChain:
         self.cfg = cfg
         C = cfg.no_chains
         shape = (C, 3, *cfg.dims_v)
-        self.v = (torch.zeros(shape) if v0 is None else v0.clone().float()).requires_grad_(True)
-        self.sigma = torch.ones(shape) if sigma is None else sigma.clone().float().expand(shape).contiguous()
+        # fp32 like the reference; under torch.set_default_dtype(torch.float64) the whole chain runs in fp64 (the error-band
+        # measurement of tests/golden/make_golden_fp64.py)
+        wd = torch.get_default_dtype()
+        self.v = (torch.zeros(shape) if v0 is None else v0.clone().to(wd)).requires_grad_(True)
+        self.sigma = torch.ones(shape) if sigma is None else sigma.clone().to(wd).expand(shape).contiguous()
         self.sobolev_kernel = None if cfg.sobolev_s is None else \
-            torch.from_numpy(ops.sobolev_kernel_1d(cfg.sobolev_s, cfg.sobolev_lambda)).float()
+            torch.from_numpy(ops.sobolev_kernel_1d(cfg.sobolev_s, cfg.sobolev_lambda)).to(wd)
 
         K = cfg.gmm_components
         self.log_std = torch.zeros(K, requires_grad=True)

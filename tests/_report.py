@@ -20,3 +20,14 @@ def check(test, key, a, b, tol):
     rec['tol'] = max(rec['tol'], tol)
     assert dev <= tol, f'{test}: {key}: max deviation {dev:.3e} > tolerance {tol:.3e}'
     return dev
+
+
+def fp64_band(key):
+    """tests/golden/fp64_bands.json: how far the fp32 evaluation of one transition is from the fp64 evaluation of the same
+    transition -- measured on the unmodified reference (32^3, 64^3) and on the oracle at the full-size test inputs (128^3, 256^3)
+    by tests/golden/make_golden_fp64.py.  Where a comparison needs more room than the north-star tolerances, THIS is the room
+    it may take: the HIP path must be no further from the fp32 oracle than the fp32 oracle is from fp64."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fp64_bands.json')) as f:
+        return json.load(f)[key]

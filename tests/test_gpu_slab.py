@@ -223,22 +223,33 @@ def test_rccl_transport_single_rank():
         dist.destroy_process_group()
 
 
-def test_misprediction_is_reported():
-    """A plan with ghost zones narrower than the displacement needs (forced here) must not pass silently: the device-side
-    validation flags the transition and a later call returns the error -- at the same call on every rank (the verdict about
-    transition t is read when t + 2 is planned, after t has finished everywhere)."""
-    from ir_sgmcmc_amd._lib import IrsError
+def test_misprediction_is_recovered():
+    """A plan with ghost zones narrower than the displacement needs (forced here) must neither pass silently nor end the chain:
+    the device-side verdict (all-reduced bounds against the planned widths) turns the transition into a no-op on every rank,
+    the count of such transitions reaches the host two calls later -- at the same call on every rank -- and the transition is
+    re-run in measuring mode.  The chain equals the one that measured its ghost widths all along."""
     from ir_sgmcmc_amd.slab import SlabEngine
     cfg, fixed, moving, v0, noise = _setup(24, 1, 'GMM', amp=20.0, with_noise=False)  # several voxels of displacement
-    eng = SlabEngine(cfg, DEV)
-    fd, md = eng.prepare(fixed, moving)
-    eng.gmm_init(fd, md)
-    v = eng.local_v(v0)
-    eng.transition(fd, md, v)                      # measures: fine
-    eng.option('slab_force_h', 1)                  # from now on: plan one plane per step whatever the bounds say
-    eng.transition(fd, md, v)                      # runs with the wrong plan; flagged on the device
-    eng.transition(fd, md, v)
-    with pytest.raises(IrsError, match='narrower than its displacement'):
-        eng.transition(fd, md, v)                  # the verdict about the first wrong transition arrives here
-        eng.transition(fd, md, v)
-    assert eng.status()['mispredictions'] >= 1
+    res = {}
+    for forced in (0, 1):
+        eng = SlabEngine(cfg, DEV)
+        fd, md = eng.prepare(fixed, moving)
+        eng.gmm_init(fd, md)
+        v = eng.local_v(v0)
+        if not forced:
+            eng.option('slab_exact', 1)            # reference chain: every transition measures
+        eng.transition(fd, md, v)                  # measures: fine
+        if forced:
+            eng.option('slab_force_h', 1)          # from now on: plan one plane per step whatever the bounds say
+        for _ in range(2):
+            eng.transition(fd, md, v)              # (forced: run with the wrong plan, dropped on the device)
+        if forced:
+            eng.option('slab_force_h', 0)
+        for _ in range(3):
+            eng.transition(fd, md, v)              # the verdicts arrive here; the dropped transitions are re-run, measuring
+        eng.flush()
+        st = eng.status()
+        res[forced] = (v.clone(), eng.state().iteration, st['mispredictions'])
+    assert res[0][1] == res[1][1] == 6
+    assert res[0][2] == 0 and res[1][2] >= 1
+    assert torch.equal(res[0][0], res[1][0])

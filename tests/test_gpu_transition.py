@@ -6,7 +6,7 @@ import torch
 from ir_sgmcmc_amd.engine import EngineConfig, TransitionEngine
 from oracle import OracleChain, OracleConfig
 from tests._golden import Golden, golden_names
-from tests._report import GRAD_RTOL, check
+from tests._report import GRAD_RTOL, check, fp64_band
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -203,20 +203,24 @@ def test_transition_matches_oracle_at_full_size(N, loss):
     check(T, 'alpha', sc['alpha'], o['alpha'], 5e-5)
     check(T, 'data_term (rel)', torch.tensor(sc['data_term']) / torch.tensor(o['data']).abs(), torch.sign(torch.tensor(o['data'])), 1e-5)
     check(T, 'reg_term (rel)', torch.tensor(sc['reg_term']) / torch.tensor(o['reg']).abs(), torch.sign(torch.tensor(o['reg'])), 1e-5)
-    # fp32 positions live in [-1, 1]: one ulp there is 3.8e-6 voxels at 128^3 and 7.6e-6 at 256^3, and twelve compositions
-    # accumulate a few of them -- at 256^3 the largest deviation measured is 1.04e-4 voxels on a 3.3-voxel field.  Checked there:
-    # 1e-4 RELATIVE to the field's maximum (the north star's "1e-4 on the displacement field") and 2e-4 voxels absolute.
+    # Displacement: the north star's 1e-4 voxels -- except where the REFERENCE ARITHMETIC ITSELF is not that accurate.  fp32
+    # positions live in [-1, 1] (one ulp = 7.6e-6 voxels at 256^3) and twelve compositions accumulate a few of them: the fp32
+    # oracle deviates 2.9e-5 voxels (128^3) / 1.17e-4 voxels (256^3) from its own fp64 evaluation on exactly these inputs
+    # (tests/golden/fp64_bands.json, written by tests/golden/make_golden_fp64.py).  The HIP path may be no further from the fp32
+    # oracle than the fp32 oracle is from fp64; the relative form (1e-4 of the field's maximum) holds at every size.
+    band = fp64_band(f'oracle_{N}_gmm_full_size_test_inputs')
     dmax_o = float(o['displacement'].abs().max())
-    check(T, 'displacement [voxels]', out['displacement'], o['displacement'], 1e-4 if N <= 128 else 2e-4)
+    check(T, 'displacement [voxels]', out['displacement'], o['displacement'], max(1e-4, band['displacement_max_abs_dev_voxels']))
     check(T, 'displacement (rel to max)', out['displacement'].cpu() / dmax_o, o['displacement'] / dmax_o, 1e-4)
-    # The gradient of trilinear interpolation jumps across cell faces.  Among 2 million voxels x 12 steps a few dozen sampling
-    # positions sit within fp32 rounding of a face, and there the CPU and the GPU (positions equal to 1e-6) take different
-    # one-sided derivatives: the gradient is compared on all but a 1e-4 fraction of the voxels (58 of 6.3 million exceed
-    # the tolerance in this configuration; every forward quantity above is compared everywhere).
+    # Gradient: trilinear interpolation's derivative jumps across cell faces, and among millions of voxels x 12 steps a few
+    # dozen sampling positions sit within fp32 rounding of a face, where two correct evaluations take different one-sided
+    # derivatives.  The yardstick is again the oracle's own fp32-vs-fp64 band on these inputs: the fraction of voxels whose
+    # gradient moves by more than 1e-3 of the maximum (2.8e-5 at 128^3, 5.0e-5 at 256^3) bounds the fraction on which the HIP
+    # path may differ from the fp32 oracle by that much, and the 99.99th percentile of the deviation stays below 1e-3.
     gmax = float(o['grad_v'].abs().max())
     dev = (out['grad_v'].cpu() - o['grad_v']).abs() / gmax
     frac_bad = float((dev > GRAD_RTOL).double().mean())
-    check(T, 'grad_v: fraction of voxels beyond tolerance', torch.tensor(frac_bad), torch.tensor(0.0), 1e-4)
+    check(T, 'grad_v: fraction of voxels beyond tolerance', torch.tensor(frac_bad), torch.tensor(0.0), band['grad_frac_beyond_1e-3'])
     check(T, 'grad_v (rel to max), 99.99th percentile', torch.tensor(float(dev.flatten().kthvalue(int(0.9999 * dev.numel())).values)), torch.tensor(0.0), GRAD_RTOL)
 
 
@@ -275,3 +279,36 @@ def test_variant_prediction_never_changes_the_result(amp):
         scale = float(res[0][1].abs().max())
         assert float((res[mode][1] - res[0][1]).abs().max()) < 1e-4 * scale                # gradient (summation order only)
         assert float((res[mode][0] - res[0][0]).abs().max()) < 1e-5 * float(res[0][0].abs().max())
+
+
+def test_misprediction_is_recovered_not_fatal():
+    """A transition launched WITHOUT a kernel variant its displacement then needs (forced: predict_variants = 3 always predicts
+    'tiny', so the radius-2 adjoint is never launched, while the field carries several voxels) must not end the chain: the
+    device finds the assumption violated, the transition is a no-op (velocity, mixture, Adam moments, Philox counter untouched),
+    and a later call re-runs it with every variant.  The chain equals the one that launched every variant all along -- bit for
+    bit with in-kernel Philox noise (the failed transition did not consume its counter)."""
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    from ir_sgmcmc_amd.ops import perturb_smooth, sobolev_kernel_1d
+    N, T = 24, 6
+    f1, m1 = synthetic_pair((N, N, N), seed=0)
+    fixed = to_dev({k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'})
+    moving = to_dev({k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'})
+    g = torch.Generator().manual_seed(3)
+    v0 = perturb_smooth(torch.randn(1, 3, N, N, N, generator=g).to(DEV), sobolev_kernel_1d(3, 0.5))
+    v0 = v0 * (3.5 / float(v0.abs().max()))   # d_11, d_12 beyond one voxel: the radius-1 adjoint alone is wrong for them
+    res = {}
+    for mode in (0, 3):
+        eng = TransitionEngine(EngineConfig(dims=(N, N, N), seed=11), DEV)
+        eng.option('predict_variants', mode)
+        fd, md = eng.prepare(fixed, moving)
+        eng.gmm_init(fd, md)
+        v = v0.clone()
+        for _ in range(T):
+            eng.transition(fd, md, v)
+        eng.flush()                          # the last two transitions are only checked here
+        st = eng.state()
+        assert st.iteration == T             # every transition happened exactly once
+        res[mode] = (v.clone(), list(st.gmm_log_std), list(st.gmm_logits), eng.recovered_transitions)
+    assert res[0][3] == 0 and res[3][3] >= 1, (res[0][3], res[3][3])
+    assert torch.equal(res[0][0], res[3][0])
+    assert res[0][1] == res[3][1] and res[0][2] == res[3][2]

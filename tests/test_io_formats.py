@@ -1,5 +1,6 @@
 """File formats of the reference's data loader and logger, re-implemented without SimpleITK / nibabel / tvtk (CPU tests)."""
 import gzip
+import os
 import struct
 
 import numpy as np
@@ -29,6 +30,45 @@ def test_nifti_header_is_what_nibabel_writes(tmp_path):
     assert data[0] == im[0, 0, 0] and data[1] == im[1, 0, 0] and data[2] == im[0, 1, 0]
     back, zooms = read_nifti(str(p))
     assert np.array_equal(back, im) and zooms == (1.5, 2.0, 2.5)
+
+
+IO_FIXTURES = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'io')
+
+
+def test_reader_and_writer_against_spec_derived_nibabel_bytes(tmp_path):
+    """tests/golden/io/nifti1_nibabel_2x3x4_f32.nii.gz was packed field by field after nifti1.h the way nibabel -- the reference's
+    writer, logger/logger.py:84-102 -- fills the header (tests/golden/make_io_fixtures.py; NOT with utils/imageio.py): the reader
+    must decode it (including nibabel's NaN "no scaling" slope), and the writer must produce the same 352 header bytes."""
+    raw = gzip.open(os.path.join(IO_FIXTURES, 'nifti1_nibabel_2x3x4_f32.nii.gz'), 'rb').read()
+    im = np.arange(24, dtype=np.float32).reshape(2, 3, 4) * 0.25 - 1.0
+    back, zooms = read_nifti(os.path.join(IO_FIXTURES, 'nifti1_nibabel_2x3x4_f32.nii.gz'))
+    assert back.dtype == np.float32 and np.array_equal(back, im) and zooms == (1.5, 2.0, 2.5)
+    p = tmp_path / 'mine.nii.gz'
+    save_im_to_disk(im, str(p), spacing=(1.5, 2.0, 2.5))
+    mine = gzip.open(p, 'rb').read()
+    assert mine[:352] == raw[:352], [i for i in range(352) if mine[i] != raw[i]]
+    assert mine[352:] == raw[352:]
+
+
+def test_reader_against_spec_derived_scanner_style_bytes():
+    back, zooms = read_nifti(os.path.join(IO_FIXTURES, 'nifti1_int16_be_scaled.nii'))
+    lab = (np.arange(24, dtype=np.int16).reshape(2, 3, 4) - 5).astype(np.float32)
+    assert np.allclose(back, lab * 0.5 + 10.0) and zooms == pytest.approx((0.9, 0.9, 3.0))
+
+
+def test_vtk_reader_against_spec_derived_legacy_files(tmp_path):
+    """the reference writes ASCII legacy files with double vectors (tvtk write_data, dtype=float) and reads them back with
+    vtkStructuredPointsReader (utils/util.py:94-111; round trip in tests/test_utils.py:153-159)"""
+    kind, dims, f = read_vtk_vectors(os.path.join(IO_FIXTURES, 'vtk_legacy_ascii_field.vtk'))
+    x, y, z = np.meshgrid(np.arange(2.0), np.arange(3.0), np.arange(2.0), indexing='ij')
+    want = np.stack([100.0 * c + x + 10.0 * y + 0.5 * z for c in range(3)]).astype(np.float32)
+    assert kind == 'STRUCTURED_POINTS' and dims == (2, 3, 2) and np.array_equal(f, want)
+    kind, dims, g = read_vtk_vectors(os.path.join(IO_FIXTURES, 'vtk_legacy_binary_grid.vtk'))
+    wantg = np.stack([-1.0 + 2.0 * x, -1.0 + y, 0.25 * z]).astype(np.float32)
+    assert kind == 'STRUCTURED_GRID' and np.array_equal(g, wantg)
+    # and the writer's own files read back the same way
+    save_field_to_disk(torch.from_numpy(want), str(tmp_path / 'f.vtk'), spacing=(1.5, 2.0, 2.5))
+    assert np.array_equal(read_vtk_vectors(str(tmp_path / 'f.vtk'))[2], want)
 
 
 @pytest.mark.parametrize('dtype', [np.uint8, np.int16, np.int32, np.float32, np.float64])
