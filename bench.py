@@ -193,7 +193,10 @@ def main():
     ap.add_argument('--cpu-reps', type=int, default=1)
     args = ap.parse_args()
 
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    # no launcher (or a stale single-process WORLD_SIZE = 1 in the environment): start the ranks ourselves
+    if args.gpus > 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1 and 'TORCHELASTIC_RUN_ID' not in os.environ:
+        for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+            os.environ.pop(k, None)
         sys.exit(spawn_ranks(args.gpus))
     if args.gpus > 1 and args.watchdog > 0:
         # a multi-rank run that stops making progress (a transport that hangs instead of failing) must end with a diagnosis,

@@ -147,6 +147,11 @@ int irs_perturb_smooth(const float* v, const float* sigma, const float* eps, flo
     taps.s = s;
     for (int i = 0; i <= 2 * s; ++i) taps.k[i] = kernel[i];
     const float* src = v;
+    if (tau >= 0.0f && global_knobs().fuse_noise) {  // the noise is generated while the smoothing kernel stages its planes
+        launch_perturb_sobolev_march(v, sigma, eps, (float)sqrt(2.0 * (double)tau), out, taps, C, vol, nullptr, 12, seed, iteration, nullptr, st);
+        LAUNCH_CHECK();
+        return 0;
+    }
     if (tau >= 0.0f) {
         launch_perturb(v, sigma, eps, (float)sqrt(2.0 * (double)tau), out, C, vol, seed, iteration, nullptr, st);
         src = out;
@@ -523,8 +528,6 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     const size_t o_sums = take(sizeof(double) * (kStatVals + 2 * IRS_MAX_CHAINS));
     const size_t o_dmax = take(sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32);
     const size_t o_cmm = take(coarse_minmax_bytes(c->vol, C));
-    const size_t o_tailc = take(sizeof(unsigned) * (1 + kTailMaxGroups));
-    const size_t o_tailr = take(sizeof(double) * kTailMaxGroups * kStatVals);
     const size_t o_state = take(sizeof(DevState));
     c->slab_bytes = off;
     if (hipMalloc((void**)&c->slab, off) != hipSuccess) {
@@ -532,7 +535,6 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
         return fail("irs_create: hipMalloc of %zu workspace bytes failed", off);
     }
     if (c->sl.on) (void)hipMemset(c->slab, 0, off);  // ghost planes nobody has written yet must hold finite values
-    else (void)hipMemset(c->slab + o_tailc, 0, sizeof(unsigned) * (1 + kTailMaxGroups));  // arrival counters of the tail reductions
     c->steps = (float*)(c->slab + o_steps);
     c->tmpA = (float*)(c->slab + o_tmpA);
     c->tmpB = (float*)(c->slab + o_tmpB);
@@ -554,7 +556,6 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     c->dmax = (unsigned*)(c->slab + o_dmax);
     c->cmm = (float*)(c->slab + o_cmm);
     c->state = (DevState*)(c->slab + o_state);
-    c->tail = TailScratch{(unsigned*)(c->slab + o_tailc), (double*)(c->slab + o_tailr)};
 
     if (ensure_lin_tables(c->lin, D, H, W, nullptr)) {
         (void)hipFree(c->slab);
@@ -687,17 +688,24 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     const irs_config& cfg = c->cfg;
     const int C = chains;
     const uint64_t* it = &c->state->st.iteration;
-    // 1. SGLD perturbation + Sobolev smoothing
-    float* first = cfg.sobolev_s > 0 ? c->tmpA : vs;
-    if (with_noise) launch_perturb(v, io->sigma, io->eps, (float)sqrt(2.0 * (double)cfg.lr), first, C, c->volv, cfg.seed, 0, it, st);
-    else HIP_TRY(hipMemcpyAsync(first, v, (size_t)C * 3 * c->volv.V * sizeof(float), hipMemcpyDeviceToDevice, st));
     // (the finalize kernel of a transition leaves the bound scratch cleared for the next one)
     if (!c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (cfg.no_steps + 1), st));
     c->dmax_clean = false;
+    // 1. SGLD perturbation + Sobolev smoothing: one kernel that generates the noise while it stages its planes (v + noise is
+    //    never materialised); the two-kernel form for the mixture initialisation (no noise) and the small SVFFD control grid
     bool have_dmax0 = false;
-    if (cfg.sobolev_s > 0) {
-        have_dmax0 = !c->ffd;
-        launch_sobolev_march(c->tmpA, vs, c->sob, C * 3, c->volv, have_dmax0 ? c->dmax : nullptr, cfg.no_steps, st);
+    const float amp = (float)sqrt(2.0 * (double)cfg.lr);
+    if (with_noise && cfg.sobolev_s > 0 && !c->ffd && c->kn.fuse_noise) {
+        have_dmax0 = true;
+        launch_perturb_sobolev_march(v, io->sigma, io->eps, amp, vs, c->sob, C, c->volv, c->dmax, cfg.no_steps, cfg.seed, 0, it, st);
+    } else {
+        float* first = cfg.sobolev_s > 0 ? c->tmpA : vs;
+        if (with_noise) launch_perturb(v, io->sigma, io->eps, amp, first, C, c->volv, cfg.seed, 0, it, st);
+        else HIP_TRY(hipMemcpyAsync(first, v, (size_t)C * 3 * c->volv.V * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (cfg.sobolev_s > 0) {
+            have_dmax0 = !c->ffd;
+            launch_sobolev_march(c->tmpA, vs, c->sob, C * 3, c->volv, have_dmax0 ? c->dmax : nullptr, cfg.no_steps, st);
+        }
     }
     // 2. dense velocity
     const float* dense = vs;
@@ -817,10 +825,8 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
     for (int ch = 0; ch < C; ++ch) {
         const uint8_t* mask = io->mask + (io->mask_chains == 1 ? 0 : (int64_t)ch * vol.V);
         const float* zc = z + (int64_t)ch * vol.V;
-        // (the statistics kernel leaves its total in stat_sum: the scalar stage reads one row instead of reducing 2048)
-        const bool tailed = sb <= kTailGroup * kTailMaxGroups;
-        launch_stats(cfg.virtual_decimation, zc, mask, c->state, c->stat_partials, vol, st, c->dcfg.K, c->tail, c->stat_sum);
-        launch_chain_scalar(c->state, tailed ? c->stat_sum : c->stat_partials, tailed ? 1 : sb, ch, ch == 0 ? 7 : 3, c->dcfg, st, vd);  // chain 0: + the verdict
+        launch_stats(cfg.virtual_decimation, zc, mask, c->state, c->stat_partials, vol, st, c->dcfg.K);
+        launch_chain_scalar(c->state, c->stat_partials, sb, ch, ch == 0 ? 7 : 3, c->dcfg, st, vd);  // chain 0: + the verdict
         const float* f = cfg.data_loss == IRS_DATA_GMM_LCC ? c->fhat + (c->fhat_chains == 1 ? 0 : (int64_t)ch * vol.V) : nullptr;
         launch_data_bwd(cfg.data_loss, f, 0, zc, c->sigM + (int64_t)ch * vol.V, mask, 0, nullptr, c->state, ch,
                         c->gM + (int64_t)ch * vol.V, c->nll_partials + (int64_t)ch * c->nll_blocks, cfg.lcc_s, 1, vol, st);
@@ -872,6 +878,7 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
         launch_sgld_update(io->v, io->sigma, g0, vs, c->state, cfg.lr, s[0], s[1], s[2], io->grad_v, C, volv, st,
                            energy_in_update ? c->energy_partials : nullptr, energy_in_update);
     }
+    // bookkeeping (+ the regulariser scalar stage of the L2 family, whose energy the update has just produced: one launch)
     launch_finalize(c->state, c->nll_partials, c->nll_blocks, c->dcfg, true, c->dmax, c->hint, 4 * C * (cfg.no_steps + 1), vd,
                     kHintWords - 7, true, st, energy_in_update ? c->energy_partials : nullptr, upd_blocks);
     c->dmax_clean = true;

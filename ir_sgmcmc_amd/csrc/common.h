@@ -264,56 +264,6 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* smem) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Deterministic tail reduction inside the producing kernel.  Every block of a launch has written one row of NV partial sums,
-// rows[block][0 .. NV) (thread 0, before the call); the LAST block of each group of kTailGroup consecutive blocks to arrive sums
-// the group's rows in index order, and the last GROUP to finish sums the group rows in index order into out[0 .. NV).  The
-// order of the additions is fixed by the indices, not by who arrives when: bitwise reproducible.  The single-workgroup kernel
-// that used to read thousands of rows (20 us on the critical path of every transition) then reads one.
-// counters: 1 + kTailMaxGroups unsigned, zero on entry, left zero on exit; group_rows: [kTailMaxGroups][NV] doubles.
-// Every thread of every block calls (barriers inside); true in the block that wrote `out`.  nblocks <= kTailGroup * kTailMaxGroups.
-// ------------------------------------------------------------------------------------------------
-constexpr int kTailGroup = 32, kTailMaxGroups = 128;
-struct TailScratch {
-    unsigned* counters;
-    double* group_rows;
-};
-__device__ __forceinline__ double ld_coherent(const double* p) {  // device-scope load: rows written by other XCDs (own L2 may be stale)
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_AGENT));
-}
-template <int NV>
-__device__ __forceinline__ bool tail_reduce(const double* __restrict__ rows, int nblocks, int my_block, TailScratch ts,
-                                            double* __restrict__ out) {
-    __shared__ int tail_flag;
-    const int ngroups = (nblocks + kTailGroup - 1) / kTailGroup;
-    const int g = my_block / kTailGroup, g0 = g * kTailGroup;
-    const int gsize = min(kTailGroup, nblocks - g0);
-    __syncthreads();
-    if (threadIdx.x == 0)  // release: this block's row; acquire: the rows of the blocks that arrived before
-        tail_flag = __hip_atomic_fetch_add(&ts.counters[1 + g], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(gsize - 1);
-    __syncthreads();
-    if (!tail_flag) return false;
-    if ((int)threadIdx.x < NV) {
-        double s = 0.0;
-        for (int r = 0; r < gsize; ++r) s += ld_coherent(rows + (int64_t)(g0 + r) * NV + threadIdx.x);
-        ts.group_rows[(int64_t)g * NV + threadIdx.x] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-        tail_flag = __hip_atomic_fetch_add(&ts.counters[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ngroups - 1);
-    __syncthreads();
-    if (!tail_flag) return false;
-    if ((int)threadIdx.x < NV) {
-        double s = 0.0;
-        for (int q = 0; q < ngroups; ++q) s += ld_coherent(ts.group_rows + (int64_t)q * NV + threadIdx.x);
-        out[threadIdx.x] = s;
-    }
-    for (int i = threadIdx.x; i <= ngroups; i += blockDim.x) ts.counters[i] = 0u;  // ready for the next launch
-    __syncthreads();
-    return true;
-}
-
-// ------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter-based RNG (in-kernel noise when the caller injects none).
 // counter = (index lo, index hi, iteration lo, stream id), key = seed.
 // ------------------------------------------------------------------------------------------------

@@ -60,7 +60,6 @@ struct irs_ctx {
     unsigned* hint = nullptr;  // pinned host copy of dmax as of the last finished transition (written by finalize_kernel, read
                      // by the host WITHOUT synchronisation: a hint that only decides which variants are launched)
     irs::DevState* state;
-    irs::TailScratch tail;  // arrival counters + group rows of the in-kernel tail reductions (common.h)
     int fhat_chains;
     bool fixed_set;
     int nll_blocks;

@@ -59,8 +59,8 @@ int stats_blocks(Vol vol) {
 }
 
 void launch_stats(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, Vol vol,
-                  hipStream_t st, int K, TailScratch tail, double* total) {
-    launch_stats_march(want_vd, z, mask, dev_state, partials, stats_blocks(vol), vol, K, st, tail, total);
+                  hipStream_t st, int K) {
+    launch_stats_march(want_vd, z, mask, dev_state, partials, stats_blocks(vol), vol, K, st);
 }
 
 // SSD residual z = F - M o phi (builder-defined data term)

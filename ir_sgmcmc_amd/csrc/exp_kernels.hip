@@ -482,6 +482,11 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #ifndef IRS_MARCH_WAVES
 #define IRS_MARCH_WAVES 4
 #endif
+// The radius-1 adjoint only runs for max|d_k| < 1 (selected on the device from the exact bound): the eight corners of a voxel's
+// own sample then ALWAYS sit in the ring, and the global-memory fallback for taps that leave it is dead code.  1: keep it (A/B).
+#ifndef IRS_BWD_R1_FALLBACK
+#define IRS_BWD_R1_FALLBACK 0
+#endif
 // hat of (r + c) for a relative position r and a compile-time integer offset c.
 template <int R>
 __device__ __forceinline__ float rel_hat(float r, int c);
@@ -782,7 +787,8 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                     // the "+1" corners are read unconditionally: where ATen clamps them (i0 = n-1) their weight is exactly 0 and
                     // the ring holds a finite halo value there
                     const int bx0 = lx + R + rx0, by0 = ly + R + ry0;
-                    const bool in_ring = (unsigned)bx0 < (unsigned)(PX - 1) && (unsigned)by0 < (unsigned)(M::PY - 1) && rel >= -R && rel < R;
+                    const bool in_ring = (R == 1 && !IRS_BWD_R1_FALLBACK) ||
+                                         ((unsigned)bx0 < (unsigned)(PX - 1) && (unsigned)by0 < (unsigned)(M::PY - 1) && rel >= -R && rel < R);
                     float dot[2][2][2];
                     if (in_ring) {
                         int sl0 = ((a - R + NP) % NP) * PN, sl1 = ((a - R + 1 + NP) % NP) * PN;  // rel == -R

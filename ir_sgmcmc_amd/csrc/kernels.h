@@ -67,6 +67,10 @@ void launch_field_absmax(const float* d, bool prescale, int no_steps, unsigned* 
 // ---- data_kernels.hip
 void launch_sobolev_march(const float* in, float* out, const Taps& taps, int planes, Vol vol, unsigned* dmax0, int no_steps,
                           hipStream_t st);  // z-marching version (stencil_kernels.hip)
+// SGLD perturbation generated while the smoothing kernel stages its planes (SVF_3D path, s > 0): v + noise is never materialised
+void launch_perturb_sobolev_march(const float* v, const float* sigma, const float* eps, float amp, float* out, const Taps& taps,
+                                  int C, Vol vol, unsigned* dmax0, int no_steps, uint64_t seed, uint64_t iteration,
+                                  const uint64_t* dev_iteration, hipStream_t st);  // stencil_kernels.hip
 void launch_lcc_fwd_march(const float* fhat, int64_t fhat_stride, const float* im, float* z, float* sigma_out, int s, int C,
                     Vol vol, hipStream_t st);  // z-marching version (stencil_kernels.hip)
 struct GmmDev;  // device-side mixture parameters (scalar_kernels.hip)
@@ -75,9 +79,8 @@ void launch_data_bwd(int mode, const float* fhat_or_fixed, int64_t f_stride, con
                      const uint8_t* mask, int64_t mask_stride, const float* g_z_override, const void* dev_state,
                      int chain, float* g_warped, double* nll_partials, int s, int C_launch, Vol vol, hipStream_t st);
 // K: number of mixture components if the caller knows it (selects the K <= 4 build of the kernel), 0 = unknown
-// tail / total (optional): the kernel also leaves the launch's total in total[0 .. kStatVals) (common.h: tail_reduce)
 void launch_stats(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, Vol vol,
-                  hipStream_t st, int K = 0, TailScratch tail = TailScratch{nullptr, nullptr}, double* total = nullptr);
+                  hipStream_t st, int K = 0);
 void launch_residual_ssd(const float* fixed, int64_t f_stride, const float* warped, float* z, int C, Vol vol,
                          hipStream_t st);
 // z-marching fused data-term backward (stencil_kernels.hip)
@@ -100,7 +103,7 @@ int sgld_update_blocks_per_chain(Vol vol, int C);
 void launch_gradient_operator(const float* v, float* nabla, int transformation, int C, Vol vol, hipStream_t st);
 void launch_log_det_jacobian(const float* t, float* log_det, long long* nan_count, int C, Vol vol, hipStream_t st);
 void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, int blocks,
-                        Vol vol, int K, hipStream_t st, TailScratch tail, double* total);  // stencil_kernels.hip
+                        Vol vol, int K, hipStream_t st);  // stencil_kernels.hip
 void launch_reg_energy_march(const float* v, double* partials, int blocks, int C, Vol vol, hipStream_t st);
 void launch_sgld_update_march(float* v, const float* sigma, const float* g_d0, const float* v_s, const void* dev_state,
                               float lr, float s0, float s1, float s2, float* grad_out, int C, Vol vol, hipStream_t st,

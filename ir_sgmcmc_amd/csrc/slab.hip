@@ -102,9 +102,11 @@ int plan_rounds(Plan& p, int gmax, int min_slab) {
 
 int default_margin(const irs_config* cfg, int gmax) {
     const int ls = cfg->data_loss == IRS_DATA_GMM_LCC ? cfg->lcc_s : 0;
+    // widest read beyond the slab: the smoothing stage on slab +- e0 (e0 <= gmax) reads sobolev_s planes further; the LCC map on
+    // slab +- 2 ls reads 2 ls further.  + 1: the adjoint kernel prefetches one plane past the last one it uses.
     int m = cfg->sobolev_s + gmax;
     if (4 * ls > m) m = 4 * ls;
-    return m + 2;
+    return m + 1;
 }
 
 int plan_layout(const irs_config* cfg, const irs_slab_config* scfg, int rank, int world, SlabInfo* sl) {
@@ -198,6 +200,7 @@ struct Sched {
     int next_id = 0;
 
     bool want_split_ = true;  // Knobs::slab_split (measurements): no interior / boundary split when false
+    bool fuse_noise_ = true;  // Knobs::fuse_noise
     bool ffd;   // SVFFD_3D: v / noisy / v_s live on the control grid, whole on every rank; d_0 is the up-sampled DENSE field
     Vol volv;   // the velocity grid (control grid, or the image grid for SVF_3D)
 
@@ -316,14 +319,20 @@ struct Sched {
             launch(IRS_SG_FFD_UP, 0, W(e0), -1, -1, 0, IRS_SB_DENSE);
             return;
         }
-        launch(noise ? IRS_SG_PERTURB : IRS_SG_COPY_V, 0, W(0), IRS_SB_V, -1, 0, first);
-        wait(exchange(first, sb + e0));
-        launch(IRS_SG_SMOOTH, 0, W(e0), first, -1, sb, IRS_SB_VS);
-        *energy_ar = -1;
-        if (energy) {
-            launch(IRS_SG_ENERGY, 0, W(0), IRS_SB_VS, -1, 1, -1);
-            *energy_ar = allreduce(IRS_AR_ENERGY);
+        if (noise && sb > 0 && fuse_noise_) {
+            // the smoothing kernel generates the noise itself while staging (Philox keyed by the GLOBAL voxel index: a ghost plane
+            // draws what its owner draws): what travels is the velocity, and the perturbed field is never materialised
+            wait(exchange(IRS_SB_V, sb + e0));
+            launch(IRS_SG_SMOOTH, 1, W(e0), IRS_SB_V, -1, sb, IRS_SB_VS);   // k = 1: fused perturbation
+        } else {
+            launch(noise ? IRS_SG_PERTURB : IRS_SG_COPY_V, 0, W(0), IRS_SB_V, -1, 0, first);
+            wait(exchange(first, sb + e0));
+            launch(IRS_SG_SMOOTH, 0, W(e0), first, -1, sb, IRS_SB_VS);
         }
+        // the energy partial sum of the slab stays local for now: it travels with the data-term sums (IRS_AR_NLL carries both:
+        // three all-reduces per transition -- bounds, statistics, loss terms -- instead of four)
+        *energy_ar = -1;
+        if (energy) launch(IRS_SG_ENERGY, 0, W(0), IRS_SB_VS, -1, 1, -1);
     }
     void forward_planned(const Plan& p) {
         const int n = cfg.no_steps;
@@ -403,11 +412,11 @@ struct Sched {
             launch(IRS_SG_FINALIZE, 0, W(0), -1, -1, 0, -1);
             return;
         }
-        // regulariser scalars (their all-reduce has been in flight since the smoothing stage), update, bookkeeping
-        wait(energy_ar);
+        // regulariser scalars (the energies came with the data-term sums), update, bookkeeping
+        (void)energy_ar;
+        wait(nll_ar);
         launch(IRS_SG_REG_SCALAR, 0, W(0), -1, -1, 0, -1);
         launch(IRS_SG_UPDATE, 0, W(0), grad_id(0, false), IRS_SB_VS, 1, IRS_SB_V);
-        wait(nll_ar);
         launch(IRS_SG_FINALIZE, 0, W(0), -1, -1, 0, -1);
     }
 };
@@ -507,7 +516,10 @@ struct Exec {
         switch (o.stage) {
             case IRS_AR_ENERGY: buf = c->energy_sum; count = (size_t)chains; break;
             case IRS_AR_STATS: buf = c->stat_sum; count = kStatVals; break;
-            case IRS_AR_NLL: buf = c->nll_sum; count = (size_t)chains; break;
+            case IRS_AR_NLL:  // data-term sums + (SVF) the regulariser energies, adjacent in the workspace: one payload
+                if (c->ffd) { buf = c->nll_sum; count = (size_t)chains; }  // (SVFFD: the energy is computed whole on every rank)
+                else { buf = c->energy_sum; count = (size_t)2 * IRS_MAX_CHAINS; }
+                break;
             case IRS_AR_DMAX: buf = c->dmax; count = (size_t)4 * c->C * (n + 1); mx = 1; break;
             case IRS_AR_MOMENTS: buf = c->stat_sum; count = 3; break;
             case IRS_AR_CPGRAD: buf = c->tmpB; count = (size_t)chains * 3 * c->volv.V; mx = 2; break;
@@ -551,7 +563,9 @@ struct Exec {
                 break;
             }
             case IRS_SG_SMOOTH:
-                if (cfg.sobolev_s > 0) launch_sobolev_march(noisy, vs, c->sob, C * 3, wv, c->ffd ? nullptr : c->dmax, n, st);
+                if (o.k == 1)  // perturbation fused into the smoothing kernel (SVF_3D, s > 0)
+                    launch_perturb_sobolev_march(v_src, io.sigma, io.eps, (float)sqrt(2.0 * (double)cfg.lr), vs, c->sob, C, w, c->dmax, n, cfg.seed, 0, it, st);
+                else if (cfg.sobolev_s > 0) launch_sobolev_march(noisy, vs, c->sob, C * 3, wv, c->ffd ? nullptr : c->dmax, n, st);
                 else if (!c->ffd) launch_field_absmax(vs, true, n, c->dmax, C, w, st);
                 break;
             case IRS_SG_ENERGY:
@@ -595,8 +609,8 @@ struct Exec {
                 break;
             case IRS_SG_STATS: {
                 const uint8_t* mask = io.mask + (io.mask_chains == 1 ? 0 : (int64_t)o.k * c->vol.V);
-                // (the total is formed by the kernel's last blocks: no reduction launch)
-                launch_stats(stats_vd, z + (int64_t)o.k * c->vol.V, mask, c->state, c->stat_partials, w, st, c->dcfg.K, c->tail, c->stat_sum);
+                launch_stats(stats_vd, z + (int64_t)o.k * c->vol.V, mask, c->state, c->stat_partials, w, st, c->dcfg.K);
+                launch_reduce_cols(c->stat_partials, stats_blocks(w), kStatVals, c->stat_sum, st);
                 break;
             }
             case IRS_SG_CHAIN_SCALAR:
@@ -806,7 +820,11 @@ int irs_slab_create(const irs_config* cfg, const irs_slab_config* scfg, irs_comm
     irs_ctx* c = nullptr;
     if (create_ctx(cfg, &s, &c)) return 1;
     c->comm = comm;
-    hipError_t e = hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking);
+    // the communication stream gets the HIGHEST priority: its send / recv kernels are enqueued while interior launches of a
+    // thousand workgroups occupy every CU, and the overlap the schedule is built on needs them to be dispatched ahead of those
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    hipError_t e = hipStreamCreateWithPriority(&c->cs, hipStreamNonBlocking, prio_greatest);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->plan_hint, sizeof(unsigned) * 2 * kHintWords, hipHostMallocDefault);
     if (e == hipSuccess)
         for (int i = 0; i < 2 * kHintWords; ++i) c->plan_hint[i] = (i % kHintWords) < kHintWords - 8 ? 0x7f800000u : 0u;  // +inf: nothing known; flags clear
@@ -892,6 +910,7 @@ int slab_transition_once(irs_ctx* c, const irs_io* io_in, hipStream_t st) {
     ex.planned_ = planned;
     Sched sch(s, cfg, C);
     sch.want_split_ = c->kn.slab_split != 0;
+    sch.fuse_noise_ = c->kn.fuse_noise != 0;
     if (!c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));
     c->dmax_clean = false;
     int energy_ar = -1;
@@ -1058,6 +1077,7 @@ int irs_slab_trace(const irs_config* cfg, const irs_slab_config* scfg, int rank,
     for (int k = 0; k < plan.n; ++k) plan.h[k] = h[k];
     if (plan_rounds(plan, s.gmax, world > 1 ? s.min_slab : 1 << 30)) return 1;
     Sched sch(s, *cfg, cfg->no_chains);
+    sch.fuse_noise_ = global_knobs().fuse_noise != 0;
     int energy_ar = -1;
     sch.head(true, true, plan.fw[0] > 1 ? plan.fw[0] : 1, &energy_ar);
     sch.forward_planned(plan);

@@ -186,6 +186,236 @@ void launch_sobolev_march(const float* in, float* out, const Taps& taps, int pla
 }
 
 // ------------------------------------------------------------------------------------------------
+// SGLD.forward fused into the smoothing kernel (utils/functions.py:76-84 + 98-109): the perturbed velocity v + sqrt(2 tau) sigma eps
+// is formed while the planes are staged and never written to memory (the two-kernel form moved 878 MB for a 403 MB stage at
+// 256^3).  One Philox4x32-10 call yields the six normals of a voxel PAIR (z even, z + 1) x three channels -- exactly the mapping
+// of perturb_kernel (field_kernels.hip), so a chain draws the same noise with either form -- which is why this kernel takes
+// all three channels of a tile at once: 512 threads, 32 x 32 columns, the z windows of 3 columns x 3 channels per thread in
+// registers, the normals of the odd plane of the pair generated last kept for the next iteration.  Replicate padding: a plane /
+// column outside the volume is a copy of the border one INCLUDING its noise (it is the perturbed field that is padded), which
+// the clamped coordinates of the counter give for free.  Same tap order as sobolev_march_kernel: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPsBlock = 512, PSX = 32, PSY = 32;
+
+struct NoiseSrc {
+    const float* sigma;       // (C,3,D,H,W) or nullptr (= 1)
+    const float* eps;         // injected standard normals or nullptr (Philox)
+    float amp;                // sqrt(2 tau)
+    uint64_t seed, iteration;
+    const uint64_t* dev_iter; // device-side Philox counter (overrides `iteration`)
+};
+
+template <int S, bool SIGMA, bool EPS>
+__global__ __launch_bounds__(kPsBlock) void perturb_sobolev_march_kernel(const float* __restrict__ v, NoiseSrc ns,
+                                                                         float* __restrict__ out, Taps taps, Vol vol,
+                                                                         unsigned* __restrict__ dmax0, float inv_pow,
+                                                                         int seg_len, int nseg) {
+    constexpr int NT = 2 * S + 1, PX = PSX + 2 * S, PY = PSY + 2 * S, PN = PX * PY;
+    constexpr int NIT = (PN + kPsBlock - 1) / kPsBlock;
+    constexpr int NY = PX * PSY, NITY = (NY + kPsBlock - 1) / kPsBlock;
+    constexpr int NOUT = PSX * PSY / kPsBlock, ROWS = kPsBlock / PSX;
+    static_assert(PSX * PSY % kPsBlock == 0 && kPsBlock % PSX == 0, "tile shape");
+    __shared__ float P1[3 * PN];
+    __shared__ float P2[3 * NY];
+    __shared__ float red[3 * (kPsBlock / kWave)];
+
+    const Blk3 blk = swizzled_block();
+    const int chain = blk.z / nseg, seg = blk.z % nseg;
+    const int ox = blk.x * PSX, oy = blk.y * PSY;
+    const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
+    const int64_t HW = (int64_t)vol.H * vol.W, cb = (int64_t)chain * 3 * vol.V;
+    const float* __restrict__ src = v + cb;
+    const float* __restrict__ sgp = SIGMA ? ns.sigma + cb : nullptr;
+    const float* __restrict__ epp = EPS ? ns.eps + cb : nullptr;
+    float* __restrict__ dst = out + cb;
+    const uint64_t iter = EPS ? 0ull : (ns.dev_iter ? *ns.dev_iter : ns.iteration);
+    const uint64_t chain_base = (uint64_t)chain * (uint64_t)vol.Vg;
+
+    float k[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) k[t] = taps.k[t];
+
+    unsigned coff[NIT];  // element offset (y * W + x, clamped = replicate padding in x / y) of the columns this thread owns
+    bool cval[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * kPsBlock;
+        const int px = i % PX, py = i / PX;
+        const int cx = min(max(ox - S + px, 0), vol.W - 1), cy = min(max(oy - S + py, 0), vol.H - 1);
+        cval[it] = i < PN;
+        coff[it] = (unsigned)(cy * vol.W + cx);
+    }
+    const int lx = threadIdx.x % PSX, ly = threadIdx.x / PSX;
+
+    float win[NIT][3][NT];
+    float pend[NIT][3];                         // the perturbed plane in flight (enters the windows at the next shift)
+    float stash[NIT][3];                        // normals of the odd plane of the pair generated last
+    int stash_pair = -(1 << 30);
+    int plane_in_flight = -(1 << 30);           // clamped index of the plane held in `pend`
+    // issue the loads of plane p, generate its noise meanwhile (the Philox rounds hide the load latency), combine:
+    // SGLD.forward with perturb_kernel's arithmetic, v + (amp * sigma) * n
+    auto fetch = [&](int p) {
+        const int pc = min(max(p, 0), vol.D - 1);
+        if (pc == plane_in_flight) return;      // replicate padding in z: the border plane again, noise included
+        plane_in_flight = pc;
+        const int64_t zo = (int64_t)pc * HW;
+        float tv[NIT][3], tn[NIT][3], tsg[NIT][3];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (cval[it]) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    tv[it][c] = (src + c * vol.V + zo)[coff[it]];
+                    if (SIGMA) tsg[it][c] = (sgp + c * vol.V + zo)[coff[it]];
+                    if (EPS) tn[it][c] = (epp + c * vol.V + zo)[coff[it]];
+                }
+            }
+        if (!EPS) {
+            const int pair = pc >> 1;
+            if (pair != stash_pair) {           // (uniform branch)
+                stash_pair = pair;
+                const uint64_t za = (uint64_t)(2 * pair) * (uint64_t)HW;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    if (cval[it]) {
+                        const uint64_t idx = chain_base + za + coff[it];  // global voxel index of the pair's even plane
+                        const U4 r = philox4x32_10(U4{(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)iter, 0x5347u ^ (uint32_t)(iter >> 32)},
+                                                   (uint32_t)ns.seed, (uint32_t)(ns.seed >> 32));
+                        uint32_t w[6];
+                        split21(r, w);
+                        float e0, e1, e2, o0, o1, o2;  // even plane: channels 0..2, odd plane: channels 0..2 (perturb_kernel's order)
+                        box_muller21(w[0], w[1], e0, e1);
+                        box_muller21(w[2], w[3], e2, o0);
+                        box_muller21(w[4], w[5], o1, o2);
+                        const bool odd = (pc & 1) != 0;
+                        tn[it][0] = odd ? o0 : e0;
+                        tn[it][1] = odd ? o1 : e1;
+                        tn[it][2] = odd ? o2 : e2;
+                        stash[it][0] = o0;
+                        stash[it][1] = o1;
+                        stash[it][2] = o2;
+                    }
+            } else {                            // the odd plane of the pair generated for the plane before
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) tn[it][c] = stash[it][c];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                pend[it][c] = cval[it] ? __fadd_rn(tv[it][c], __fmul_rn(__fmul_rn(ns.amp, SIGMA ? tsg[it][c] : 1.0f), tn[it][c])) : 0.0f;
+    };
+    auto perturbed = [&](int it, int c) { return pend[it][c]; };
+
+    // run-in: planes z0 - S .. z0 + S - 1 occupy window entries 1 .. 2S (entry 0 is shifted out first)
+#pragma unroll
+    for (int t = 1; t < NT; ++t) {
+        fetch(z0 - S + t - 1);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) win[it][c][t] = perturbed(it, c);
+    }
+    fetch(z0 + S);
+
+    float m[3] = {0.0f, 0.0f, 0.0f};
+    for (int z = z0; z < z1; ++z) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int t = 0; t < NT - 1; ++t) win[it][c][t] = win[it][c][t + 1];
+                win[it][c][NT - 1] = perturbed(it, c);
+            }
+        if (z + 1 < z1) fetch(z + 1 + S);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (!cval[it]) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc = fmaf(k[t], win[it][c][t], acc);
+                P1[c * PN + threadIdx.x + it * kPsBlock] = acc;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+            const int j = threadIdx.x + it * kPsBlock;
+            if (j >= NY) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc = fmaf(k[t], P1[c * PN + j + t * PX], acc);
+                P2[c * NY + j] = acc;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const int yy = ly + o * ROWS;
+            const int gx = ox + lx, gy = oy + yy;
+            if (gx >= vol.W || gy >= vol.H) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc = fmaf(k[t], P2[c * NY + yy * PX + lx + t], acc);
+                dst[c * vol.V + (int64_t)z * HW + (unsigned)(gy * vol.W + gx)] = acc;
+                m[c] = fmaxf(m[c], fabsf(acc));
+            }
+        }
+        // (P1 is rewritten after the next iteration's window shift, P2 only after the next first barrier: see sobolev_march_kernel)
+    }
+    if (dmax0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float mc = m[c];
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) mc = fmaxf(mc, __shfl_down(mc, off, kWave));
+            if ((threadIdx.x & (kWave - 1)) == 0) red[c * (kPsBlock / kWave) + threadIdx.x / kWave] = mc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float mm = 0.0f;
+            for (int w = 0; w < kPsBlock / kWave; ++w) mm = fmaxf(mm, red[threadIdx.x * (kPsBlock / kWave) + w]);
+            atomic_max_bits(dmax0 + chain * 4 + threadIdx.x, mm * inv_pow);  // |d_0| in voxels (see sobolev_march_kernel)
+        }
+    }
+}
+
+void launch_perturb_sobolev_march(const float* v, const float* sigma, const float* eps, float amp, float* out, const Taps& taps,
+                                  int C, Vol vol, unsigned* dmax0, int no_steps, uint64_t seed, uint64_t iteration,
+                                  const uint64_t* dev_iteration, hipStream_t st) {
+    const int ntx = (vol.W + PSX - 1) / PSX, nty = (vol.H + PSY - 1) / PSY;
+    const int seg_len = pick_seg_len(vol.nz, (int64_t)ntx * nty * C, 4, global_knobs().sobolev_seg, 512);
+    const int nseg = (vol.nz + seg_len - 1) / seg_len;
+    const float inv_pow = 1.0f / (float)(1 << no_steps);
+    const dim3 grid(ntx, nty, (unsigned)(nseg * C));
+    const NoiseSrc ns{sigma, eps, amp, seed, iteration, dev_iteration};
+#define IRS_PS(SS, SG, EP) hipLaunchKernelGGL((perturb_sobolev_march_kernel<SS, SG, EP>), grid, dim3(kPsBlock), 0, st, v, ns, out, taps, vol, dmax0, inv_pow, seg_len, nseg)
+#define IRS_PS2(SS)                                   \
+    if (sigma && eps) IRS_PS(SS, true, true);         \
+    else if (sigma) IRS_PS(SS, true, false);          \
+    else if (eps) IRS_PS(SS, false, true);            \
+    else IRS_PS(SS, false, false)
+    switch (taps.s) {
+        case 1: IRS_PS2(1); break;
+        case 2: IRS_PS2(2); break;
+        case 3: IRS_PS2(3); break;
+        default: IRS_PS2(4); break;
+    }
+#undef IRS_PS2
+#undef IRS_PS
+}
+
+// ------------------------------------------------------------------------------------------------
 // LCC map (model/loss.py:53-59,102-111):  u = box(I)/n,  w = I - u,  var = box(w^2)/n,  sigma = sqrt(var + 1e-10),
 // out = w / sigma  (MAP: fhat - w / sigma, the fixed side being pre-normalised once).  box = (2S+1)^3 all-ones filter
 // with REPLICATE padding -- of I for the first box, of w^2 for the second (so the second box indexes clamped
@@ -659,7 +889,7 @@ template <int KMAX>
 __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __restrict__ z, const uint8_t* __restrict__ mask,
                                                                const DevState* __restrict__ state, int want_vd,
                                                                double* __restrict__ partials, Vol vol, int seg_len, int nseg,
-                                                               int ntx, int nty, TailScratch tail, double* __restrict__ total_out) {
+                                                               int ntx, int nty) {
     constexpr int NIT = (TPN + kStBlock - 1) / kStBlock;
     constexpr int NACC = 5 + 2 * KMAX;  // n, sum x^2, 3 lag-1 products, KMAX dNLL/dlog_std, KMAX responsibility sums
     __shared__ float X[TPN];
@@ -761,23 +991,20 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
             p[5 + IRS_MAX_COMPONENTS + k] = k < KMAX ? acc[5 + KMAX + (k < KMAX ? k : 0)] : 0.0;
         }
     }
-    // the launch's total, summed in fixed order by the blocks that finish last: the scalar stage reads ONE row (common.h)
-    if (total_out) tail_reduce<kStatVals>(partials, (int)gridDim.x, (int)blockIdx.x, tail, total_out);
 }
 
 void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, int blocks,
-                        Vol vol, int K, hipStream_t st, TailScratch tail, double* total) {
-    if (blocks > kTailGroup * kTailMaxGroups) total = nullptr;
+                        Vol vol, int K, hipStream_t st) {
     const int seg_env = global_knobs().stats_seg;
     const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + TTY - 1) / TTY), 4, seg_env, 2048);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + TTY - 1) / TTY;
     if (K >= 1 && K <= 4)
         hipLaunchKernelGGL(stats_march_kernel<4>, dim3(blocks), dim3(kStBlock), 0, st, z, mask, (const DevState*)dev_state, want_vd,
-                           partials, vol, seg_len, nseg, ntx, nty, tail, total);
+                           partials, vol, seg_len, nseg, ntx, nty);
     else
         hipLaunchKernelGGL(stats_march_kernel<IRS_MAX_COMPONENTS>, dim3(blocks), dim3(kStBlock), 0, st, z, mask,
-                           (const DevState*)dev_state, want_vd, partials, vol, seg_len, nseg, ntx, nty, tail, total);
+                           (const DevState*)dev_state, want_vd, partials, vol, seg_len, nseg, ntx, nty);
 }
 
 // ------------------------------------------------------------------------------------------------

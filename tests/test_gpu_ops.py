@@ -66,6 +66,32 @@ def test_sobolev_tile_shapes(s):
     assert torch.equal(outs['small'], outs['big'])
 
 
+@pytest.mark.parametrize('dims', [(37, 45, 70), (16, 16, 16), (64, 64, 64)])
+@pytest.mark.parametrize('s', [1, 3])
+def test_noise_generated_while_staging_is_the_same_noise(dims, s):
+    """SGLD.forward fused into the smoothing kernel (the perturbed velocity is never written) against the two-kernel form: the
+    same Philox counters -> the same normals -> bit-identical smoothed fields, for in-kernel noise, injected eps, and a sigma
+    field; ragged volumes leave every tile edge partially filled and make the replicate padding (noise included) matter."""
+    from ir_sgmcmc_amd._lib import option_set
+    g = torch.Generator().manual_seed(9)
+    v = dev(torch.randn(2, 3, *dims, generator=g))
+    sigma = dev(torch.rand(2, 3, *dims, generator=g) + 0.5)
+    eps = dev(torch.randn(2, 3, *dims, generator=g))
+    k = G.sobolev_kernel_1d(s, 0.5)
+    cases = [dict(tau=0.4, seed=5, iteration=7), dict(tau=0.4, seed=5, iteration=7, sigma=sigma), dict(tau=0.4, eps=eps),
+             dict(tau=0.4, eps=eps, sigma=sigma)]
+    outs = {}
+    try:
+        for fuse in (0, 1):
+            option_set('fuse_noise', fuse)
+            outs[fuse] = [G.perturb_smooth(v, k, **kw) for kw in cases]
+    finally:
+        option_set('fuse_noise', 1)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[1][0], outs[1][2])   # (different noise sources do differ)
+
+
 def test_philox_noise_statistics():
     v = torch.zeros(1, 3, 64, 64, 64, device=DEV)
     a = G.perturb_smooth(v, None, tau=0.5, seed=7, iteration=3)   # sqrt(2 tau) = 1 -> N(0,1)

@@ -232,8 +232,10 @@ def test_in_kernel_noise_path_runs_and_is_reproducible():
     fixed = to_dev({k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'})
     moving = to_dev({k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'})
     res = []
-    for seed in (5, 5, 6):
+    for i, seed in enumerate((5, 5, 6)):
         eng = TransitionEngine(EngineConfig(dims=(N, N, N), seed=seed), DEV)
+        if i == 1:
+            eng.option('fuse_noise', 0)   # the two-kernel form of perturbation + smoothing draws the same noise: the same chain
         fd, md = eng.prepare(fixed, moving)
         eng.gmm_init(fd, md)
         v = torch.zeros(1, 3, N, N, N, device=DEV)
@@ -295,7 +297,7 @@ def test_misprediction_is_recovered_not_fatal():
     moving = to_dev({k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'})
     g = torch.Generator().manual_seed(3)
     v0 = perturb_smooth(torch.randn(1, 3, N, N, N, generator=g).to(DEV), sobolev_kernel_1d(3, 0.5))
-    v0 = v0 * (3.5 / float(v0.abs().max()))   # d_11, d_12 beyond one voxel: the radius-1 adjoint alone is wrong for them
+    v0 = v0 * (9.0 / float(v0.abs().max()))   # d_10, d_11 beyond one voxel: the radius-1 adjoint alone is wrong for them
     res = {}
     for mode in (0, 3):
         eng = TransitionEngine(EngineConfig(dims=(N, N, N), seed=11), DEV)

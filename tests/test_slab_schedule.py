@@ -72,7 +72,7 @@ class Replay:
         self.a, self.b, self.lo, self.hi = (self.lay[k] for k in ('a', 'b', 'lo', 'hi'))
         self.h = h
         self.ops = trace(cfg, rank, world, h, ghost_max=ghost_max)
-        self.valid = {L.IRS_SB_V: {z: ('input', 0) for z in range(self.a, self.b)}}   # buffer -> {plane: tensor it holds}
+        self.valid = {L.IRS_SB_V: {z: (-1, 0) for z in range(self.a, self.b)}}   # tag (-1, 0): the chain state as the caller handed it over   # buffer -> {plane: tensor it holds}
         self.flight = {}                                                        # exchange id -> (buf, sent planes, ghost planes, reqs, bufs)
         self.written = {}                                                       # (stage, k) -> planes written so far
         self.n_exchanges = 0
@@ -117,6 +117,8 @@ class Replay:
             tag = (o['stage'], o['k']) if o['stage'] != L.IRS_SG_COPY_V else (L.IRS_SG_PERTURB, 0)
             if o['stage'] == L.IRS_SG_PERTURB and o['out'] == L.IRS_SB_VS:
                 tag = (L.IRS_SG_SMOOTH, 0)  # no Sobolev smoothing: the perturbed field is v_s
+            if o['stage'] == L.IRS_SG_SMOOTH:
+                tag = (L.IRS_SG_SMOOTH, 0)  # (k = 1 marks the form that generates the Langevin noise while staging: same tensor)
             for f in self.flight.values():
                 assert not (f[0] == o['out'] and wins & (f[1] | f[2])), f'rank {self.rank}: {o} overwrites strips of buffer {o["out"]} in flight'
             self.valid.setdefault(o['out'], {}).update({z: tag for z in wins})
