@@ -8,8 +8,8 @@ virtual decimation, regulariser, backward, SGLD update) over one synthetic fixed
 in-kernel Philox noise.  One process per GPU.
 
 N > 1 (default `--decomp slab`, "scaling": "strong"): ONE chain, the volume split into N z-slabs; ghost planes travel
-between neighbouring GPUs through RCCL send / recv issued by the library on its communication stream, four small
-all-reduces per transition carry the partial sums (csrc/slab.hip).  value = transitions of that one
+between neighbouring GPUs through RCCL send / recv issued by the library on its (high-priority) communication stream, three small
+all-reduces per transition carry the displacement bounds and the partial sums (csrc/slab.hip).  value = transitions of that one
 chain / max-over-ranks wall time.  `--decomp chains` is the other, trivial, decomposition: independent chains per rank, no
 data-path collective (weak scaling).  Without a launcher (no WORLD_SIZE in the environment) `--gpus N` starts the N ranks
 itself, as child processes of torch.distributed.run, before anything touches a GPU.
@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is 
 BYTES_PER_VOXEL = {'gmm': 878.0, 'ssd': 854.0}  # algorithmic bytes / voxel / chain / transition
 BWD_STEP_BYTES_PER_VOXEL = 36.0
 FWD_STEP_BYTES_PER_VOXEL = 24.0
-TRAFFIC_PROFILE = os.path.join('profiles', 'r02_pmc_traffic.json')  # written by tools/profile_round.sh for THIS library build
+TRAFFIC_PROFILE = os.path.join('profiles', 'r03_pmc_traffic.json')  # written by tools/profile_round.sh for THIS library build
 
 
 def traffic_from_profile(n):

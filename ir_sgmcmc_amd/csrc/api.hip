@@ -39,7 +39,6 @@ static Knobs knobs_from_env() {
     k.fuse_warp_bwd = env_or("IRS_FUSE_WARP_BWD", k.fuse_warp_bwd);
     k.energy_in_update = env_or("IRS_ENERGY_IN_UPDATE", k.energy_in_update);
     k.fuse_noise = env_or("IRS_FUSE_NOISE", k.fuse_noise);
-    k.fuse_stats = env_or("IRS_FUSE_STATS", k.fuse_stats);
     k.recover = env_or("IRS_RECOVER", k.recover);
     k.coarse_box = env_or("IRS_COARSE_BOX", k.coarse_box);
     const char* tile = getenv("IRS_SOBOLEV_TILE");
@@ -71,7 +70,7 @@ int knob_set(Knobs& k, const char* name, int value) {
     };
     static const Entry table[] = {
         {"predict_variants", &Knobs::predict_variants}, {"run_ahead", &Knobs::run_ahead}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd},
-        {"energy_in_update", &Knobs::energy_in_update}, {"fuse_noise", &Knobs::fuse_noise}, {"fuse_stats", &Knobs::fuse_stats},
+        {"energy_in_update", &Knobs::energy_in_update}, {"fuse_noise", &Knobs::fuse_noise},
         {"recover", &Knobs::recover}, {"coarse_box", &Knobs::coarse_box}, {"sobolev_tile", &Knobs::sobolev_tile},
         {"march_seg", &Knobs::march_seg}, {"march_seg_fwd", &Knobs::march_seg_fwd}, {"swz_run", &Knobs::swz_run},
         {"seg_min_blocks", &Knobs::seg_min_blocks}, {"seg_min_len", &Knobs::seg_min_len}, {"sobolev_seg", &Knobs::sobolev_seg},

@@ -86,7 +86,6 @@ struct Knobs {
     int fuse_warp_bwd = 1;     // IRS_FUSE_WARP_BWD     backward warp folded into the first adjoint step
     int energy_in_update = 1;  // IRS_ENERGY_IN_UPDATE  regulariser energy as a by-product of the update kernel (L2 family)
     int fuse_noise = 1;        // IRS_FUSE_NOISE        Langevin noise generated while the smoothing kernel stages its planes
-    int fuse_stats = 1;        // IRS_FUSE_STATS        mixture statistics of the first chain accumulated by the LCC map kernel
     int recover = 1;           // IRS_RECOVER           keep the previous velocity and re-run a transition whose variant prediction failed
     int coarse_box = 1;        // IRS_COARSE_BOX        any-radius adjoint: source boxes from the coarse displacement extrema
     int sobolev_tile = 0;      // IRS_SOBOLEV_TILE      0: by size; 1: 32 x 16; 2: 64 x 32 ("small" / "big")

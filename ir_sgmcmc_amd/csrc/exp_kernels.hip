@@ -482,6 +482,13 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #ifndef IRS_MARCH_WAVES
 #define IRS_MARCH_WAVES 4
 #endif
+// Two round-3 experiments on the radius-1 adjoint, both measured SLOWER and not kept:
+//  * its own-term global-memory branch is dead code for max|d_k| < 1; compiled out (125 instead of 128 VGPRs) the kernel took
+//    217.5 instead of 202.0 us per launch -- the smaller kernel schedules worse;
+//  * a build that records, per committed source plane, which signs the relative positions take per axis (six __any + one LDS
+//    word per wave) and skips the gather candidates whose hat weight is then exactly 0 behind scalar branches (27 -> 18 / 12 / 8
+//    candidates; bit-identical results): 199 instead of 166 us per launch on a smooth 6-voxel field where most planes qualify,
+//    243 instead of 199 us on a smooth 3-voxel one.
 // The radius-1 adjoint only runs for max|d_k| < 1 (selected on the device from the exact bound): the eight corners of a voxel's
 // own sample then ALWAYS sit in the ring, and the global-memory fallback for taps that leave it is dead code.  1: keep it (A/B).
 #ifndef IRS_BWD_R1_FALLBACK
