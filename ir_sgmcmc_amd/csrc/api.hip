@@ -40,7 +40,6 @@ static Knobs knobs_from_env() {
     k.energy_in_update = env_or("IRS_ENERGY_IN_UPDATE", k.energy_in_update);
     k.fuse_noise = env_or("IRS_FUSE_NOISE", k.fuse_noise);
     k.recover = env_or("IRS_RECOVER", k.recover);
-    k.bwd_shift = env_or("IRS_BWD_SHIFT", k.bwd_shift);
     k.coarse_box = env_or("IRS_COARSE_BOX", k.coarse_box);
     const char* tile = getenv("IRS_SOBOLEV_TILE");
     if (tile && *tile) k.sobolev_tile = tile[0] == 'b' ? 2 : (tile[0] == 's' ? 1 : atoi(tile));
@@ -72,7 +71,7 @@ int knob_set(Knobs& k, const char* name, int value) {
     static const Entry table[] = {
         {"predict_variants", &Knobs::predict_variants}, {"run_ahead", &Knobs::run_ahead}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd},
         {"energy_in_update", &Knobs::energy_in_update}, {"fuse_noise", &Knobs::fuse_noise},
-        {"recover", &Knobs::recover}, {"bwd_shift", &Knobs::bwd_shift}, {"coarse_box", &Knobs::coarse_box}, {"sobolev_tile", &Knobs::sobolev_tile},
+        {"recover", &Knobs::recover}, {"coarse_box", &Knobs::coarse_box}, {"sobolev_tile", &Knobs::sobolev_tile},
         {"march_seg", &Knobs::march_seg}, {"march_seg_fwd", &Knobs::march_seg_fwd}, {"swz_run", &Knobs::swz_run},
         {"seg_min_blocks", &Knobs::seg_min_blocks}, {"seg_min_len", &Knobs::seg_min_len}, {"sobolev_seg", &Knobs::sobolev_seg},
         {"lcc_seg", &Knobs::lcc_seg}, {"stats_seg", &Knobs::stats_seg}, {"update_seg", &Knobs::update_seg},
@@ -226,10 +225,8 @@ static int exp_backward(const float* v, const float* steps, const float* g_last,
         const float* dk = k == 0 ? v : steps + (int64_t)(k - 1) * field;
         // every variant is launched (radius-1 / radius-2 gather, any-radius fixed-point scatter); the device picks by max|d_k|
         launch_field_absmax(dk, k == 0, no_steps, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, C, vol, st);
-        const bool shift = k > 0 && global_knobs().bwd_shift && global_knobs().coarse_box;
-        const bool shifted = launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, false,
-                                                       nullptr, 0, nullptr, st, shift ? cmm : nullptr);
-        launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, 2, nullptr, 0, cmm, st, shifted);
+        launch_exp_step_bwd_march(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, false, nullptr, 0, nullptr, st);
+        launch_exp_step_bwd_lds(G, dk, out, k == 0, no_steps, C, vol, lin, dmax + (int64_t)k * IRS_MAX_CHAINS * 4, 2, 2, nullptr, 0, cmm, st);
         G = out;
         cur ^= 1;
     }
@@ -858,11 +855,9 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
             const bool sa = k < 32 && skip_any[k], s2 = k < 32 && skip_r2[k];
             // timed mode: the end event of step k closes right after the radius-1 kernel, so that exp_bwd_kernel_ms is the time
             // of the dominant kernel alone (as rocprofv3 reports it), not of the idle variants after it
-            // (steps that may reach a voxel: tiles with large but smooth displacements go to the shifted-window gather)
-            const bool shift = !s2 && k > 0 && c->kn.bwd_shift && global_knobs().coarse_box;
-            const bool shifted = launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, s2 ? 1 : 2, sa, gscale, lay,
-                                                           timed ? c->ev_bwd[2 * k + 1] : nullptr, st, shift ? c->cmm : nullptr);
-            if (!sa) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, 2, gscale, lay, c->cmm, st, shifted);
+            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, s2 ? 1 : 2, sa, gscale, lay,
+                                      timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
+            if (!sa) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, 2, gscale, lay, c->cmm, st);
             G = out;
             cur ^= 1;
         }

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
                                                                 float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
                                                                 const unsigned* __restrict__ dmax, TileGrid tg,
                                                                 int gather_radius, const float* __restrict__ gscale, int lay,
-                                                                const float* __restrict__ cmm, const int* __restrict__ tinfo) {
+                                                                const float* __restrict__ cmm) {
     using B = ExpBox<H>;
     const Lay3 LD = lay3(lay & 1, vol.V), LG = lay3(lay & 2, vol.V), LO = lay3(lay & 4, vol.V);
     constexpr bool STAGED = H > 0;  // H = 0: no staged copy of d at all (sources and taps are far from the tile anyway)
@@ -289,7 +289,6 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
     const int hy = (int)floorf(__uint_as_float(dmax[chain * 4 + 1])) + 1;
     const int hz = (int)floorf(__uint_as_float(dmax[chain * 4 + 2])) + 1;
     if (hx <= gather_radius && hy <= gather_radius && hz <= gather_radius) continue;  // a gather kernel owns this chain
-    if (tinfo && (tinfo[2 * tile] & 1)) continue;  // the shifted-window kernel has taken this tile
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
     const float* c0 = dk + cb;
@@ -424,147 +423,31 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Shifted-window gather for LARGE BUT SMOOTH displacements (round 3).  A converged registration carries voxels of displacement,
-// but smoothly: inside one 32 x 8 x 8 tile of outputs the displacements of the sources that reach it differ by less than a voxel
-// around some integer offset D0.  Then every source s that contributes to an output y of the tile lies within one voxel of
-// y - D0, its relative position minus D0 is in (-1, 1), and the radius-1 gather -- on the window tile - D0 instead of the tile --
-// computes the adjoint exactly, at the radius-1 kernel's speed instead of the radius-2 gather's (125 candidates) or the
-// any-radius scatter's.  WHICH tiles qualify is decided on the device, tile by tile, from the coarse grid of displacement
-// extrema, with the box argument of exp_bwd_lds_kernel: B0 = tile +- (global bound + 1) contains every source that can reach the
-// tile; two rounds over the cells covering the box shrink it to (tile - local displacement range) +- 1; the extrema over the
-// cells of the final box bound the displacement of every contributing source.  A tile qualifies when on every axis
-// D0 - 1 < min d and max d < D0 + 1 (2e-3 margin: the grid holds v (n-1)/2, the kernel forms ((g+1)/2)(n-1)), and -- where it
-// touches the volume border, whose clip folds distant positions onto it -- only with D0 = 0 on that axis (|r| < 1 survives the
-// clip; a shifted window would not).  The other tiles stay with the radius-2 / any-radius kernels, which skip the qualified
-// ones.  Tile info: two ints per tile behind the coarse grid, [C][ntz][nty][ntx]:
-//   w0 = 1 | (D0x + 64) << 8 | (D0y + 64) << 16 | (D0z + 64) << 24     (0: not qualified)
-//   w1 = the same packing of E0, the integer offset near the displacement of the tile's OWN voxels (where their eight own-term
-//        corners sit): only a staging hint -- a corner outside the staged ring is read from global memory.
-// ------------------------------------------------------------------------------------------------
-static size_t coarse_grid_floats(Vol vol, int C) {
-    return (size_t)kCmm * C * ((vol.W + kCell - 1) / kCell) * ((vol.H + kCell - 1) / kCell) * ((vol.D + kCell - 1) / kCell);
-}
-static size_t tile_count(Vol vol, int C) {  // (full-volume decomposition; a z-window uses a prefix)
-    return (size_t)C * ((vol.W + ETX - 1) / ETX) * ((vol.H + ETY - 1) / ETY) * ((vol.D + ETZ - 1) / ETZ);
-}
-size_t coarse_minmax_bytes(Vol vol, int C) { return sizeof(float) * coarse_grid_floats(vol, C) + 2 * sizeof(int) * tile_count(vol, C); }
-static int* tile_info(float* cmm, Vol vol, int C) { return cmm ? reinterpret_cast<int*>(cmm + coarse_grid_floats(vol, C)) : nullptr; }
-
-__device__ __forceinline__ int pack_off(int x, int y, int z) { return 1 | ((x + 64) << 8) | ((y + 64) << 16) | ((z + 64) << 24); }
-__device__ __forceinline__ void unpack_off(int w, int& x, int& y, int& z) {
-    x = ((w >> 8) & 0xFF) - 64;
-    y = ((w >> 16) & 0xFF) - 64;
-    z = ((w >> 24) & 0xFF) - 64;
-}
-
-// one wavefront per 32 x 8 x 8 tile
-__global__ __launch_bounds__(kBlock) void qualify_tiles_kernel(const float* __restrict__ cmm, int* __restrict__ tinfo, Vol vol,
-                                                               const unsigned* __restrict__ dmax, TileGrid tg) {
-    const int tile = blockIdx.x * (kBlock / kWave) + (int)(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1);
-    if (tile >= tg.total) return;
-    int t_ = tile;
-    const int tx = t_ % tg.ntx;
-    t_ /= tg.ntx;
-    const int ty = t_ % tg.nty;
-    t_ /= tg.nty;
-    const int tz = t_ % tg.ntz, chain = t_ / tg.ntz;
-    const int hx = (int)floorf(__uint_as_float(dmax[chain * 4 + 0])) + 1, hy = (int)floorf(__uint_as_float(dmax[chain * 4 + 1])) + 1,
-              hz = (int)floorf(__uint_as_float(dmax[chain * 4 + 2])) + 1;
-    if (hx <= 1 && hy <= 1 && hz <= 1) return;  // the radius-1 kernel owns the chain: the tile info is not read
-    const int nax[3] = {vol.W, vol.H, vol.D};
-    const int tlo[3] = {tx * ETX, ty * ETY, vol.z0 + tz * ETZ};
-    const int thi[3] = {min(tlo[0] + ETX, vol.W) - 1, min(tlo[1] + ETY, vol.H) - 1, min(tlo[2] + ETZ, vol.D) - 1};
-    const int h[3] = {hx, hy, hz};
-    int lo[3], hi[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = max(tlo[a] - h[a], 0);
-        hi[a] = min(thi[a] + h[a], nax[a] - 1);
-    }
-    const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.D + kCell - 1) / kCell;
-    const float* __restrict__ cm = cmm + (int64_t)chain * ncx * ncy * ncz * kCmm;
-    auto extrema = [&](const int (&l)[3], const int (&u)[3], float (&m6)[6]) {  // min / max of d per axis over the cells covering [l, u]
-        const int c0x = l[0] / kCell, c0y = l[1] / kCell, c0z = l[2] / kCell;
-        const int nx_ = u[0] / kCell - c0x + 1, ny_ = u[1] / kCell - c0y + 1, nz_ = u[2] / kCell - c0z + 1;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) m6[j] = (j & 1) ? -3.0e38f : 3.0e38f;
-        for (int i = lane; i < nx_ * ny_ * nz_; i += kWave) {
-            const int cell = ((c0z + i / (nx_ * ny_)) * ncy + c0y + (i / nx_) % ny_) * ncx + c0x + i % nx_;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float o = cm[cell * kCmm + j];
-                m6[j] = (j & 1) ? fmaxf(m6[j], o) : fminf(m6[j], o);
-            }
-        }
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float o = __shfl_xor(m6[j], off, kWave);
-                m6[j] = (j & 1) ? fmaxf(m6[j], o) : fminf(m6[j], o);
-            }
-    };
-    float m6[6];
-    for (int round = 0; round < 3; ++round) {  // (the third round only collects the extrema over the final box)
-        extrema(lo, hi, m6);
-        if (round == 2) break;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float mn = m6[2 * a], mx = m6[2 * a + 1];
-            if (!(mn <= mx) || fabsf(mn) > 1.0e6f || fabsf(mx) > 1.0e6f) continue;
-            if (tlo[a] - 1 > 0) lo[a] = max(lo[a], (int)floorf((float)(tlo[a] - 1) - mx - 1e-3f));  // (exp_bwd_lds_kernel's rule)
-            if (thi[a] + 1 < nax[a] - 1) hi[a] = min(hi[a], (int)ceilf((float)(thi[a] + 1) - mn + 1e-3f));
-        }
-    }
-    bool ok = true;
-    int D0[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float mn = m6[2 * a], mx = m6[2 * a + 1];
-        ok = ok && mn <= mx && fabsf(mn) < 60.0f && fabsf(mx) < 60.0f;
-        D0[a] = ok ? (int)rintf(0.5f * (mn + mx)) : 0;
-        if (tlo[a] <= 1 || thi[a] >= nax[a] - 2) D0[a] = 0;  // at (or next to) the border: the clip only keeps |r| < 1 for D0 = 0
-        ok = ok && mx < (float)D0[a] + 1.0f - 2e-3f && mn > (float)D0[a] - 1.0f + 2e-3f;
-    }
-    float o6[6];
-    extrema(tlo, thi, o6);  // where the tile's own samples point
-    int E0[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float mid = 0.5f * (o6[2 * a] + o6[2 * a + 1]);
-        E0[a] = fabsf(mid) < 60.0f ? (int)rintf(mid) : 0;
-    }
-    if (lane == 0) {
-        tinfo[2 * tile] = ok ? pack_off(D0[0], D0[1], D0[2]) : 0;
-        tinfo[2 * tile + 1] = pack_off(E0[0], E0[1], E0[2]);
-    }
+size_t coarse_minmax_bytes(Vol vol, int C) {
+    return sizeof(float) * kCmm * (size_t)C * ((vol.W + kCell - 1) / kCell) * ((vol.H + kCell - 1) / kCell) * ((vol.D + kCell - 1) / kCell);
 }
 
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                              Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, int lay,
-                             float* cmm, hipStream_t st, bool shifted) {
+                             float* cmm, hipStream_t st) {
     if (vol.nzb > 0) {  // two windows (slab boundary strips): this rarely selected kernel takes them one launch each
         launch_exp_step_bwd_lds(G, dk, gout, prescale_in, no_steps, C, window(vol, vol.z0, vol.z0 + vol.nz), lin, dmax, halo,
-                                gather_radius, gscale, lay, cmm, st, false);
+                                gather_radius, gscale, lay, cmm, st);
         launch_exp_step_bwd_lds(G, dk, gout, prescale_in, no_steps, C, window(vol, vol.z0b, vol.z0b + vol.nzb), lin, dmax, halo,
-                                gather_radius, gscale, lay, cmm, st, false);
+                                gather_radius, gscale, lay, cmm, st);
         return;
     }
     TileGrid tz;
     const dim3 grid = exp_grid(vol, C, &tz);
     const Scale3L sc = make_scale_l(vol, no_steps);
-    // `shifted`: launch_exp_step_bwd_march has already built the coarse grid of this step and qualified tiles for the
-    // shifted-window kernel (this kernel skips those)
-    const int* tinfo = shifted ? tile_info(cmm, vol, C) : nullptr;
-    if (!global_knobs().coarse_box && !shifted) cmm = nullptr;  // parity test of the two source boxes
-    if (cmm && !shifted) {  // coarse displacement extrema / gradient maxima (coarse_minmax_bytes(vol, C) of scratch)
+    if (!global_knobs().coarse_box) cmm = nullptr;  // parity test of the two source boxes
+    if (cmm) {  // coarse displacement extrema / gradient maxima (coarse_minmax_bytes(vol, C) of scratch)
         const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.D + kCell - 1) / kCell;
         const dim3 cg((unsigned)(((ncx + 7) / 8) * ncy * ncz), (unsigned)C);
         if (prescale_in) hipLaunchKernelGGL((coarse_minmax_kernel<true>), cg, dim3(kWave), 0, st, dk, G, gscale, cmm, vol, sc, dmax, gather_radius, ncx, ncy, ncz, lay);
         else hipLaunchKernelGGL((coarse_minmax_kernel<false>), cg, dim3(kWave), 0, st, dk, G, gscale, cmm, vol, sc, dmax, gather_radius, ncx, ncy, ncz, lay);
     }
-#define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay, cmm, tinfo)
+#define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay, cmm)
     // With the gather variants in front (gather_radius >= 2) the staged box of d around the tile is of little use (sources
     // and taps are far away): H = 0 stages nothing (49 KB of accumulators instead of 111 KB of LDS -> three workgroups per CU)
     if (gather_radius >= 2) halo = 0;
@@ -713,8 +596,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                                                    float* __restrict__ gout, const Vol vol, const Lin lin, const Scale3L sc,
                                                    const unsigned* __restrict__ dmax, const int seg_len, const int nseg,
                                                    const int r_lo, const int own_rest, const int swz_run, const int tile_id,
-                                                   const dim3 tiles, const float* __restrict__ gscale, const int lay,
-                                                   const int* __restrict__ tinfo) {
+                                                   const dim3 tiles, const float* __restrict__ gscale, const int lay) {
     using M = March<PRESCALE, R>;
     constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
     // ring slot layout (9 floats per source, 8-byte fields so that the gather needs three ds_read_b64 per candidate):
@@ -731,8 +613,6 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
                        (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
     if (hs <= r_lo || (hs > R && !(R == 2 && own_rest))) return;  // another variant of this step owns the chain
-    // the shifted-window kernel has taken this tile (launched with 8-plane segments then: the tiles are the qualification's)
-    if (R == 2 && tinfo && (tinfo[2 * (((chain * nseg + seg) * (int)tiles.y + tby) * (int)tiles.x + tbx)] & 1)) return;
     const int ox = tbx * MTX, oy = tby * MTY;
     int z0, z1;
     seg_range(vol, seg, seg_len, z0, z1);
@@ -981,271 +861,6 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Radius-1 gather on a SHIFTED window (qualify_tiles_kernel above): for a tile whose contributing sources all have
-// displacements within a voxel of the integer offset D0, the sources of output y sit at y - D0 + {-1, 0, 1}^3.  The kernel is the
-// marching radius-1 gather in VIRTUAL source coordinates s~ = s + D0 (ring slot, hat offsets and accumulators are indexed by
-// s~, the loads go to s~ - D0, the relative position is r~ = clip(s + d(s)) - s~ in (-1, 1)), over 8-plane segments so that its
-// tiles are the 32 x 8 x 8 tiles the qualification speaks about.  The own term of an output voxel -- J^T G of the sample IT took
-// -- needs the eight corners of d around y + d(y), i.e. near y + E0: a second ring of d, staged from the window tile + E0 (E0 is
-// a hint: a corner outside that ring is read from global memory), and the voxel's own d and G, loaded per output plane.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kMarchBlock, 3) void exp_bwd_shift_kernel(const float* __restrict__ G, const float* __restrict__ dk,
-                                                                      float* __restrict__ gout, Vol vol, Lin lin,
-                                                                      const unsigned* __restrict__ dmax,
-                                                                      const int* __restrict__ tinfo, TileGrid tg,
-                                                                      const float* __restrict__ gscale, int lay) {
-    using M = March<false, 1>;
-    constexpr int R = 1, NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
-    __shared__ float2 q_xy[NP * PN], q_zg[NP * PN], q_g[NP * PN], q_d[NP * PN];
-    __shared__ float q_dz[NP * PN];
-    const int64_t V = vol.V, HW = (int64_t)vol.H * vol.W;
-    const Lay3 LD = lay3(lay & 1, V), LG = lay3(lay & 2, V), LO = lay3(lay & 4, V);
-    const float nxm = (float)(vol.W - 1), nym = (float)(vol.H - 1), nzm = (float)(vol.D - 1);
-    const int lx = threadIdx.x % MTX, ly = threadIdx.x / MTX;
-  for (int tile = blockIdx.x; tile < tg.total; tile += gridDim.x) {
-    const int w0 = tinfo[2 * tile];
-    int t_ = tile;
-    const int tbx = t_ % tg.ntx;
-    t_ /= tg.ntx;
-    const int tby = t_ % tg.nty;
-    t_ /= tg.nty;
-    const int tbz = t_ % tg.ntz, chain = t_ / tg.ntz;
-    const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
-                       (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
-    if (hs <= 1 || !(w0 & 1)) continue;  // the radius-1 kernel owns the chain / the tile did not qualify (uniform)
-    int D0x, D0y, D0z, E0x, E0y, E0z;
-    unpack_off(w0, D0x, D0y, D0z);
-    unpack_off(tinfo[2 * tile + 1], E0x, E0y, E0z);
-    const int ox = tbx * MTX, oy = tby * MTY;
-    const int z0 = vol.z0 + tbz * ETZ, z1 = min(z0 + ETZ, vol.z0 + vol.nz);
-    const int64_t cb = (int64_t)chain * 3 * V;
-    const float* __restrict__ dx_ = dk + cb;
-    const float* __restrict__ dy_ = dx_ + LD.cs;
-    const float* __restrict__ dz_ = dy_ + LD.cs;
-    const float* __restrict__ Gx_ = G + cb;
-    const float* __restrict__ Gy_ = Gx_ + LG.cs;
-    const float* __restrict__ Gz_ = Gy_ + LG.cs;
-    const float* __restrict__ gs_ = gscale ? gscale + (int64_t)chain * V : nullptr;
-    float* __restrict__ o = gout + cb;
-    const int x = ox + lx, y = oy + ly;
-    const bool col_in = x < vol.W && y < vol.H;
-
-    // staging: ring position i <-> virtual in-plane coordinate (ox - 1 + px, oy - 1 + py); its SOURCE lives D0 lower, the d of
-    // the own-term ring E0 higher
-    int sxy[NIT], exy[NIT];
-    bool sin_[NIT];
-    float slx[NIT], sly[NIT], sfx[NIT], sfy[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = threadIdx.x + it * kMarchBlock;
-        const int px = i % PX, py = i / PX;
-        const int ux = ox - R + px, uy = oy - R + py;
-        const int tx_ = ux - D0x, ty_ = uy - D0y;  // the source's true coordinates
-        sin_[it] = i < PN && (unsigned)tx_ < (unsigned)vol.W && (unsigned)ty_ < (unsigned)vol.H;
-        const int cx = min(max(tx_, 0), vol.W - 1), cy = min(max(ty_, 0), vol.H - 1);
-        sxy[it] = i < PN ? cy * vol.W + cx : -1;
-        slx[it] = lin.x[cx];
-        sly[it] = lin.y[cy];
-        sfx[it] = (float)ux;  // virtual coordinate: r~ = clipped position - (true coordinate + D0)
-        sfy[it] = (float)uy;
-        exy[it] = min(max(uy + E0y, 0), vol.H - 1) * vol.W + min(max(ux + E0x, 0), vol.W - 1);
-    }
-    float pre[NIT][6], pgs[NIT], pe[NIT][3];
-    auto load3 = [&](const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2, int em, unsigned off,
-                     float (&v)[3]) {
-        if (em == 3) {
-            const F3 t = ld3_off(b0, off * 3u);
-            v[0] = t.x;
-            v[1] = t.y;
-            v[2] = t.z;
-        } else {
-            v[0] = ld_off(b0, off);
-            v[1] = ld_off(b1, off);
-            v[2] = ld_off(b2, off);
-        }
-    };
-    auto prefetch = [&](int sv) {  // virtual source plane sv: sources from plane sv - D0z, own-term d from plane sv + E0z
-        const int st = sv - D0z;
-        if (st >= 0 && st < vol.D) {
-            const int64_t zo = (int64_t)st * HW;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                if (sxy[it] < 0) continue;
-                const unsigned g = (unsigned)sxy[it] * 4u;
-                float dv[3], gv[3];
-                load3(dx_ + zo * LD.em, dy_ + zo * LD.em, dz_ + zo * LD.em, LD.em, g, dv);
-                load3(Gx_ + zo * LG.em, Gy_ + zo * LG.em, Gz_ + zo * LG.em, LG.em, g, gv);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    pre[it][c] = dv[c];
-                    pre[it][3 + c] = gv[c];
-                }
-                if (gs_) pgs[it] = ld_off(gs_ + zo, g);
-            }
-        }
-        const int64_t ze = (int64_t)min(max(sv + E0z, 0), vol.D - 1) * HW;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            if (sxy[it] < 0) continue;
-            load3(dx_ + ze * LD.em, dy_ + ze * LD.em, dz_ + ze * LD.em, LD.em, (unsigned)exy[it] * 4u, pe[it]);
-        }
-    };
-    auto commit = [&](int sv, int slot) {
-        const int st = sv - D0z;
-        const bool zin = st >= 0 && st < vol.D;
-        const float lz_ = zin ? lin.z[st] : 0.0f, fs_ = (float)sv;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            if (sxy[it] < 0) continue;
-            const int i = slot * PN + threadIdx.x + it * kMarchBlock;
-            q_d[i] = make_float2(pe[it][0], pe[it][1]);
-            q_dz[i] = pe[it][2];
-            if (!zin) {
-                q_xy[i] = make_float2(0.0f, 0.0f);
-                q_zg[i] = make_float2(0.0f, 0.0f);
-                q_g[i] = make_float2(0.0f, 0.0f);
-                continue;
-            }
-            const float qx = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(slx[it], pre[it][0]), 1.0f), 0.5f), nxm);
-            const float qy = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(sly[it], pre[it][1]), 1.0f), 0.5f), nym);
-            const float qz = __fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lz_, pre[it][2]), 1.0f), 0.5f), nzm);
-            const float p0 = __builtin_amdgcn_fmed3f(qx, 0.0f, nxm), p1 = __builtin_amdgcn_fmed3f(qy, 0.0f, nym),
-                        p2 = __builtin_amdgcn_fmed3f(qz, 0.0f, nzm);
-            const float gm_ = gs_ ? pgs[it] : 1.0f;
-            const float g0 = sin_[it] ? pre[it][3] * gm_ : 0.0f, g1 = sin_[it] ? pre[it][4] * gm_ : 0.0f,
-                        g2 = sin_[it] ? pre[it][5] * gm_ : 0.0f;
-            q_xy[i] = make_float2(p0 - sfx[it], p1 - sfy[it]);
-            q_zg[i] = make_float2(p2 - fs_, g2);
-            q_g[i] = make_float2(g0, g1);
-        }
-    };
-
-    float2 acc01[NP];
-    float acc2[NP];
-#pragma unroll
-    for (int a = 0; a < NP; ++a) {
-        acc01[a] = make_float2(0.0f, 0.0f);
-        acc2[a] = 0.0f;
-    }
-    const int sbase = z0 - R, slast = z1 - 1 + R;
-    prefetch(sbase);
-    for (int sb = sbase; sb <= slast; sb += NP) {
-#pragma unroll
-        for (int PH = 0; PH < NP; ++PH) {
-            const int s = sb + PH;
-            if (s > slast) break;
-            // the voxel's own d and G for the output plane this step completes (in flight during the commit and the gather)
-            const int zo = s - R;
-            const bool out_now = zo >= z0 && zo < z1 && col_in;
-            float od[3] = {0.0f, 0.0f, 0.0f}, og[3] = {0.0f, 0.0f, 0.0f}, ogs = 1.0f;
-            if (out_now) {
-                const int64_t zb = (int64_t)zo * HW;
-                const unsigned g = (unsigned)(y * vol.W + x) * 4u;
-                load3(dx_ + zb * LD.em, dy_ + zb * LD.em, dz_ + zb * LD.em, LD.em, g, od);
-                load3(Gx_ + zb * LG.em, Gy_ + zb * LG.em, Gz_ + zb * LG.em, LG.em, g, og);
-                if (gs_) ogs = ld_off(gs_ + zb, g);
-            }
-            commit(s, PH);
-            if (s + 1 <= slast) prefetch(s + 1);
-            __syncthreads();
-            if (col_in) {  // contributions of virtual source plane s to output planes s - 1 .. s + 1
-#pragma unroll 1
-                for (int dy = 0; dy <= 2 * R; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx <= 2 * R; ++dx) {
-                        const int ri = PH * PN + (ly + dy) * PX + (lx + dx);
-                        const float2 rxy = q_xy[ri], rzg = q_zg[ri], g01 = q_g[ri];
-                        const float hxy = rel_hat<R>(rxy.x, dx - R) * rel_hat<R>(rxy.y, dy - R);
-#pragma unroll
-                        for (int oo = -R; oo <= R; ++oo) {
-                            const int a = (PH + oo + NP) % NP;
-                            const float w = hxy * rel_hat<R>(rzg.x, -oo);
-                            acc01[a].x = fmaf(w, g01.x, acc01[a].x);
-                            acc01[a].y = fmaf(w, g01.y, acc01[a].y);
-                            acc2[a] = fmaf(w, rzg.y, acc2[a]);
-                        }
-                    }
-            }
-            {
-                const int a = (PH - R + NP) % NP;
-                if (out_now) {
-                    const float G0 = og[0] * ogs, G1 = og[1] * ogs, G2 = og[2] * ogs;
-                    // the sample this voxel took in the forward step (same arithmetic as the staging above)
-                    const float pax = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.x[x], od[0]), 1.0f), 0.5f), nxm), 0.0f, nxm);
-                    const float pay = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.y[y], od[1]), 1.0f), 0.5f), nym), 0.0f, nym);
-                    const float paz = __builtin_amdgcn_fmed3f(__fmul_rn(__fmul_rn(__fadd_rn(__fadd_rn(lin.z[zo], od[2]), 1.0f), 0.5f), nzm), 0.0f, nzm);
-                    const float fx0 = floorf(pax), fy0 = floorf(pay), fz0 = floorf(paz);
-                    const float wx1 = __fsub_rn(pax, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), pax);
-                    const float wy1 = __fsub_rn(pay, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.0f), pay);
-                    const float wz1 = __fsub_rn(paz, fz0), wz0 = __fsub_rn(__fadd_rn(fz0, 1.0f), paz);
-                    const float gmx = pax > 0.0f && pax < nxm ? 0.5f * nxm : 0.0f;
-                    const float gmy = pay > 0.0f && pay < nym ? 0.5f * nym : 0.0f;
-                    const float gmz = paz > 0.0f && paz < nzm ? 0.5f * nzm : 0.0f;
-                    const int ix0 = (int)fx0, iy0 = (int)fy0, iz0 = (int)fz0;
-                    // ring position of corner (ix0, iy0, iz0): the own-term ring holds d at virtual + E0
-                    const int bx0 = ix0 - E0x - (ox - R), by0 = iy0 - E0y - (oy - R), rel = iz0 - E0z - zo;
-                    // (ring position p of virtual plane v holds d at the TRUE coordinates clamp(p + E0), clamp(v + E0z): for a corner inside
-                    // the volume that is the corner itself; the "+1" corner past the border is a finite replica with weight exactly 0)
-                    const bool in_ring = (unsigned)bx0 < (unsigned)(PX - 1) && (unsigned)by0 < (unsigned)(M::PY - 1) && rel >= -R && rel < R;
-                    float dot[2][2][2];
-                    if (in_ring) {
-                        const int sl0 = ((a + rel + NP) % NP) * PN, sl1 = ((a + rel + 1 + NP) % NP) * PN;
-                        const int off = by0 * PX + bx0;
-#pragma unroll
-                        for (int cz = 0; cz < 2; ++cz) {
-                            const int bs = (cz ? sl1 : sl0) + off;
-#pragma unroll
-                            for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-                                for (int cx = 0; cx < 2; ++cx) {
-                                    const float2 v01 = q_d[bs + cy * PX + cx];
-                                    dot[cz][cy][cx] = fmaf(q_dz[bs + cy * PX + cx], G2, fmaf(v01.y, G1, v01.x * G0));
-                                }
-                        }
-                    } else {
-#pragma unroll
-                        for (int cz = 0; cz < 2; ++cz)
-#pragma unroll
-                            for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-                                for (int cx = 0; cx < 2; ++cx) {
-                                    const int64_t idx = (((int64_t)min(iz0 + cz, vol.D - 1) * vol.H + min(iy0 + cy, vol.H - 1)) * vol.W + min(ix0 + cx, vol.W - 1)) * LD.em;
-                                    dot[cz][cy][cx] = fmaf(dz_[idx], G2, fmaf(dy_[idx], G1, dx_[idx] * G0));
-                                }
-                    }
-                    const float wyz[2][2] = {{wy0 * wz0, wy1 * wz0}, {wy0 * wz1, wy1 * wz1}};
-                    const float wxz[2][2] = {{wx0 * wz0, wx1 * wz0}, {wx0 * wz1, wx1 * wz1}};
-                    const float wxy[2][2] = {{wx0 * wy0, wx1 * wy0}, {wx0 * wy1, wx1 * wy1}};
-                    float gix = 0.0f, giy = 0.0f, giz = 0.0f;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int w = 0; w < 2; ++w) {
-                            gix = fmaf(wyz[u][w], dot[u][w][1] - dot[u][w][0], gix);
-                            giy = fmaf(wxz[u][w], dot[u][1][w] - dot[u][0][w], giy);
-                            giz = fmaf(wxy[u][w], dot[1][u][w] - dot[0][u][w], giz);
-                        }
-                    const int64_t pl = (int64_t)zo * HW * LO.em;
-                    const unsigned g = (unsigned)(y * vol.W + x) * 4u * (unsigned)LO.em;
-                    const float o0 = (G0 + gmx * gix) + acc01[a].x, o1 = (G1 + gmy * giy) + acc01[a].y, o2 = (G2 + gmz * giz) + acc2[a];
-                    if (LO.em == 3) {
-                        st3_off(o + pl, g, o0, o1, o2);
-                    } else {
-                        st_off(o + pl, g, o0);
-                        st_off(o + LO.cs + pl, g, o1);
-                        st_off(o + 2 * LO.cs + pl, g, o2);
-                    }
-                }
-                acc01[a] = make_float2(0.0f, 0.0f);
-                acc2[a] = 0.0f;
-            }
-            __syncthreads();
-        }
-    }
-  }
-}
-
 // One tile per workgroup for the common radius-1 variant (XCD-aware order); the rarely selected variants are launched on a
 // small persistent grid that strides over the tiles, so that a launch whose variant is not selected costs ~2 us instead of
 // the dispatch of thousands of workgroups that exit at once.
@@ -1253,61 +868,35 @@ template <bool PRESCALE, int R>
 __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp_bwd_march_kernel(
     const float* __restrict__ G, const float* __restrict__ dk, float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
     const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int own_rest, int swz_run, dim3 tiles,
-    const float* __restrict__ gscale, int lay, const int* __restrict__ tinfo) {
+    const float* __restrict__ gscale, int lay) {
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     for (int id = blockIdx.x; id < total; id += gridDim.x)
-        exp_bwd_march_tile<PRESCALE, R>(G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, r_lo, own_rest, swz_run, id, tiles, gscale, lay, tinfo);
+        exp_bwd_march_tile<PRESCALE, R>(G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, r_lo, own_rest, swz_run, id, tiles, gscale, lay);
 }
 
 constexpr int kRareGrid = 512;  // persistent grid of the rarely selected variants (two workgroups per CU)
 
-bool launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
+void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
-                               hipEvent_t after_primary, hipStream_t st, float* cmm_shift) {
-    bool shifted = false;
+                               hipEvent_t after_primary, hipStream_t st) {
     const int seg_env = global_knobs().march_seg;
-    int seg_len = pick_seg_len(vol.nz + vol.nzb, (int64_t)((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * C, 8, seg_env);
-    int nseg = vol_nseg(vol, seg_len);  // segments of both windows
-    dim3 tiles((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
-    int total = (int)(tiles.x * tiles.y * tiles.z);
+    const int seg_len = pick_seg_len(vol.nz + vol.nzb, (int64_t)((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * C, 8, seg_env);
+    const int nseg = vol_nseg(vol, seg_len);  // segments of both windows
+    const dim3 tiles((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
+    const int total = (int)(tiles.x * tiles.y * tiles.z);
     const Scale3L sc = make_scale_l(vol, no_steps);
     const int swz_env = global_knobs().swz_run;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;  // 0/1: no remap; default: one x-row of tiles per XCD run
-    const int* tinfo = nullptr;
-#define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale, lay, tinfo)
-    int rare = total < kRareGrid ? total : kRareGrid;
+#define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale, lay)
+    const int rare = total < kRareGrid ? total : kRareGrid;
     // the radius-1 kernel first (the one the roofline is quoted on: `after_primary` brackets exactly its launch), then the
     // rarely selected radius-2 variant on the small persistent grid
     if (prescale_in) IRS_BWM(true, 1, 0, total); else IRS_BWM(false, 1, 0, total);
     if (after_primary) (void)hipEventRecord(after_primary, st);
     if (max_radius >= 2) {
-        // Large but smooth displacements (a converged registration): the tiles whose contributing sources all sit within a
-        // voxel of one integer offset are gathered by the radius-1 kernel on a SHIFTED window; the radius-2 gather below (and
-        // the any-radius kernel, launch_exp_step_bwd_lds) take what is left.  All of it is selected on the device and idle
-        // (a few us per launch) while max|d_k| < 1.
-        if (cmm_shift && !prescale_in && vol.nzb == 0 && MTX == ETX && MTY == ETY && global_knobs().bwd_shift) {
-            TileGrid tg;
-            (void)exp_grid(vol, C, &tg);
-            shifted = true;
-            tinfo = tile_info(cmm_shift, vol, C);
-            const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.D + kCell - 1) / kCell;
-            const dim3 cg((unsigned)(((ncx + 7) / 8) * ncy * ncz), (unsigned)C);
-            hipLaunchKernelGGL((coarse_minmax_kernel<false>), cg, dim3(kWave), 0, st, dk, G, gscale, cmm_shift, vol, sc, dmax, 1, ncx, ncy, ncz, lay);
-            hipLaunchKernelGGL(qualify_tiles_kernel, dim3((unsigned)((tg.total + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, st,
-                               cmm_shift, const_cast<int*>(tinfo), vol, dmax, tg);
-            hipLaunchKernelGGL(exp_bwd_shift_kernel, dim3((unsigned)(tg.total < 3 * 256 ? tg.total : 3 * 256)), dim3(kMarchBlock), 0, st, G, dk, gout, vol,
-                               lin, dmax, tinfo, tg, gscale, lay);
-            // the radius-2 gather on the qualification's tiles (8-plane segments), skipping the ones just done
-            seg_len = ETZ;
-            nseg = vol_nseg(vol, seg_len);
-            tiles = dim3((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
-            total = (int)(tiles.x * tiles.y * tiles.z);
-            rare = total < kRareGrid ? total : kRareGrid;
-        }
         if (prescale_in) IRS_BWM(true, 2, 1, rare); else IRS_BWM(false, 2, 1, rare);
     }
 #undef IRS_BWM
-    return shifted;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -53,18 +53,15 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale, int
                                const unsigned* dmax_in, unsigned* dmax_out, bool only_r1, int lay, hipStream_t st);
 // the adjoint is launched as a set: gather radius 1, gather radius 2 and the scatter fallback; exactly one of them does
 // the work, chosen on the device from the bound max|d_k|
-bool launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
+void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
-                               hipEvent_t after_primary, hipStream_t st, float* cmm_shift = nullptr);
-// cmm_shift (optional, coarse_minmax_bytes of scratch, single window): large-but-smooth displacements go through the
-// shifted-window radius-1 gather (exp_kernels.hip); returns whether that path was launched -- a following
-// launch_exp_step_bwd_lds must be told (`shifted`): it then reuses the coarse grid and skips the tiles already done
+                               hipEvent_t after_primary, hipStream_t st);
 // cmm: scratch of coarse_minmax_bytes(vol, C) for the per-cell displacement extrema (nullptr: sources are bounded by the
 // global bound around the tile only -- correct, slow for large displacements)
 size_t coarse_minmax_bytes(Vol vol, int C);
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
                              Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, int lay,
-                             float* cmm, hipStream_t st, bool shifted = false);
+                             float* cmm, hipStream_t st);
 void launch_field_absmax(const float* d, bool prescale, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st);
 
 // ---- data_kernels.hip

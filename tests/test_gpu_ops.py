@@ -163,45 +163,6 @@ def test_svf_exp_backward_large_smooth_displacement():
     assert int(bad) <= 1e-3 * gv_ref.numel()
 
 
-@pytest.mark.parametrize('kind', ['translation', 'drift', 'mixed'])
-def test_svf_exp_backward_shifted_window(kind):
-    """Large but SMOOTH displacements: tiles whose contributing sources all sit within a voxel of one integer offset run the
-    radius-1 gather on a shifted window (qualified on the device from the coarse displacement extrema); border tiles and tiles
-    with too much variation stay with the radius-2 / any-radius kernels.  Same result as with the shifted path switched off (to
-    rounding: another summation order), and the same as autograd through the oracle."""
-    from ir_sgmcmc_amd._lib import option_set
-    dims = (40, 40, 104)   # (D, H, W): several interior tiles of 32 x 8 x 8 along every axis
-    g = torch.Generator().manual_seed(12)
-    D, H, W = dims
-    z, y, x = torch.meshgrid(torch.linspace(0, 1, D), torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing='ij')
-    # (velocity v: d_12 ~ v, d_11 ~ v / 2, d_10 ~ v / 4 ... -- the last adjoint steps see 3.3 and 1.65 voxels: the any-radius and
-    # the radius-2 regime, both with tiles for the shifted window)
-    if kind == 'translation':     # the same 6.6 / -5.2 / 3.6 voxels everywhere
-        v = torch.stack([6.6 + 0 * x, -5.2 + 0 * x, 3.6 + 0 * x])
-    elif kind == 'drift':         # under a voxel of smooth variation around an offset
-        v = torch.stack([8.4 + 0.8 * torch.sin(3.0 * x + y), -3.0 + 0.6 * torch.cos(2.0 * z), 5.2 + 0.5 * torch.sin(4.0 * y)])
-    else:                         # one region that qualifies, one that varies too fast for any single offset
-        v = torch.stack([6.0 + 5.0 * (x > 0.8) * torch.sin(40.0 * x), 0.8 * torch.sin(5.0 * y) + 0 * x, -4.4 + 0 * x])
-    v = v.unsqueeze(0).float().contiguous().requires_grad_(True)
-    g_last = smooth_field(1, dims, 1.0, 33)
-    _, _, steps_ref = O.svf_exp(v, 12, keep_steps=True)
-    gv_ref, = torch.autograd.grad(steps_ref[-1], v, g_last)
-    _, _, steps = G.svf_exp_fwd(dev(v.detach()), 12, want_outputs=False)
-    res = {}
-    try:
-        for shift in (0, 1):
-            option_set('bwd_shift', shift)
-            res[shift] = G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last))
-            assert torch.equal(res[shift], G.svf_exp_bwd(dev(v.detach()), steps, dev(g_last)))   # deterministic either way
-    finally:
-        option_set('bwd_shift', 1)
-    scale = float(gv_ref.abs().max())
-    assert maxdiff(res[0], res[1]) < 5e-6 * scale
-    assert not torch.equal(res[0], res[1])        # the shifted kernel did take tiles (another summation order)
-    bad = ((res[1].cpu() - gv_ref).abs() > GRAD_RTOL * scale).sum()
-    assert int(bad) <= 1e-3 * gv_ref.numel()
-
-
 @pytest.mark.parametrize('N,cps', [(16, 4), (16, 2), (17, 4), (20, 3)])
 def test_ffd_up_and_adjoint(N, cps):
     dims, c = (N,) * 3, (cps,) * 3
