@@ -361,7 +361,7 @@ int irs_slab_trace(const irs_config* cfg, const irs_slab_config* scfg, int rank,
  * launched, test hooks).  The library reads its IRS_* environment variables ONCE per process, on first use; a context copies
  * them when it is created and no transition calls getenv.  This call changes one switch by name afterwards: on `ctx`, or --
  * ctx == NULL -- process-wide (the stateless operators and every context created later).  Names: predict_variants,
- * run_ahead, fuse_warp_bwd, energy_in_update, fuse_noise, recover, coarse_box, sobolev_tile, march_seg,
+ * run_ahead, fuse_warp_bwd, energy_in_update, fuse_noise, recover, fwd_rows1, coarse_box, sobolev_tile, march_seg,
  * march_seg_fwd, swz_run, seg_min_blocks, seg_min_len, sobolev_seg, lcc_seg, stats_seg, update_seg, slab_split, slab_exact,
  * slab_force_h (csrc/common.h: Knobs).  The reference has no counterpart (it has one code path). */
 int irs_option_set(irs_ctx* ctx, const char* name, int value);

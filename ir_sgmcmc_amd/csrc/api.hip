@@ -40,6 +40,7 @@ static Knobs knobs_from_env() {
     k.energy_in_update = env_or("IRS_ENERGY_IN_UPDATE", k.energy_in_update);
     k.fuse_noise = env_or("IRS_FUSE_NOISE", k.fuse_noise);
     k.recover = env_or("IRS_RECOVER", k.recover);
+    k.fwd_rows1 = env_or("IRS_FWD_ROWS1", k.fwd_rows1);
     k.coarse_box = env_or("IRS_COARSE_BOX", k.coarse_box);
     const char* tile = getenv("IRS_SOBOLEV_TILE");
     if (tile && *tile) k.sobolev_tile = tile[0] == 'b' ? 2 : (tile[0] == 's' ? 1 : atoi(tile));
@@ -71,7 +72,7 @@ int knob_set(Knobs& k, const char* name, int value) {
     static const Entry table[] = {
         {"predict_variants", &Knobs::predict_variants}, {"run_ahead", &Knobs::run_ahead}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd},
         {"energy_in_update", &Knobs::energy_in_update}, {"fuse_noise", &Knobs::fuse_noise},
-        {"recover", &Knobs::recover}, {"coarse_box", &Knobs::coarse_box}, {"sobolev_tile", &Knobs::sobolev_tile},
+        {"recover", &Knobs::recover}, {"fwd_rows1", &Knobs::fwd_rows1}, {"coarse_box", &Knobs::coarse_box}, {"sobolev_tile", &Knobs::sobolev_tile},
         {"march_seg", &Knobs::march_seg}, {"march_seg_fwd", &Knobs::march_seg_fwd}, {"swz_run", &Knobs::swz_run},
         {"seg_min_blocks", &Knobs::seg_min_blocks}, {"seg_min_len", &Knobs::seg_min_len}, {"sobolev_seg", &Knobs::sobolev_seg},
         {"lcc_seg", &Knobs::lcc_seg}, {"stats_seg", &Knobs::stats_seg}, {"update_seg", &Knobs::update_seg},

@@ -916,9 +916,14 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
 #ifndef IRS_FWD_PITCH_ALIGN
 #define IRS_FWD_PITCH_ALIGN 16
 #endif
-constexpr int FTX = IRS_FTX, FTY = IRS_FTY, FROWS = IRS_FROWS, kFwdBlock = FTX * FTY / FROWS;
-template <int R>
+// FROWS is a template parameter of the radius-1 kernel: two rows per thread (256 threads) where the launch fills the chip; ONE row
+// per thread (512 threads, 8 waves per tile) on small volumes and thin slabs, where a launch has a workgroup or two per CU and
+// twice the waves per tile hide more of a plane step's latency (128^3: 22.9 against 24.7 us per step; at 256^3 it loses, 142
+// against 118 us)
+constexpr int FTX = IRS_FTX, FTY = IRS_FTY, FROWS_BIG = IRS_FROWS;
+template <int R, int FROWS = FROWS_BIG>
 struct MarchF {
+    static constexpr int kFwdBlock = FTX * FTY / FROWS;
     static constexpr int NP = 2 * R + 1, PX = FTX + 2 * R, PY = FTY + 2 * R, PN = PX * PY;
     static constexpr int NIT = (PN + kFwdBlock - 1) / kFwdBlock;
     // LDS row pitch: a multiple of 16 elements, so that rows and ring slots of the 8-byte (d0, d1) records start on the same
@@ -942,14 +947,14 @@ extern "C" int irs_debug_fwd_trace(unsigned long long* out) {
 #else
 #define IRS_TR(slot)
 #endif
-template <bool PRESCALE, int R>
+template <bool PRESCALE, int R, int FROWS>
 __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din, float* __restrict__ dout, const Vol vol,
                                                    const Lin lin, const Scale3L sc, const unsigned* __restrict__ dmax_in,
                                                    unsigned* __restrict__ dmax_out, const int seg_len, const int nseg,
                                                    const int h_lo, const int h_hi, const int swz_run, const int tile_id,
                                                    const dim3 tiles, const int lay) {
-    using M = MarchF<R>;
-    constexpr int PX = M::PX, PN = M::PN, NIT = M::NIT, PITCH = M::PITCH, PNP = M::PNP;
+    using M = MarchF<R, FROWS>;
+    constexpr int PX = M::PX, PN = M::PN, NIT = M::NIT, PITCH = M::PITCH, PNP = M::PNP, kFwdBlock = M::kFwdBlock;
     // ring of 2R+2 slots: one more than a sample can reach, so that the commit of the next source plane never overwrites
     // a plane another wavefront is still sampling -> ONE barrier per plane instead of two
     constexpr int NS = M::NP + 1;
@@ -1155,15 +1160,15 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
 #ifndef IRS_FWD_WAVES
 #define IRS_FWD_WAVES 1
 #endif
-template <bool PRESCALE, int R>
-__global__ __launch_bounds__(kFwdBlock, R == 1 ? IRS_FWD_WAVES : 1) void exp_fwd_march_kernel(const float* __restrict__ din, float* __restrict__ dout,
+template <bool PRESCALE, int R, int FROWS = FROWS_BIG>
+__global__ __launch_bounds__(FTX * FTY / FROWS, R == 1 ? IRS_FWD_WAVES : 1) void exp_fwd_march_kernel(const float* __restrict__ din, float* __restrict__ dout,
                                                                   Vol vol, Lin lin, Scale3L sc,
                                                                   const unsigned* __restrict__ dmax_in,
                                                                   unsigned* __restrict__ dmax_out, int seg_len, int nseg,
                                                                   int h_lo, int h_hi, int swz_run, dim3 tiles, int lay) {
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     for (int id = blockIdx.x; id < total; id += gridDim.x) {
-        exp_fwd_march_tile<PRESCALE, R>(din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, h_lo, h_hi, swz_run, id, tiles, lay);
+        exp_fwd_march_tile<PRESCALE, R, FROWS>(din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, h_lo, h_hi, swz_run, id, tiles, lay);
         __syncthreads();  // the ring and the reduction scratch are reused by the next tile
     }
 }
@@ -1178,12 +1183,21 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     const Scale3L sc = make_scale_l(vol, no_steps);
     const int swz_env = global_knobs().swz_run;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;
-#define IRS_FWM(P, RR, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), dim3(GRID), dim3(kFwdBlock), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
+#define IRS_FWM(P, RR, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), dim3(GRID), dim3(FTX * FTY / FROWS_BIG), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
+#define IRS_FWS(P, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 1, 1>), dim3(total), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run, tiles, lay)
     const int rare = total < kRareGrid ? total : kRareGrid;
+    // small launches (at most two workgroups of tiles per CU): the radius-1 kernel with one output row per thread
+    const int small_env = global_knobs().fwd_rows1;
+    const bool small = FROWS_BIG != 1 && (small_env >= 0 ? small_env != 0 : total <= 640);
     if (!dmax_in || only_r1) {  // no bound / predicted small: the radius-1 ring is correct for any displacement (far taps go to global memory)
-        if (prescale_in) IRS_FWM(true, 1, -1, 1 << 30, total); else IRS_FWM(false, 1, -1, 1 << 30, total);
-    } else if (prescale_in) { IRS_FWM(true, 1, -1, 1, total); IRS_FWM(true, 2, 1, 1 << 30, rare); }
-    else { IRS_FWM(false, 1, -1, 1, total); IRS_FWM(false, 2, 1, 1 << 30, rare); }
+        if (small) { if (prescale_in) IRS_FWS(true, -1, 1 << 30); else IRS_FWS(false, -1, 1 << 30); }
+        else if (prescale_in) IRS_FWM(true, 1, -1, 1 << 30, total); else IRS_FWM(false, 1, -1, 1 << 30, total);
+    } else {
+        if (small) { if (prescale_in) IRS_FWS(true, -1, 1); else IRS_FWS(false, -1, 1); }
+        else if (prescale_in) IRS_FWM(true, 1, -1, 1, total); else IRS_FWM(false, 1, -1, 1, total);
+        if (prescale_in) IRS_FWM(true, 2, 1, 1 << 30, rare); else IRS_FWM(false, 2, 1, 1 << 30, rare);
+    }
+#undef IRS_FWS
 #undef IRS_FWM
 }
 
