@@ -224,6 +224,59 @@ def test_transition_matches_oracle_at_full_size(N, loss):
     check(T, 'grad_v (rel to max), 99.99th percentile', torch.tensor(float(dev.flatten().kthvalue(int(0.9999 * dev.numel())).values)), torch.tensor(0.0), GRAD_RTOL)
 
 
+@pytest.mark.parametrize('case', ['lcc_s2_128', 'svffd_cps4_64'])
+def test_larger_sizes_of_the_less_common_configurations(case):
+    """The LCC window s = 2 (configs/experiment3-4 of the reference) and SVFFD_3D with control-point spacing 4 (experiment5) are
+    pinned by reference fixtures at 16^3 only; here one transition each at a realistic size against the oracle on the same
+    injected noise: 128^3 with s = 2 (125-tap box filters: other tile / halo arithmetic than s = 1), 64^3 SVFFD cps 4 (a 19^3
+    control grid: B-spline up-sampling and its adjoint around the dense squaring steps)."""
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    if case == 'lcc_s2_128':
+        N = 128
+        oc = OracleConfig(dims=(N, N, N), lcc_s=2)
+    else:
+        N = 64
+        oc = OracleConfig(dims=(N, N, N), transformation='SVFFD_3D', cps=(4, 4, 4), lr=0.01)
+    f1, m1 = synthetic_pair((N, N, N), seed=0)
+    fixed = {k: v.unsqueeze(0).contiguous() for k, v in f1.items() if k != 'seg'}
+    moving = {k: v.unsqueeze(0).contiguous() for k, v in m1.items() if k != 'seg'}
+    gen = torch.Generator().manual_seed(33)
+    dv = oc.dims_v
+    lo = torch.randn(1, 3, max(dv[0] // 8, 2), max(dv[1] // 8, 2), max(dv[2] // 8, 2), generator=gen)
+    v0 = torch.nn.functional.interpolate(lo, size=dv, mode='trilinear', align_corners=True)
+    v0 = (v0 * (2.5 / float(v0.abs().max()))).contiguous()
+    orc = OracleChain(oc, v0=v0)
+    orc.init_gmm(fixed, moving)
+    cfg = engine_config(oc)
+    eng = TransitionEngine(cfg, DEV)
+    fixed_d, moving_d = eng.prepare(to_dev(fixed), to_dev(moving))
+    eng.gmm_init(fixed_d, moving_d)
+    v = v0.to(DEV).contiguous()
+    out = outputs_for(cfg)
+    eps = torch.randn(1, 3, *dv, generator=gen)
+    unif = torch.rand(1, 3, N, N, N, generator=gen)
+    o = orc.transition(fixed, moving, eps, unif)
+    eng.transition(fixed_d, moving_d, v, None, eps.to(DEV), unif.to(DEV), out)
+    sc = eng.scalars()
+    T = 'oracle/' + case
+    assert float(o['displacement'].abs().max()) > 0.5
+    check(T, 'alpha', sc['alpha'], o['alpha'], 5e-5)
+    check(T, 'data_term (rel)', torch.tensor(sc['data_term']) / torch.tensor(o['data']).abs(), torch.sign(torch.tensor(o['data'])), 1e-5)
+    check(T, 'reg_term (rel)', torch.tensor(sc['reg_term']) / torch.tensor(o['reg']).abs(), torch.sign(torch.tensor(o['reg'])), 1e-5)
+    check(T, 'displacement [voxels]', out['displacement'], o['displacement'], 1e-4)
+    # (the LCC residual divides by the local standard deviation of the warped image: in a nearly flat window the 1e-6 agreement of
+    # the warped images is amplified by 1 / sigma_M -- a handful of such voxels among two million; the sums above are unaffected)
+    zr = torch.where(fixed['mask'], o['residuals'], torch.zeros(()))
+    dz = (out['residuals'].cpu() * fixed['mask'].float() - zr).abs().flatten()
+    check(T, 'residuals, 99.99th percentile', torch.tensor(float(dz.kthvalue(max(1, int(0.9999 * dz.numel()))).values)), torch.tensor(0.0), 2e-4)
+    check(T, 'residuals, max', torch.tensor(float(dz.max())), torch.tensor(0.0), 1e-3)
+    gmax = float(o['grad_v'].abs().max())
+    dev = (out['grad_v'].cpu() - o['grad_v']).abs() / gmax
+    check(T, 'grad_v: fraction of voxels beyond tolerance', torch.tensor(float((dev > GRAD_RTOL).double().mean())), torch.tensor(0.0), 1e-4)
+    check(T, 'v_new (99.99th percentile)', torch.tensor(float((v.cpu() - o['v_new']).abs().flatten().kthvalue(max(1, int(0.9999 * v.numel()))).values)),
+          torch.tensor(0.0), oc.lr * GRAD_RTOL * gmax + 1e-5)
+
+
 def test_in_kernel_noise_path_runs_and_is_reproducible():
     """eps / unif = NULL -> Philox noise keyed by (seed, iteration): same seed -> same chain, other seed -> other chain."""
     from ir_sgmcmc_amd.data_loader import synthetic_pair
