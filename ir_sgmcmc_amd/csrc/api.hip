@@ -695,7 +695,9 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     //    never materialised); the two-kernel form for the mixture initialisation (no noise) and the small SVFFD control grid
     bool have_dmax0 = false;
     const float amp = (float)sqrt(2.0 * (double)cfg.lr);
-    if (with_noise && cfg.sobolev_s > 0 && !c->ffd && c->kn.fuse_noise) {
+    // (with a sigma FIELD -- the preconditioner of a chain started from the VI posterior -- the one-kernel form holds 149 VGPRs,
+    // one workgroup per CU, and measured 2 % slower end to end than the two kernels: config 5 at 192^3, 408-411 against 415-417 samples/s)
+    if (with_noise && cfg.sobolev_s > 0 && !c->ffd && c->kn.fuse_noise && !io->sigma) {
         have_dmax0 = true;
         launch_perturb_sobolev_march(v, io->sigma, io->eps, amp, vs, c->sob, C, c->volv, c->dmax, cfg.no_steps, cfg.seed, 0, it, st);
     } else {
