@@ -42,6 +42,8 @@ static Knobs knobs_from_env() {
     k.recover = env_or("IRS_RECOVER", k.recover);
     k.fwd_rows1 = env_or("IRS_FWD_ROWS1", k.fwd_rows1);
     k.coarse_box = env_or("IRS_COARSE_BOX", k.coarse_box);
+    k.lds_from = env_or("IRS_LDS_FROM", k.lds_from);
+    k.fwd_r2_rows1 = env_or("IRS_FWD_R2_ROWS1", k.fwd_r2_rows1);
     const char* tile = getenv("IRS_SOBOLEV_TILE");
     if (tile && *tile) k.sobolev_tile = tile[0] == 'b' ? 2 : (tile[0] == 's' ? 1 : atoi(tile));
     k.march_seg = env_or("IRS_MARCH_SEG", k.march_seg);
@@ -72,7 +74,7 @@ int knob_set(Knobs& k, const char* name, int value) {
     static const Entry table[] = {
         {"predict_variants", &Knobs::predict_variants}, {"run_ahead", &Knobs::run_ahead}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd},
         {"energy_in_update", &Knobs::energy_in_update}, {"fuse_noise", &Knobs::fuse_noise},
-        {"recover", &Knobs::recover}, {"fwd_rows1", &Knobs::fwd_rows1}, {"coarse_box", &Knobs::coarse_box}, {"sobolev_tile", &Knobs::sobolev_tile},
+        {"recover", &Knobs::recover}, {"fwd_rows1", &Knobs::fwd_rows1}, {"coarse_box", &Knobs::coarse_box}, {"lds_from", &Knobs::lds_from}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1}, {"sobolev_tile", &Knobs::sobolev_tile},
         {"march_seg", &Knobs::march_seg}, {"march_seg_fwd", &Knobs::march_seg_fwd}, {"swz_run", &Knobs::swz_run},
         {"seg_min_blocks", &Knobs::seg_min_blocks}, {"seg_min_len", &Knobs::seg_min_len}, {"sobolev_seg", &Knobs::sobolev_seg},
         {"lcc_seg", &Knobs::lcc_seg}, {"stats_seg", &Knobs::stats_seg}, {"update_seg", &Knobs::update_seg},
@@ -795,7 +797,7 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
     vd.n = cfg.no_steps;
     vd.C = C;
     for (int k = 0; k < cfg.no_steps && k < 32; ++k) {
-        skip_any[k] = predicted_below(c, k, 1.5f);
+        skip_any[k] = predicted_below(c, k, c->kn.lds_from <= 2 ? 0.75f : 1.5f);
         skip_r2[k] = skip_any[k] && predicted_tiny(c, k);
         if (skip_r2[k]) vd.need_lt1 |= 1u << k;
     }
@@ -858,9 +860,11 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
             const bool sa = k < 32 && skip_any[k], s2 = k < 32 && skip_r2[k];
             // timed mode: the end event of step k closes right after the radius-1 kernel, so that exp_bwd_kernel_ms is the time
             // of the dominant kernel alone (as rocprofv3 reports it), not of the idle variants after it
-            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, s2 ? 1 : 2, sa, gscale, lay,
+            // lds_from 2: the any-radius kernel, when launched, takes every step beyond the radius-1 gather (no radius-2 gather then)
+            const int gr = c->kn.lds_from <= 2 ? 1 : 2;
+            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, (s2 || (gr == 1 && !sa)) ? 1 : 2, sa, gscale, lay,
                                       timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
-            if (!sa) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, 2, gscale, lay, c->cmm, st);
+            if (!sa) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, gr, gscale, lay, c->cmm, st);
             G = out;
             cur ^= 1;
         }

@@ -18,7 +18,12 @@
 
 namespace irs {
 
-constexpr int ETX = 32, ETY = 8, ETZ = 8, ETN = ETX * ETY * ETZ;
+#ifndef IRS_ETX
+#define IRS_ETX 32
+#define IRS_ETY 8
+#define IRS_ETZ 8
+#endif
+constexpr int ETX = IRS_ETX, ETY = IRS_ETY, ETZ = IRS_ETZ, ETN = ETX * ETY * ETZ;
 constexpr int kExpBlock = 512;
 
 struct Scale3L {
@@ -26,6 +31,13 @@ struct Scale3L {
     float rnm1[3];  // correctly rounded 1 / nm1 (common.h: exact_rcp, div_exact)
     float inv_pow;
 };
+
+typedef float F3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ F3 ld3g(const float* __restrict__ p) {  // three consecutive floats, one global_load_dwordx3
+    F3 v;
+    __builtin_memcpy(&v, p, 12);
+    return v;
+}
 
 template <bool PRESCALE>
 __device__ __forceinline__ float ldp(const float* __restrict__ p, int64_t i, float nm1, float rnm1, float inv_pow) {
@@ -136,7 +148,9 @@ __global__ __launch_bounds__(kWave) void coarse_minmax_kernel(const float* __res
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, gm = 0.0f;
     if (x < vol.W) {
         for (int z = cz * kCell; z < min(cz * kCell + kCell, vol.D); ++z)
-            for (int y = cy * kCell; y < min(cy * kCell + kCell, vol.H); ++y) {
+#pragma unroll
+            for (int yy = 0; yy < kCell; ++yy) {  // fixed trip count: eight rows of loads in flight (a clamped row repeats: harmless)
+                const int y = min(cy * kCell + yy, vol.H - 1);
                 const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
                 const float gsc = gs_ ? gs_[g] : 1.0f;
 #pragma unroll
@@ -169,16 +183,14 @@ __global__ __launch_bounds__(kWave) void coarse_minmax_kernel(const float* __res
     }
 }
 
-// corner contributions of one source voxel that land in the owned tile.  d0..d2: the source's displacement (already read)
-template <bool PRESCALE, int H>
-__device__ __forceinline__ void adjoint_scatter(const int x, const int y, const int z, const float d0, const float d1,
-                                                const float d2, const int ox, const int oy, const int oz,
+// corner contributions of one source voxel that land in the owned tile
+// (gx, gy, gz): the source's sampling coordinates lin[.] + d, formed by the caller
+__device__ __forceinline__ void adjoint_scatter(const float gx, const float gy, const float gz, const int ox, const int oy, const int oz,
                                                 const float G0, const float G1, const float G2,
-                                                unsigned long long* __restrict__ acc, const float scale, const Vol vol,
-                                                const Lin lin) {
-    const AxisTap tx = axis_tap(__fadd_rn(lin.x[x], d0), vol.W);
-    const AxisTap ty = axis_tap(__fadd_rn(lin.y[y], d1), vol.H);
-    const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
+                                                unsigned long long* __restrict__ acc, const float scale, const Vol vol) {
+    const AxisTap tx = axis_tap(gx, vol.W);
+    const AxisTap ty = axis_tap(gy, vol.H);
+    const AxisTap tz = axis_tap(gz, vol.D);
     // tile-local corner coordinates; a corner contributes iff it lies inside the owned tile
     const int ax0 = tx.i0 - ox, ax1 = tx.i1 - ox, ay0 = ty.i0 - oy, ay1 = ty.i1 - oy, az0 = tz.i0 - oz, az1 = tz.i1 - oz;
     if (!(ax1 >= 0 && ax0 < ETX && ay1 >= 0 && ay0 < ETY && az1 >= 0 && az0 < ETZ)) return;
@@ -222,7 +234,17 @@ __device__ __forceinline__ void adjoint_self(const int x, const int y, const int
     const AxisTap tz = axis_tap(__fadd_rn(lin.z[z], d2), vol.D);
     const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
     const float gsc = gs_ ? gs_[g] : 1.0f;
-    const float G0 = Gc[g * LG.em] * gsc, G1 = Gc[LG.cs + g * LG.em] * gsc, G2 = Gc[2 * LG.cs + g * LG.em] * gsc;
+    float G0, G1, G2;
+    if (LG.em == 3) {
+        const F3 v = ld3g(Gc + g * 3);
+        G0 = v.x * gsc;
+        G1 = v.y * gsc;
+        G2 = v.z * gsc;
+    } else {
+        G0 = Gc[g] * gsc;
+        G1 = Gc[LG.cs + g] * gsc;
+        G2 = Gc[2 * LG.cs + g] * gsc;
+    }
     const int bx0 = tx.i0 - (ox - H), bx1 = tx.i1 - (ox - H);
     const int by0 = ty.i0 - (oy - H), by1 = ty.i1 - (oy - H);
     const int bz0 = tz.i0 - (oz - H), bz1 = tz.i1 - (oz - H);
@@ -242,9 +264,16 @@ __device__ __forceinline__ void adjoint_self(const int x, const int y, const int
                     v2 = lds[2 * B::SN + idx];
                 } else {
                     const int64_t idx = ((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0);
-                    v0 = ldp<PRESCALE>(c0, idx * LD.em, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
-                    v1 = ldp<PRESCALE>(c0 + LD.cs, idx * LD.em, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
-                    v2 = ldp<PRESCALE>(c0 + 2 * LD.cs, idx * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
+                    if (LD.em == 3) {  // interleaved field: the three channels of a corner in one 12-byte load
+                        const F3 v = ld3g(c0 + idx * 3);
+                        v0 = PRESCALE ? prescale(v.x, sc.nm1[0], sc.rnm1[0], sc.inv_pow) : v.x;
+                        v1 = PRESCALE ? prescale(v.y, sc.nm1[1], sc.rnm1[1], sc.inv_pow) : v.y;
+                        v2 = PRESCALE ? prescale(v.z, sc.nm1[2], sc.rnm1[2], sc.inv_pow) : v.z;
+                    } else {
+                        v0 = ldp<PRESCALE>(c0, idx, sc.nm1[0], sc.rnm1[0], sc.inv_pow);
+                        v1 = ldp<PRESCALE>(c0 + LD.cs, idx, sc.nm1[1], sc.rnm1[1], sc.inv_pow);
+                        v2 = ldp<PRESCALE>(c0 + 2 * LD.cs, idx, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
+                    }
                 }
                 const float wx = cx ? tx.w1 : tx.w0, wy = cy ? ty.w1 : ty.w0, wz = cz ? tz.w1 : tz.w0;
                 const float dot = v0 * G0 + v1 * G1 + v2 * G2;
@@ -257,8 +286,22 @@ __device__ __forceinline__ void adjoint_self(const int x, const int y, const int
     out[2] = G2 + tz.gmul * giz;
 }
 
+#ifdef IRS_LDS_TRACE
+// timing experiment (tools/lds_phase_trace.py; build with tools/build_variant.sh ldstrace -DIRS_LDS_TRACE): wall-clock stamps
+// (100 MHz) of one thread of one workgroup at the phase boundaries of its tiles, plus the source box it walked
+__device__ unsigned long long g_lds_trace[8 * 32];
+extern "C" int irs_debug_lds_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lds_trace), sizeof(g_lds_trace)) == hipSuccess ? 0 : 1;
+}
+#define IRS_LT(slot, val)                                                                                  \
+    do {                                                                                                   \
+        if (blockIdx.x == 37 && threadIdx.x == 0 && lt_i < 32) g_lds_trace[lt_i * 8 + (slot)] = (val);     \
+    } while (0)
+#else
+#define IRS_LT(slot, val)
+#endif
 template <bool PRESCALE, int H>
-__global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __restrict__ G, const float* __restrict__ dk,
+__global__ __launch_bounds__(kExpBlock, H == 0 ? 4 : 2) void exp_bwd_lds_kernel(const float* __restrict__ G, const float* __restrict__ dk,
                                                                 float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
                                                                 const unsigned* __restrict__ dmax, TileGrid tg,
                                                                 int gather_radius, const float* __restrict__ gscale, int lay,
@@ -276,7 +319,14 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
             any |= (int)floorf(fmaxf(fmaxf(__uint_as_float(dmax[c * 4 + 0]), __uint_as_float(dmax[c * 4 + 1])), __uint_as_float(dmax[c * 4 + 2]))) + 1 > gather_radius;
         if (!any) return;
     }
+#ifdef IRS_LDS_TRACE
+  int lt_i = -1;
+#endif
   for (int tile = blockIdx.x; tile < tg.total; tile += gridDim.x) {
+#ifdef IRS_LDS_TRACE
+    ++lt_i;
+#endif
+    IRS_LT(0, wall_clock64());
     int t_ = tile;
     const int ox = (t_ % tg.ntx) * ETX;
     t_ /= tg.ntx;
@@ -331,7 +381,9 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
         const int thi[3] = {min(ox + ETX, vol.W) - 1, min(oy + ETY, vol.H) - 1, min(oz + ETZ, vol.D) - 1};
         const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.D + kCell - 1) / kCell;
         const float* __restrict__ cm = cmm + (int64_t)chain * ncx * ncy * ncz * kCmm;
-        for (int round = 0; round < 3; ++round) {  // the third round only collects max |G| over the final box
+        // two rounds; max |G| is the one of the second round's cells, a superset of the final box: the scale may come out a power
+        // of two smaller than the final box would allow, never too large
+        for (int round = 0; round < 2; ++round) {
             const int c0x = lo[0] / kCell, c0y = lo[1] / kCell, c0z = lo[2] / kCell;
             const int nx_ = hi[0] / kCell - c0x + 1, ny_ = hi[1] / kCell - c0y + 1, nz_ = hi[2] / kCell - c0z + 1;
             float m7[kCmm] = {3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 0.0f};
@@ -345,7 +397,6 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
             }
             block_reduce7(m7);
             gmax = m7[6];
-            if (round == 2) break;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const float mn = m7[2 * a], mx = m7[2 * a + 1];
@@ -374,6 +425,7 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
     const bool usable = gmax > 0.0f && gmax < 3.0e38f;
     const float scale = usable ? ldexpf(1.0f, 30 - e2) : 0.0f, inv_scale = usable ? ldexpf(1.0f, e2 - 30) : 0.0f;
     __syncthreads();  // acc zeroed, lds staged
+    IRS_LT(1, wall_clock64());
 
     auto disp_at = [&](int x, int y, int z, float& d0, float& d1, float& d2) {
         const int bx = x - (ox - H), by = y - (oy - H), bz = z - (oz - H);
@@ -389,37 +441,135 @@ __global__ __launch_bounds__(kExpBlock) void exp_bwd_lds_kernel(const float* __r
             d2 = ldp<PRESCALE>(c0 + 2 * LD.cs, g * LD.em, sc.nm1[2], sc.rnm1[2], sc.inv_pow);
         }
     };
-    // ---- scatter: one wavefront per (y, z) row of the box, lanes along x (row coordinates are wave-uniform)
-    const int ey = max(hi[1] - lo[1] + 1, 0), ez = max(hi[2] - lo[2] + 1, 0);
-    for (int row = threadIdx.x / kWave; row < ey * ez; row += kExpBlock / kWave) {
-        const int y = lo[1] + row % ey, z = lo[2] + row / ey;
-        for (int x = lo[0] + (int)(threadIdx.x & (kWave - 1)); x <= hi[0]; x += kWave) {
-            // d and G in one round trip (G unconditionally: about half of the box contributes, and a second dependent
-            // load per row is what this latency-bound loop cannot afford)
-            float d0, d1, d2;
-            disp_at(x, y, z, d0, d1, d2);
-            const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-            const float gsc = gsc_ ? gsc_[g] : 1.0f;  // optional scalar factor of the incoming gradient (fused backward warp)
-            const float G0 = Gc[g * LG.em] * gsc, G1 = Gc[LG.cs + g * LG.em] * gsc, G2 = Gc[2 * LG.cs + g * LG.em] * gsc;
-            adjoint_scatter<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, G0, G1, G2, acc, scale, vol, lin);
+    // ---- scatter: the sources of the box in one flat order (x fastest), 64 consecutive ones per wavefront step -- a row of the box
+    // is ~36 sources long, so a wavefront per row left 44 % of the lanes idle, and the loop is bound by instruction issue (~250
+    // per source).  Everything a source needs from memory (d, G, the three identity-grid coordinates) is requested kPipe steps
+    // ahead of its scatter.
+    const int ex = max(hi[0] - lo[0] + 1, 0), ey = max(hi[1] - lo[1] + 1, 0), ez = max(hi[2] - lo[2] + 1, 0);
+    const unsigned exy = (unsigned)(ex * ey), nsrc = exy * (unsigned)ez;
+    // idx / exy and rem / ex by multiply-high with m = floor(2^32 / d) + 1: exact while idx * d < 2^32
+    const bool magic_ok = exy > 0 && (unsigned long long)nsrc * exy < (1ull << 32);
+    const unsigned m_xy = magic_ok ? 0xFFFFFFFFu / exy + 1u : 0u, m_x = magic_ok ? 0xFFFFFFFFu / (unsigned)ex + 1u : 0u;
+    const int nitems = (int)((nsrc + kWave - 1) / kWave);
+    constexpr int kWaves = kExpBlock / kWave, kPipe = 2;
+    struct Src {  // the identity-grid coordinates stay separate from d until the scatter: adding them here would wait for the loads
+        float d0, d1, d2, l0, l1, l2, G0, G1, G2, gsc;
+        bool ok;
+    };
+    auto load_item = [&](int it, Src& q) {
+        q.ok = false;
+        if (it >= nitems) return;  // wave-uniform
+        const unsigned idx = (unsigned)it * kWave + (threadIdx.x & (kWave - 1));
+        q.ok = idx < nsrc;
+        if (!q.ok) return;
+        unsigned zq, yq, xq;
+        if (magic_ok) {
+            zq = __umulhi(idx, m_xy);
+            const unsigned rem = idx - zq * exy;
+            yq = __umulhi(rem, m_x);
+            xq = rem - yq * (unsigned)ex;
+        } else {
+            zq = idx / exy;
+            const unsigned rem = idx % exy;
+            yq = rem / (unsigned)ex;
+            xq = rem % (unsigned)ex;
+        }
+        const int x = lo[0] + (int)xq, y = lo[1] + (int)yq, z = lo[2] + (int)zq;
+        const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
+        if (!STAGED && LD.em == 3) {  // interleaved field: one 12-byte load
+            const F3 v = ld3g(c0 + g * 3);
+            q.d0 = v.x;
+            q.d1 = v.y;
+            q.d2 = v.z;
+        } else if (!STAGED) {
+            q.d0 = c0[g];
+            q.d1 = c0[LD.cs + g];
+            q.d2 = c0[2 * LD.cs + g];
+        } else {
+            disp_at(x, y, z, q.d0, q.d1, q.d2);  // staged copies are already prescaled
+        }
+        q.gsc = gsc_ ? gsc_[g] : 1.0f;  // optional scalar factor of the incoming gradient (fused backward warp)
+        if (LG.em == 3) {
+            const F3 v = ld3g(Gc + g * 3);
+            q.G0 = v.x;
+            q.G1 = v.y;
+            q.G2 = v.z;
+        } else {
+            q.G0 = Gc[g];
+            q.G1 = Gc[LG.cs + g];
+            q.G2 = Gc[2 * LG.cs + g];
+        }
+        q.l0 = lin.x[x];
+        q.l1 = lin.y[y];
+        q.l2 = lin.z[z];
+    };
+    auto scatter_item = [&](const Src& q) {
+        const bool raw = PRESCALE && !STAGED;  // values straight from global memory still need the prescale of step 0
+        const float d0 = raw ? prescale(q.d0, sc.nm1[0], sc.rnm1[0], sc.inv_pow) : q.d0;
+        const float d1 = raw ? prescale(q.d1, sc.nm1[1], sc.rnm1[1], sc.inv_pow) : q.d1;
+        const float d2 = raw ? prescale(q.d2, sc.nm1[2], sc.rnm1[2], sc.inv_pow) : q.d2;
+        adjoint_scatter(__fadd_rn(q.l0, d0), __fadd_rn(q.l1, d1), __fadd_rn(q.l2, d2), ox, oy, oz, q.G0 * q.gsc, q.G1 * q.gsc, q.G2 * q.gsc,
+                        acc, scale, vol);
+    };
+    {
+        const int w0 = threadIdx.x / kWave;
+        Src cur[kPipe], nxt[kPipe];
+#pragma unroll
+        for (int u = 0; u < kPipe; ++u) load_item(w0 + u * kWaves, cur[u]);
+        for (int it = w0; it < nitems; it += kWaves * kPipe) {
+#pragma unroll
+            for (int u = 0; u < kPipe; ++u) load_item(it + (kPipe + u) * kWaves, nxt[u]);
+#pragma unroll
+            for (int u = 0; u < kPipe; ++u)
+                if (cur[u].ok) scatter_item(cur[u]);
+#pragma unroll
+            for (int u = 0; u < kPipe; ++u) cur[u] = nxt[u];
         }
     }
     __syncthreads();
-    // ---- own voxels: identity path + grid-gradient (no atomics: one thread per output) + the scattered sum
+    IRS_LT(2, wall_clock64());
+    IRS_LT(4, (unsigned long long)ex | ((unsigned long long)ey << 16) | ((unsigned long long)ez << 32));
+    // ---- own voxels: identity path + grid-gradient (no atomics: one thread per output) + the scattered sum.  The displacements
+    // of all of a thread's outputs are requested first (their taps depend on them)
     float* o = gout + cb;
-    for (int i = threadIdx.x; i < ETN; i += kExpBlock) {
+    constexpr int kOwn = ETN / kExpBlock;
+    float sd[kOwn][3];
+#pragma unroll
+    for (int j = 0; j < kOwn; ++j) {
+        const int i = threadIdx.x + j * kExpBlock;
+        const int x = min(ox + i % ETX, vol.W - 1), y = min(oy + (i / ETX) % ETY, vol.H - 1), z = min(oz + i / (ETX * ETY), vol.z0 + vol.nz - 1);
+        if (!STAGED && LD.em == 3) {
+            const F3 v = ld3g(c0 + (((int64_t)z * vol.H + y) * vol.W + x) * 3);
+            sd[j][0] = PRESCALE ? prescale(v.x, sc.nm1[0], sc.rnm1[0], sc.inv_pow) : v.x;
+            sd[j][1] = PRESCALE ? prescale(v.y, sc.nm1[1], sc.rnm1[1], sc.inv_pow) : v.y;
+            sd[j][2] = PRESCALE ? prescale(v.z, sc.nm1[2], sc.rnm1[2], sc.inv_pow) : v.z;
+        } else {
+            disp_at(x, y, z, sd[j][0], sd[j][1], sd[j][2]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kOwn; ++j) {
+        const int i = threadIdx.x + j * kExpBlock;
         const int lx = i % ETX, ly = (i / ETX) % ETY, lz = i / (ETX * ETY);
-        const int x = ox + lx, y = oy + ly, z = oz + lz;
-        if (x >= vol.W || y >= vol.H || z >= vol.z0 + vol.nz) continue;
-        float d0, d1, d2, self[3];
-        disp_at(x, y, z, d0, d1, d2);
-        adjoint_self<PRESCALE, H>(x, y, z, d0, d1, d2, ox, oy, oz, Gc, LG, gsc_, c0, LD, lds, vol, lin, sc, self);
+        const bool valid = ox + lx < vol.W && oy + ly < vol.H && oz + lz < vol.z0 + vol.nz;
+        const int x = min(ox + lx, vol.W - 1), y = min(oy + ly, vol.H - 1), z = min(oz + lz, vol.z0 + vol.nz - 1);
+        float self[3];
+        adjoint_self<PRESCALE, H>(x, y, z, sd[j][0], sd[j][1], sd[j][2], ox, oy, oz, Gc, LG, gsc_, c0, LD, lds, vol, lin, sc, self);
+        if (!valid) continue;
         const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-        o[g * LO.em] = self[0] + (float)(long long)acc[i] * inv_scale;
-        o[LO.cs + g * LO.em] = self[1] + (float)(long long)acc[ETN + i] * inv_scale;
-        o[2 * LO.cs + g * LO.em] = self[2] + (float)(long long)acc[2 * ETN + i] * inv_scale;
+        const float o0 = self[0] + (float)(long long)acc[i] * inv_scale, o1 = self[1] + (float)(long long)acc[ETN + i] * inv_scale,
+                    o2 = self[2] + (float)(long long)acc[2 * ETN + i] * inv_scale;
+        if (LO.em == 3) {
+            const F3 v = {o0, o1, o2};
+            __builtin_memcpy(o + g * 3, &v, 12);
+        } else {
+            o[g] = o0;
+            o[LO.cs + g] = o1;
+            o[2 * LO.cs + g] = o2;
+        }
     }
     __syncthreads();
+    IRS_LT(3, wall_clock64());
   }
 }
 
@@ -438,7 +588,7 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
         return;
     }
     TileGrid tz;
-    const dim3 grid = exp_grid(vol, C, &tz);
+    (void)exp_grid(vol, C, &tz);
     const Scale3L sc = make_scale_l(vol, no_steps);
     if (!global_knobs().coarse_box) cmm = nullptr;  // parity test of the two source boxes
     if (cmm) {  // coarse displacement extrema / gradient maxima (coarse_minmax_bytes(vol, C) of scratch)
@@ -447,10 +597,25 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
         if (prescale_in) hipLaunchKernelGGL((coarse_minmax_kernel<true>), cg, dim3(kWave), 0, st, dk, G, gscale, cmm, vol, sc, dmax, gather_radius, ncx, ncy, ncz, lay);
         else hipLaunchKernelGGL((coarse_minmax_kernel<false>), cg, dim3(kWave), 0, st, dk, G, gscale, cmm, vol, sc, dmax, gather_radius, ncx, ncy, ncz, lay);
     }
-#define IRS_BWD(P, HH) hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), grid, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay, cmm)
+    // the persistent grid is ONE resident set of workgroups (asked from the runtime once per variant): a grid that is not a
+    // multiple of it leaves a partial last round in which most of the chip idles
+#define IRS_BWD(P, HH)                                                                                                           \
+    do {                                                                                                                         \
+        static int resident = 0;                                                                                                 \
+        if (!resident) {                                                                                                         \
+            int per_cu = 0, dev = 0, cus = 0;                                                                                    \
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && \
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, exp_bwd_lds_kernel<P, HH>, kExpBlock, 0) == hipSuccess && per_cu > 0 && cus > 0) \
+                resident = per_cu * cus;                                                                                         \
+            else                                                                                                                 \
+                resident = kExpGridCap;                                                                                          \
+        }                                                                                                                        \
+        const dim3 g_((unsigned)(tz.total < resident ? tz.total : resident));                                                    \
+        hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), g_, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay, cmm); \
+    } while (0)
     // With the gather variants in front (gather_radius >= 2) the staged box of d around the tile is of little use (sources
     // and taps are far away): H = 0 stages nothing (49 KB of accumulators instead of 111 KB of LDS -> three workgroups per CU)
-    if (gather_radius >= 2) halo = 0;
+    if (gather_radius >= 2 || global_knobs().lds_from == 2) halo = 0;
     if (prescale_in) {
         if (halo <= 0) IRS_BWD(true, 0); else if (halo <= 1) IRS_BWD(true, 1); else IRS_BWD(true, 2);
     } else {
@@ -490,9 +655,10 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 //    candidates; bit-identical results): 199 instead of 166 us per launch on a smooth 6-voxel field where most planes qualify,
 //    243 instead of 199 us on a smooth 3-voxel one.
 // The radius-1 adjoint only runs for max|d_k| < 1 (selected on the device from the exact bound): the eight corners of a voxel's
-// own sample then ALWAYS sit in the ring, and the global-memory fallback for taps that leave it is dead code.  1: keep it (A/B).
+// own sample then ALWAYS sit in the ring, and the global-memory fallback for taps that leave it is dead code -- which stays in
+// (1): compiled out (0) the kernel is 3 VGPRs smaller and 7 % SLOWER (219 against 204 us per launch, two same-box A/B runs).
 #ifndef IRS_BWD_R1_FALLBACK
-#define IRS_BWD_R1_FALLBACK 0
+#define IRS_BWD_R1_FALLBACK 1
 #endif
 // hat of (r + c) for a relative position r and a compile-time integer offset c.
 template <int R>
@@ -505,7 +671,6 @@ __device__ __forceinline__ float rel_hat(float r, int c);
 __device__ __forceinline__ float ld_off(const float* __restrict__ base, unsigned byte_off) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
-typedef float F3 __attribute__((ext_vector_type(3)));
 // one 12-byte access per lane for an interleaved field (global_load / store_dwordx3; 4-byte alignment suffices)
 __device__ __forceinline__ F3 ld3_off(const float* __restrict__ base, unsigned byte_off) {
     F3 v;
@@ -756,12 +921,17 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
 #pragma unroll
                     for (int dx = 0; dx <= 2 * R; ++dx) {
                         const int ri = PH * PN + (ly + dy) * PX + (lx + dx);
-                        const float2 rxy = q_xy[ri], rzg = q_zg[ri], g01 = q_g[ri];
+                        const float2 rxy = q_xy[ri];
                         // weight of source (x + dx - R, y + dy - R, s) on output (x, y, s + oo): hat(r + offset) per axis.
                         // R == 1 guarantees |r| < 1 (variant selection by the displacement bound), where
                         // hat(r + 1) = max(0, -r) and hat(r - 1) = max(0, r): one clamped op each
                         const float hx = rel_hat<R>(rxy.x, dx - R), hy = rel_hat<R>(rxy.y, dy - R);
                         const float hxy = hx * hy;
+                        // radius 2: a source reaches 2 of the 5 offsets per axis, so 21 of the 25 in-plane candidates of an output
+                        // carry weight 0 -- and where the field is smooth they are the SAME 21 for every lane of the wavefront:
+                        // skip the rest of such a candidate (two LDS reads, 5 weights, 15 multiply-adds) behind one vote
+                        if (R == 2 && !__any(hxy != 0.0f)) continue;
+                        const float2 rzg = q_zg[ri], g01 = q_g[ri];
 #pragma unroll
                         for (int oo = -R; oo <= R; ++oo) {
                             const int a = (PH + oo + NP) % NP;  // accumulator of output plane s + oo (static index)
@@ -1184,6 +1354,7 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     const int swz_env = global_knobs().swz_run;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;
 #define IRS_FWM(P, RR, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), dim3(GRID), dim3(FTX * FTY / FROWS_BIG), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
+#define IRS_FW2(P, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 2, 1>), dim3(GRID), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
 #define IRS_FWS(P, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 1, 1>), dim3(total), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run, tiles, lay)
     const int rare = total < kRareGrid ? total : kRareGrid;
     // small launches (at most two workgroups of tiles per CU): the radius-1 kernel with one output row per thread
@@ -1195,9 +1366,12 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     } else {
         if (small) { if (prescale_in) IRS_FWS(true, -1, 1); else IRS_FWS(false, -1, 1); }
         else if (prescale_in) IRS_FWM(true, 1, -1, 1, total); else IRS_FWM(false, 1, -1, 1, total);
-        if (prescale_in) IRS_FWM(true, 2, 1, 1 << 30, rare); else IRS_FWM(false, 2, 1, 1 << 30, rare);
+        // radius-2 ring: 59 KB, two workgroups per CU -- with one output row per thread they are 16 waves instead of 8
+        if (global_knobs().fwd_r2_rows1) { if (prescale_in) IRS_FW2(true, 1, 1 << 30, rare); else IRS_FW2(false, 1, 1 << 30, rare); }
+        else if (prescale_in) IRS_FWM(true, 2, 1, 1 << 30, rare); else IRS_FWM(false, 2, 1, 1 << 30, rare);
     }
 #undef IRS_FWS
+#undef IRS_FW2
 #undef IRS_FWM
 }
 
