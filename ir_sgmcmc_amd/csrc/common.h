@@ -90,6 +90,7 @@ struct Knobs {
     int fwd_rows1 = -1;        // IRS_FWD_ROWS1         forward squaring step with one output row per thread (512 threads): -1 by launch size, 0 / 1
     int lds_from = 3;          // IRS_LDS_FROM          adjoint: smallest source halo (floor(max|d_k|) + 1) the any-radius kernel takes; 3 = radius-2 gather in front of it, 2 = not
     int fwd_r2_rows1 = 1;      // IRS_FWD_R2_ROWS1      radius-2 forward squaring step with one output row per thread (512 threads)
+    int fwd_pf = 2;            // IRS_FWD_PF            one-row forward variant (small launches): planes of global loads in flight ahead of the commit (1 / 2)
     int coarse_box = 1;        // IRS_COARSE_BOX        any-radius adjoint: source boxes from the coarse displacement extrema
     int sobolev_tile = 0;      // IRS_SOBOLEV_TILE      0: by size; 1: 32 x 16; 2: 64 x 32 ("small" / "big")
     int march_seg = 0, march_seg_fwd = 0, swz_run = -1, seg_min_blocks = 0, seg_min_len = 0;  // IRS_MARCH_SEG, _FWD, IRS_SWZ_RUN, IRS_SEG_MIN_*

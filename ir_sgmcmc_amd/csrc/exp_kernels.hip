@@ -55,6 +55,10 @@ struct Lay3 {
     int em;
 };
 __host__ __device__ __forceinline__ Lay3 lay3(int aos, int64_t V) { return aos ? Lay3{1, 3} : Lay3{V, 1}; }
+template <int L>
+struct LayC {  // a layout bit set as a type: the marching tiles instantiate their body per layout
+    static constexpr int value = L;
+};
 
 __device__ __forceinline__ void atomic_max_nonneg(unsigned* addr, float v) {
     // non-negative floats order like their bit patterns
@@ -657,6 +661,11 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 // The radius-1 adjoint only runs for max|d_k| < 1 (selected on the device from the exact bound): the eight corners of a voxel's
 // own sample then ALWAYS sit in the ring, and the global-memory fallback for taps that leave it is dead code -- which stays in
 // (1): compiled out (0) the kernel is 3 VGPRs smaller and 7 % SLOWER (219 against 204 us per launch, two same-box A/B runs).
+// Compile-time layouts in the adjoint (as in the forward step, where they removed a wait from the middle of the prefetch and gave
+// 5 %): measured 221 against 204 us per radius-1 launch (24 bytes of scratch at the 128-VGPR limit) -- 0
+#ifndef IRS_BWD_LAYC
+#define IRS_BWD_LAYC 0
+#endif
 #ifndef IRS_BWD_R1_FALLBACK
 #define IRS_BWD_R1_FALLBACK 1
 #endif
@@ -756,6 +765,20 @@ __device__ __forceinline__ void exp_bwd_generic_column(const float* __restrict__
     }
 }
 
+#ifdef IRS_BWD_TRACE
+// timing experiment (tools/bwd_phase_trace.py; build with tools/build_variant.sh bwdtrace -DIRS_BWD_TRACE): clock stamps of one wave
+// of one workgroup at the phase boundaries of the marching loop.  For reading proportions, not for timing the kernel.
+__device__ unsigned long long g_bwd_trace[8 * 64];
+extern "C" int irs_debug_bwd_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_trace), sizeof(g_bwd_trace)) == hipSuccess ? 0 : 1;
+}
+#define IRS_BT(slot)                                                                                  \
+    do {                                                                                              \
+        if (btrace_on && btrace_it < 64) g_bwd_trace[btrace_it * 8 + (slot)] = wall_clock64();        \
+    } while (0)
+#else
+#define IRS_BT(slot)
+#endif
 template <bool PRESCALE, int R>
 __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, const float* __restrict__ dk,
                                                    float* __restrict__ gout, const Vol vol, const Lin lin, const Scale3L sc,
@@ -783,7 +806,10 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     seg_range(vol, seg, seg_len, z0, z1);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
-    const Lay3 LD = lay3(lay & 1, V), LG = lay3(lay & 2, V), LO = lay3(lay & 4, V);
+    auto run = [&](auto LC) {  // layouts as compile-time constants (see the forward tile), or (< 0) the run-time ones
+    constexpr int LAYC = decltype(LC)::value;
+    const int lay_ = LAYC < 0 ? lay : LAYC;
+    const Lay3 LD = lay3(lay_ & 1, V), LG = lay3(lay_ & 2, V), LO = lay3(lay_ & 4, V);
     if (R == 2 && hs > R) {  // the any-radius kernel was not launched for this step and the bound outgrew the ring
         const int gx = ox + (int)(threadIdx.x % MTX), gy = oy + (int)(threadIdx.x / MTX);
         if (gx < vol.W && gy < vol.H)
@@ -905,15 +931,27 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
 
     const int sbase = z0 - R;            // ring slot of plane s is (s - sbase) % NP
     const int slast = z1 - 1 + R;
+#ifdef IRS_BWD_TRACE
+    const bool btrace_on = R == 1 && !PRESCALE && tile_id == (int)(tiles.x * tiles.y * tiles.z) / 2 + 3 && threadIdx.x == 64;
+    int btrace_it = 0;
+#endif
     prefetch(sbase);
     for (int sb = sbase; sb <= slast; sb += NP) {
 #pragma unroll
         for (int PH = 0; PH < NP; ++PH) {
             const int s = sb + PH;
             if (s > slast) break;
+#ifdef IRS_BWD_TRACE
+            IRS_BT(0);
+            __builtin_amdgcn_s_waitcnt(0);  // the loads of plane s have arrived
+            IRS_BT(1);
+#endif
             commit(s, PH);
+            IRS_BT(2);
             prefetch(s + 1);
+            IRS_BT(3);
             __syncthreads();
+            IRS_BT(4);
             // ---- contributions of source plane s to output planes s-R .. s+R
             if (s >= 0 && s < vol.D && col_in) {
 #pragma unroll IRS_GATHER_UNROLL_Y
@@ -942,6 +980,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                         }
                     }
             }
+            IRS_BT(5);
             // ---- output plane zo = s - R is complete
             {
                 const int zo = s - R;
@@ -1026,9 +1065,26 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                 acc01[a] = make_float2(0.0f, 0.0f);
                 acc2[a] = 0.0f;
             }
+            IRS_BT(6);
             __syncthreads();  // the next commit overwrites the oldest ring slot
+            IRS_BT(7);
+#ifdef IRS_BWD_TRACE
+            ++btrace_it;
+#endif
         }
     }
+    };  // run
+#if IRS_BWD_LAYC
+    switch (lay & 7) {  // the combinations the library produces (ctx.h: bwd_lay; 0 = the planar operator API)
+        case 0: run(LayC<0>{}); break;
+        case 2: run(LayC<2>{}); break;
+        case 5: run(LayC<5>{}); break;
+        case 7: run(LayC<7>{}); break;
+        default: run(LayC<-1>{}); break;
+    }
+#else
+    run(LayC<-1>{});
+#endif
 }
 
 // One tile per workgroup for the common radius-1 variant (XCD-aware order); the rarely selected variants are launched on a
@@ -1117,7 +1173,9 @@ extern "C" int irs_debug_fwd_trace(unsigned long long* out) {
 #else
 #define IRS_TR(slot)
 #endif
-template <bool PRESCALE, int R, int FROWS>
+// PF: how many planes ahead of the one being committed the global loads run (1: the next plane is in flight while this one is
+// sampled; 2: two planes -- short segments on small volumes, where a plane step is otherwise one load latency long)
+template <bool PRESCALE, int R, int FROWS, int PF>
 __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din, float* __restrict__ dout, const Vol vol,
                                                    const Lin lin, const Scale3L sc, const unsigned* __restrict__ dmax_in,
                                                    unsigned* __restrict__ dmax_out, const int seg_len, const int nseg,
@@ -1144,7 +1202,12 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
     seg_range(vol, seg, seg_len, z0, z1);
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
-    const Lay3 LD = lay3(lay & 1, V), LO = lay3(lay & 4, V);
+    // The layouts are COMPILE-TIME constants inside `run`: with a run-time layout both forms of a prefetch load (one 12-byte load /
+    // three 4-byte loads) target the same registers, the 12-byte one then lands in a scratch triple and is COPIED over -- behind
+    // an s_waitcnt vmcnt(0) in the middle of the prefetch, which serialises it (seen in the ISA of rounds 1-3)
+    auto run = [&](auto LC) {
+    constexpr int LAYC = decltype(LC)::value;
+    const Lay3 LD = lay3(LAYC & 1, V), LO = lay3(LAYC & 4, V);
     const float* __restrict__ dx_ = din + cb;
     const float* __restrict__ dy_ = dx_ + LD.cs;
     const float* __restrict__ dz_ = dy_ + LD.cs;
@@ -1162,8 +1225,8 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
         sxy[it] = i < PN ? cy * vol.W + cx : -1;
         sld[it] = py * PITCH + px;
     }
-    float pre[NIT][3];
-    auto prefetch = [&](int s) {
+    float pre[PF][NIT][3];
+    auto prefetch = [&](int s, float (&pre)[NIT][3]) {
         const int sc_ = min(max(s, 0), vol.D - 1);  // planes outside the volume replicate the border plane
         const int64_t zo = (int64_t)sc_ * vol.H * vol.W * LD.em;
         const float* __restrict__ px_ = dx_ + zo;  // uniform plane bases + 32-bit lane offsets
@@ -1185,7 +1248,7 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
             }
         }
     };
-    auto commit = [&](int slot) {
+    auto commit = [&](int slot, const float (&pre)[NIT][3]) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
@@ -1198,11 +1261,21 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
 
     float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
     const int sbase = z0 - R, slast = z1 - 1 + R;
+    // Identity-grid coordinates.  The counter a wavefront waits on completes IN ORDER: a load issued after the prefetch of the
+    // next plane cannot be waited for without waiting for that whole plane first -- which, at the top of the sampling phase, is
+    // exactly the overlap the prefetch exists for.  So the y coordinates are read once per tile, and the z coordinate of the plane
+    // sampled in step s + 1 is requested in step s BEFORE that step's prefetch.
+    float liny_[FROWS];
+#pragma unroll
+    for (int j = 0; j < FROWS; ++j) liny_[j] = lin.y[min(oy + ly0 + j * (FTY / FROWS), vol.H - 1)];
+    float linz_nx = lin.z[min(max(sbase - R, 0), vol.D - 1)];
 #ifdef IRS_FWD_TRACE
     const bool trace_on = R == 1 && !PRESCALE && tile_id == (int)(tiles.x * tiles.y * tiles.z) / 2 + 3 && threadIdx.x == 64;
     int trace_it = 0;
 #endif
-    prefetch(sbase);
+    static_assert(NS % PF == 0, "the buffer of plane s is (s - sbase) % PF == PH % PF");
+    prefetch(sbase, pre[0]);
+    if (PF > 1) prefetch(sbase + 1, pre[PF - 1]);
     for (int sb = sbase; sb <= slast; sb += NS) {
 #pragma unroll
         for (int PH = 0; PH < NS; ++PH) {
@@ -1213,20 +1286,21 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
             __builtin_amdgcn_s_waitcnt(0);  // the loads of plane s have arrived
             IRS_TR(1);
 #endif
-            commit(PH);
+            commit(PH, pre[PH % PF]);
             IRS_TR(2);
-            if (s + 1 <= slast) prefetch(s + 1);
+            const float linz = linz_nx;
+            linz_nx = lin.z[min(max(s + 1 - R, 0), vol.D - 1)];
+            if (s + PF <= slast) prefetch(s + PF, pre[PH % PF]);
             IRS_TR(3);
             __syncthreads();
             IRS_TR(4);
             const int zo = s - R;
             if (zo >= z0 && zo < z1) {
-                const float linz = lin.z[zo];
 #pragma unroll
                 for (int j = 0; j < FROWS; ++j) {
                 const int ly = ly0 + j * (FTY / FROWS), y = oy + ly;
                 if (x >= vol.W || y >= vol.H) continue;
-                const float liny = lin.y[y];
+                const float liny = liny_[j];
                 const int a = (PH - R + NS) % NS;  // slot of plane zo (compile-time)
                 const int ci = a * PNP + (ly + R) * PITCH + (lx + R);
                 const float2 dxy = r_xy[ci];
@@ -1239,7 +1313,7 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                 const int bx0 = tx.i0 - (ox - R), by0 = ty.i0 - (oy - R), rel = tz.i0 - zo;
                 const bool in_ring = (unsigned)bx0 < (unsigned)(PX - 1) && (unsigned)by0 < (unsigned)(M::PY - 1) && rel >= -R && rel < R;
                 float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-                if (in_ring) {
+                auto ring_taps = [&]() {
                     // (wx * wy) is shared by the two z corners: same products, same rounding as ((wx * wy) * wz)
                     const float wxy[2][2] = {{__fmul_rn(tx.w0, ty.w0), __fmul_rn(tx.w1, ty.w0)},
                                              {__fmul_rn(tx.w0, ty.w1), __fmul_rn(tx.w1, ty.w1)}};
@@ -1265,6 +1339,14 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                                 a2 = __fadd_rn(a2, __fmul_rn(r_z[bs + cy * PITCH + cx], w));
                             }
                     }
+                };
+                // the usual case -- every tap of every lane inside the ring -- behind a WAVE-UNIFORM branch: in a divergent
+                // if / else the global-memory path is laid out first, and the registers its loads target make the ring path wait
+                // for "their" loads, i.e. (in-order counter) for the prefetch of the next plane
+                if (__all(in_ring)) {
+                    ring_taps();
+                } else if (in_ring) {
+                    ring_taps();
                 } else {
 #pragma unroll
                     for (int cz = 0; cz < 2; ++cz)
@@ -1325,12 +1407,19 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
             if (__float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_nonneg(slot, m);
         }
     }
+    };  // run
+    switch (lay & 5) {
+        case 0: run(LayC<0>{}); break;
+        case 1: run(LayC<1>{}); break;
+        case 4: run(LayC<4>{}); break;
+        default: run(LayC<5>{}); break;
+    }
 }
 
 #ifndef IRS_FWD_WAVES
-#define IRS_FWD_WAVES 1
+#define IRS_FWD_WAVES 4
 #endif
-template <bool PRESCALE, int R, int FROWS = FROWS_BIG>
+template <bool PRESCALE, int R, int FROWS = FROWS_BIG, int PF = 1>
 __global__ __launch_bounds__(FTX * FTY / FROWS, R == 1 ? IRS_FWD_WAVES : 1) void exp_fwd_march_kernel(const float* __restrict__ din, float* __restrict__ dout,
                                                                   Vol vol, Lin lin, Scale3L sc,
                                                                   const unsigned* __restrict__ dmax_in,
@@ -1338,7 +1427,7 @@ __global__ __launch_bounds__(FTX * FTY / FROWS, R == 1 ? IRS_FWD_WAVES : 1) void
                                                                   int h_lo, int h_hi, int swz_run, dim3 tiles, int lay) {
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     for (int id = blockIdx.x; id < total; id += gridDim.x) {
-        exp_fwd_march_tile<PRESCALE, R, FROWS>(din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, h_lo, h_hi, swz_run, id, tiles, lay);
+        exp_fwd_march_tile<PRESCALE, R, FROWS, PF>(din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, h_lo, h_hi, swz_run, id, tiles, lay);
         __syncthreads();  // the ring and the reduction scratch are reused by the next tile
     }
 }
@@ -1355,7 +1444,10 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;
 #define IRS_FWM(P, RR, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), dim3(GRID), dim3(FTX * FTY / FROWS_BIG), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
 #define IRS_FW2(P, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 2, 1>), dim3(GRID), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
-#define IRS_FWS(P, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 1, 1>), dim3(total), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run, tiles, lay)
+#define IRS_FWS(P, LO, HI)                                                                                                      \
+    if (global_knobs().fwd_pf >= 2) IRS_FWS_(P, 2, LO, HI);                                                                     \
+    else IRS_FWS_(P, 1, LO, HI)
+#define IRS_FWS_(P, PFF, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 1, 1, PFF>), dim3(total), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run, tiles, lay)
     const int rare = total < kRareGrid ? total : kRareGrid;
     // small launches (at most two workgroups of tiles per CU): the radius-1 kernel with one output row per thread
     const int small_env = global_knobs().fwd_rows1;
@@ -1371,6 +1463,7 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
         else if (prescale_in) IRS_FWM(true, 2, 1, 1 << 30, rare); else IRS_FWM(false, 2, 1, 1 << 30, rare);
     }
 #undef IRS_FWS
+#undef IRS_FWS_
 #undef IRS_FW2
 #undef IRS_FWM
 }

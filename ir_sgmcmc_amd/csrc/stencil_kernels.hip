@@ -504,12 +504,24 @@ __global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __
             if (aval[it]) pre[it] = ldg_off(base, aoff[it]);
     };
     const int pfirst = z0 - 2 * S, plast = z1 - 1 + 2 * S;
-    load_plane(pfirst);
-    for (int pin = pfirst; pin <= plast; ++pin) {
+    // MAP: the fixed-image value each output is subtracted from, requested one plane ahead and BEFORE that step's prefetch (a load
+    // issued in phase C could only be waited for together with the prefetch: in-order counter); two buffers, used alternately
+    struct OwnIn {
+        float f[2];
+    };
+    auto load_own = [&](int pv, OwnIn& q) {
+        if (!MAP || pv < z0 || pv >= z1) return;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+            if (oval[o]) q.f[o] = fhat[(int64_t)chain * fhat_stride + (int64_t)pv * HW + (unsigned)((oy + ly + o * (LMY / 2)) * vol.W + gx)];
+    };
+    auto step = [&](int pin, const OwnIn& cur, OwnIn& nxt) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): phase A needs the newest loads anyway; unconditional, so that `cur` counts as arrived
         // ---- A
 #pragma unroll
         for (int it = 0; it < NITA; ++it)
             if (aval[it]) LA[threadIdx.x + it * kStBlock] = pre[it];
+        load_own(pin + 1 - 2 * S, nxt);
         if (pin < plast) load_plane(pin + 1);
         __syncthreads();
         // ---- B
@@ -576,10 +588,17 @@ __global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __
                 const float wc = LW[slot_v * BN + (yy + S) * BX + lx + S];
                 const float r = wc * __builtin_amdgcn_rcpf(sigma);
                 const int64_t g = (int64_t)pv * HW + (unsigned)((oy + yy) * vol.W + gx);
-                out[(int64_t)chain * vol.V + g] = MAP ? fhat[(int64_t)chain * fhat_stride + g] - r : r;
+                out[(int64_t)chain * vol.V + g] = MAP ? cur.f[o] - r : r;
                 if (sigma_out) sigma_out[(int64_t)chain * vol.V + g] = sigma;
             }
         }
+    };
+    OwnIn qa = {}, qb = {};
+    load_own(pfirst - 2 * S, qa);
+    load_plane(pfirst);
+    for (int pin = pfirst; pin <= plast; pin += 2) {
+        step(pin, qa, qb);
+        if (pin + 1 <= plast) step(pin + 1, qb, qa);
     }
 }
 
@@ -1107,6 +1126,7 @@ constexpr int UPX = QTX + 2, UPY = QTY + 2, UPN = UPX * UPY, UNS = 4;
 // stencil above is built from exactly those differences and weights.  Used for the regularisers whose coefficient does not depend
 // on the energy (RegLoss_L2, RegLoss_LogNormal_L2: coef = w / 2, `coef_from_w`), where the energy is only needed AFTER the update
 // (loss term, Adam step on log w): one kernel and one pass over v_s less per transition.
+template <bool SIGMA>  // sigma field present (compile-time: a run-time branch around its loads leaves waits in the own-voxel prefetch)
 __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __restrict__ v, const float* __restrict__ sigma,
                                                                      const float* __restrict__ g, const float* __restrict__ v_s,
                                                                      const DevState* __restrict__ state, float lr, float s0,
@@ -1168,11 +1188,35 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
     commit(z0 - 1);
     load_plane(z0);
     commit(z0);
-    load_plane(z0 + 1);
     const unsigned own = col_in ? (unsigned)(y * vol.W + x) * 4u : 0u;
-    for (int zc = z0; zc < z1; ++zc) {
+    // The streams read once per voxel (incoming gradient, v itself, sigma) are requested ONE PLANE AHEAD and BEFORE the stencil
+    // prefetch of that step: the wavefront's memory counter completes in order, so a load issued in the compute phase -- after the
+    // prefetch -- can only be waited for together with the whole prefetch, three times per plane (once per channel: the store
+    // to v orders the next channel's load behind it).  That made this kernel latency-bound at 2.5x its HBM time.
+    struct OwnIn {
+        float g[3], v[3], s[3];
+    };
+    auto load_own = [&](int z, OwnIn& q) {
+        const int64_t pl = (int64_t)z * HW;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int64_t base = cb + c * vol.V + pl;
+            q.g[c] = ldg_off(g + base, own);
+            q.v[c] = ldg_off(v + base, own);
+            if (SIGMA) q.s[c] = ldg_off(sigma + base, own);
+        }
+    };
+    // one plane: `cur` holds the plane's own-voxel streams (requested a step ago), `nxt` receives the next plane's
+    auto step = [&](int zc, const OwnIn& cur, OwnIn& nxt) {
+        // commit needs the newest loads anyway; said unconditionally (the commit's own waits sit behind per-lane guards) it also
+        // tells the compiler that `cur` has arrived -- otherwise it re-waits for it in the compute phase, with a count that covers
+        // the loads issued below
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         commit(zc + 1);
-        if (zc + 1 < z1) load_plane(zc + 2);
+        if (zc + 1 < z1) {
+            load_own(zc + 1, nxt);
+            load_plane(zc + 2);
+        }
         __syncthreads();  // ring of 4: plane zc + 1 landed in the slot of plane zc - 3, which nobody reads any more
         if (col_in) {
             const int sm = (((zc - 1) % UNS) + UNS) % UNS, s0_ = ((zc % UNS) + UNS) % UNS, sp = (((zc + 1) % UNS) + UNS) % UNS;
@@ -1193,14 +1237,21 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
                 if (energy_partials) eacc[0] += (double)(wxp * dxp * dxp + wyp * dyp * dyp + wzp * dzp * dzp);
                 const float lap = rx + ry + rz;
                 const int64_t base = cb + c * vol.V + pl;
-                const float gr = ldg_off(g + base, own) * sc[c] + coef2 * lap;
-                const float sg = sigma ? ldg_off(sigma + base, own) : 1.0f;
+                const float gr = cur.g[c] * sc[c] + coef2 * lap;
+                const float sg = SIGMA ? cur.s[c] : 1.0f;
                 const float gs = sg * sg * gr;  // SGLD.backward: sigma^2 * grad == v.grad in the reference
                 float* __restrict__ vp = reinterpret_cast<float*>(reinterpret_cast<char*>(v + base) + own);
                 if (grad_out) *reinterpret_cast<float*>(reinterpret_cast<char*>(grad_out + base) + own) = gs;
-                if (!frozen) *vp = *vp - lr * gs;
+                if (!frozen) *vp = cur.v[c] - lr * gs;
             }
         }
+    };
+    OwnIn qa = {}, qb = {};  // two buffers used alternately (no copies: a copy would have to wait for the loads it copies)
+    load_own(z0, qa);
+    load_plane(z0 + 1);
+    for (int zc = z0; zc < z1; zc += 2) {
+        step(zc, qa, qb);
+        if (zc + 1 < z1) step(zc + 1, qb, qa);
     }
     if (energy_partials) {  // (uniform branch: every thread of the block arrives)
         block_sum<1>(eacc, esm);
@@ -1224,9 +1275,14 @@ void launch_sgld_update_march(float* v, const float* sigma, const float* g_d0, c
     const int seg_len = update_seg_len(vol, C);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + QTY - 1) / QTY;
-    hipLaunchKernelGGL(sgld_update_march_kernel, dim3((unsigned)(ntx * nty * nseg * C)), dim3(kStBlock), 0, st, v, sigma, g_d0,
-                       v_s, (const DevState*)dev_state, lr, s0, s1, s2, grad_out, vol, seg_len, nseg, ntx, nty, energy_partials,
-                       coef_from_w ? 1 : 0);
+    if (sigma)
+        hipLaunchKernelGGL(sgld_update_march_kernel<true>, dim3((unsigned)(ntx * nty * nseg * C)), dim3(kStBlock), 0, st, v, sigma, g_d0,
+                           v_s, (const DevState*)dev_state, lr, s0, s1, s2, grad_out, vol, seg_len, nseg, ntx, nty, energy_partials,
+                           coef_from_w ? 1 : 0);
+    else
+        hipLaunchKernelGGL(sgld_update_march_kernel<false>, dim3((unsigned)(ntx * nty * nseg * C)), dim3(kStBlock), 0, st, v, sigma, g_d0,
+                           v_s, (const DevState*)dev_state, lr, s0, s1, s2, grad_out, vol, seg_len, nseg, ntx, nty, energy_partials,
+                           coef_from_w ? 1 : 0);
 }
 
 }  // namespace irs
