@@ -15,10 +15,11 @@ import csv, glob, sys, json, collections
 out = sys.argv[1]
 f = glob.glob(out + '/trace/**/k_kernel_trace.csv', recursive=True)[0]
 ts = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f)))
-# the probe runs the fused engine first, then the slab rank (whose transitions carry validate_widths_kernel); every
-# transition ends with finalize_kernel
+# the probe runs the fused engine first, then (after building the slab context: the longest pause between two transitions) the slab
+# rank; every transition ends with finalize_kernel
 fin = [i for i, t in enumerate(ts) if 'finalize_kernel' in t[2]]
-first_slab = next(i for i, t in enumerate(ts) if 'validate_widths' in t[2])
+gaps = [(ts[fin[j]][0] - ts[fin[j - 1]][0], j) for j in range(1, len(fin))]
+first_slab = fin[max(gaps)[1] - 1] + 1
 def last(fins, n):
     part = ts[fins[-n - 1] + 1:fins[-1] + 1]
     busy = sum(e - s for s, e, _ in part)
