@@ -163,6 +163,27 @@ def test_svf_exp_backward_large_smooth_displacement():
     assert int(bad) <= 1e-3 * gv_ref.numel()
 
 
+def test_any_radius_adjoint_walks_huge_source_boxes_with_plain_division():
+    """The any-radius adjoint walks the source box of a tile in one flat order and splits the flat index with a multiply-high
+    division that is exact while (sources in the box) x (box extent in x, y) < 2^32; beyond that it divides.  A folding
+    100-voxel field at 128^3 without the coarse-grid refinement gives every tile (nearly) the whole volume as its box
+    (2e6 sources x 16384), with it the boxes are small: the two must agree (only the per-tile fixed-point scale differs)."""
+    dims, amp = (128, 128, 128), 100.0
+    v = smooth_field(1, dims, amp, 2)
+    g_last = smooth_field(1, dims, 1.0, 33)
+    _, _, steps = G.svf_exp_fwd(dev(v), 12, want_outputs=False)
+    assert float(steps[-2].abs().max()) * 0.5 * (min(dims) - 1) > 46.0   # B0 = tile +- 47 or more: >= 126 x 102 x 102 sources
+    gv = G.svf_exp_bwd(dev(v), steps, dev(g_last))
+    from ir_sgmcmc_amd._lib import option_set
+    try:
+        option_set('coarse_box', 0)
+        gv_plain = G.svf_exp_bwd(dev(v), steps, dev(g_last))
+    finally:
+        option_set('coarse_box', 1)
+    assert bool(torch.isfinite(gv).all())
+    assert maxdiff(gv, gv_plain) < 2e-6 * float(gv_plain.abs().max())
+
+
 @pytest.mark.parametrize('N,cps', [(16, 4), (16, 2), (17, 4), (20, 3)])
 def test_ffd_up_and_adjoint(N, cps):
     dims, c = (N,) * 3, (cps,) * 3
