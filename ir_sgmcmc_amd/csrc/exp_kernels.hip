@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                     const bool in_ring = (R == 1 && !IRS_BWD_R1_FALLBACK) ||
                                          ((unsigned)bx0 < (unsigned)(PX - 1) && (unsigned)by0 < (unsigned)(M::PY - 1) && rel >= -R && rel < R);
                     float dot[2][2][2];
-                    if (in_ring) {
+                    auto ring_dots = [&]() {
                         int sl0 = ((a - R + NP) % NP) * PN, sl1 = ((a - R + 1 + NP) % NP) * PN;  // rel == -R
 #pragma unroll
                         for (int q = -R + 1; q < R; ++q) {
@@ -1025,6 +1025,11 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                                     dot[cz][cy][cx] = fmaf(q_dz[bs + cy * PX + cx], G2, fmaf(v01.y, G1, v01.x * G0));
                                 }
                         }
+                    };
+                    // (the same path behind a wave-uniform `__all(in_ring)` branch, which took 7 % off the forward step, changes nothing
+                    // here: 204-205 us either way -- by the time a wave reaches its own term the prefetch has long arrived)
+                    if (in_ring) {
+                        ring_dots();
                     } else {  // cannot happen while max|d| < R
 #pragma unroll
                         for (int cz = 0; cz < 2; ++cz)
@@ -1286,6 +1291,10 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
             __builtin_amdgcn_s_waitcnt(0);  // the loads of plane s have arrived
             IRS_TR(1);
 #endif
+            // the commit needs the newest loads anyway; said unconditionally (its own waits sit behind per-lane guards) it also tells the
+            // compiler that everything older -- the z coordinate requested a step ago -- has arrived, which it otherwise re-waits for
+            // in the sampling phase with a count that covers most of the prefetch issued below
+            if (PF == 1) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
             commit(PH, pre[PH % PF]);
             IRS_TR(2);
             const float linz = linz_nx;
