@@ -249,11 +249,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* smem) {
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    // the butterfly of wave_sum, one LEVEL for all NV values at a time: value by value it is a chain of 6 NV dependent
+    // ds_bpermute round trips (21 values: 126 x ~150 cycles = 8 us of the 22 us chain_scalar_kernel took).  Same additions, same order.
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        v[i] = wave_sum(v[i]);
-        if (lane == 0) smem[i * (kBlock / kWave) + wid] = v[i];
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        double t[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) t[i] = __shfl_down(v[i], off, kWave);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += t[i];
     }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane == 0) smem[i * (kBlock / kWave) + wid] = v[i];
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll

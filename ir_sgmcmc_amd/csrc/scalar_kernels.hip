@@ -7,21 +7,58 @@
 
 namespace irs {
 
-// out[j] (j < nvals) = sum_b partials[b * nvals + j], same order every run.  All threads must call.
-template <int NV>
+#ifndef IRS_REDUCE_U
+#define IRS_REDUCE_U 4
+#endif
+// out[j] (j < nvals) = sum_b partials[b][j], same order every run.  All threads must call.  BY_COLUMN: the partials are stored
+// [nvals][nblocks] (the statistics kernel writes them that way): consecutive lanes then read consecutive doubles.  With [nblocks][21]
+// rows every load instruction touched ~45 cache lines, and reading 2048 rows was 11 of chain_scalar_kernel's 22 us.
+template <int NV, bool BY_COLUMN = false>
 __device__ void reduce_partials(const double* __restrict__ partials, int nblocks, int nvals, double (&out)[NV],
                                 double* smem) {
     double acc[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) acc[j] = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+    // BY_COLUMN: the loads of kU rows are in flight together (a thread still adds its rows in ascending order): the partials were
+    // written by workgroups on all eight XCDs, so every row is a trip to memory, and 2048 rows were eight of them in a row
+    constexpr int kU = BY_COLUMN ? IRS_REDUCE_U : 1;
+    for (int b0 = threadIdx.x; b0 < nblocks; b0 += kBlock * kU) {
+        double tmp[kU][NV];
 #pragma unroll
-        for (int j = 0; j < NV; ++j)
-            if (j < nvals) acc[j] += partials[(int64_t)b * nvals + j];
+        for (int u = 0; u < kU; ++u) {
+            const int b = b0 + u * kBlock;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                tmp[u][j] = (b < nblocks && j < nvals) ? (BY_COLUMN ? partials[(int64_t)j * nblocks + b] : partials[(int64_t)b * nvals + j]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (b0 + u * kBlock < nblocks) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if (j < nvals) acc[j] += tmp[u][j];
+            }
     }
     block_sum<NV>(acc, smem);
 #pragma unroll
     for (int j = 0; j < NV; ++j) out[j] = acc[j];  // valid in thread 0
+}
+
+// sum of one column of per-block partial sums: a thread's rows in ascending order as before, 8 loads in flight instead of one
+// round trip per row (finalize_kernel 12.1 -> 7.8 us at 256^3); then the fixed-order block sum.  (The same for the 21-column
+// statistics rows of chain_scalar_kernel makes it SLOWER: 18 -> 28 / 32 us with 2 / 4 rows in flight.)
+__device__ __forceinline__ void sum_rows(const double* __restrict__ p, int nblocks, double (&acc)[1], double* smem) {
+    acc[0] = 0.0;
+    constexpr int kU = 8;
+    for (int b0 = threadIdx.x; b0 < nblocks; b0 += kBlock * kU) {
+        double tmp[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) tmp[u] = b0 + u * kBlock < nblocks ? p[b0 + u * kBlock] : 0.0;
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (b0 + u * kBlock < nblocks) acc[0] += tmp[u];
+    }
+    block_sum<1>(acc, smem);
 }
 
 __device__ void refresh_derived(DevState* s, const DevCfg& cfg) {
@@ -65,9 +102,19 @@ void launch_refresh_derived(DevState* s, DevCfg cfg, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // per chain: VD factor (utils/util.py:446-485) and one _step_GMM (trainer.py:68-77)
 // ------------------------------------------------------------------------------------------------
+#ifdef IRS_SCALAR_TRACE
+__device__ unsigned long long g_scalar_trace[8];
+extern "C" int irs_debug_scalar_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scalar_trace), sizeof(g_scalar_trace)) == hipSuccess ? 0 : 1;
+}
+#define IRS_ST(i) do { if (threadIdx.x == 0) g_scalar_trace[i] = wall_clock64(); } while (0)
+#else
+#define IRS_ST(i)
+#endif
 __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const double* __restrict__ partials,
                                                               int nblocks, int chain, int op, DevCfg cfg, Verdict vd) {
     __shared__ double smem[kStatVals * (kBlock / kWave)];
+    IRS_ST(0);
     // the first scalar stage of a transition evaluates the verdict (scalar_kernels.h); a bad one freezes every parameter
     bool bad;
     if (op & 4) {
@@ -79,7 +126,9 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
     __shared__ double rs[kStatVals];
     __shared__ double alpha_s;
     double r[kStatVals];
-    reduce_partials<kStatVals>(partials, nblocks, kStatVals, r, smem);
+    IRS_ST(1);
+    reduce_partials<kStatVals, true>(partials, nblocks, kStatVals, r, smem);
+    IRS_ST(2);
     if (threadIdx.x == 0) {
         const double n = r[0];
         double alpha = (op & 1) ? 1.0 : s->sc.alpha[chain];
@@ -99,6 +148,7 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
         for (int j = 0; j < kStatVals; ++j) rs[j] = r[j];
     }
     __syncthreads();
+    IRS_ST(3);
     if (!(cfg.mode == IRS_DATA_GMM_LCC && (op & 2)) || bad) return;
     // one GMM Adam step (trainer.py:68-77), one lane per parameter: lanes 0 .. K-1 the log std, K .. 2K-1 the logits (the
     // fp64 pow / exp / sqrt of sixteen serial updates on one lane were 20 us of every transition)
@@ -140,6 +190,7 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
         }
     }
     __syncthreads();
+    IRS_ST(4);
     if (t < K) s->st.gmm_log_std[k] = newv;
     else if (t < 2 * K) s->st.gmm_logits[k] = newv;
     __syncthreads();
@@ -148,6 +199,7 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
         s->st.gmm_adam_step[1] += 1;
         refresh_derived(s, cfg);
     }
+    IRS_ST(5);
 }
 
 void launch_chain_scalar(DevState* s, const double* stat_partials, int nblocks, int chain, int op, DevCfg cfg,
@@ -164,9 +216,8 @@ __device__ void reg_scalar_body(DevState* s, const double* __restrict__ partials
     __shared__ double smem[kBlock / kWave];
     __shared__ double ysh[IRS_MAX_CHAINS];
     for (int c = 0; c < cfg.C; ++c) {
-        double acc[1] = {0.0};
-        for (int b = threadIdx.x; b < nblocks; b += kBlock) acc[0] += partials[(int64_t)c * nblocks + b];
-        block_sum<1>(acc, smem);
+        double acc[1];
+        sum_rows(partials + (int64_t)c * nblocks, nblocks, acc, smem);
         if (threadIdx.x == 0) ysh[c] = acc[0];
         __syncthreads();
     }
@@ -274,9 +325,8 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(DevState* s, const dou
         }
     }
     for (int c = 0; c < cfg.C; ++c) {
-        double acc[1] = {0.0};
-        for (int b = threadIdx.x; b < nblocks_per_chain; b += kBlock) acc[0] += partials[(int64_t)c * nblocks_per_chain + b];
-        block_sum<1>(acc, smem);
+        double acc[1];
+        sum_rows(partials + (int64_t)c * nblocks_per_chain, nblocks_per_chain, acc, smem);
         if (threadIdx.x == 0) s->sc.data_term[c] = s->sc.alpha[c] * acc[0];
         __syncthreads();
     }

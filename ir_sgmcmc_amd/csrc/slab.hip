@@ -610,7 +610,7 @@ struct Exec {
             case IRS_SG_STATS: {
                 const uint8_t* mask = io.mask + (io.mask_chains == 1 ? 0 : (int64_t)o.k * c->vol.V);
                 launch_stats(stats_vd, z + (int64_t)o.k * c->vol.V, mask, c->state, c->stat_partials, w, st, c->dcfg.K);
-                launch_reduce_cols(c->stat_partials, stats_blocks(w), kStatVals, c->stat_sum, st);
+                launch_reduce_partials(c->stat_partials, stats_blocks(w), kStatVals, c->stat_sum, st);  // stored [kStatVals][blocks]
                 break;
             }
             case IRS_SG_CHAIN_SCALAR:

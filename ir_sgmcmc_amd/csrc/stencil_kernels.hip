@@ -891,7 +891,7 @@ void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* s
 // lag-1 products x[i] x[i+1] along the three axes.  z-marching over 64 x 4 column tiles: the mixture is evaluated ONCE per
 // voxel (+ a one-voxel halo on the high x / y side and one run-out plane for the z pairs: 1.3 evaluations per voxel; the
 // pointwise version evaluated it for every neighbour again, up to 4 per voxel), the neighbours come from an LDS plane
-// (x, y) and a register (z).  partials: [gridDim.x][kStatVals], reduced by the scalar kernels in fixed order.
+// (x, y) and a register (z).  partials: [kStatVals][gridDim.x], reduced by the scalar kernels in fixed order.
 // ------------------------------------------------------------------------------------------------
 #ifndef IRS_STATS_TY
 #define IRS_STATS_TY 8
@@ -1001,13 +1001,15 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
     }
     block_sum<NACC>(acc, smem);
     if (threadIdx.x == 0) {
-        double* __restrict__ p = partials + (int64_t)blockIdx.x * kStatVals;
+        // [kStatVals][gridDim.x]: the scalar kernel that sums them reads a column with consecutive lanes
+        double* __restrict__ p = partials + blockIdx.x;
+        const int64_t cs = gridDim.x;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) p[j] = acc[j];
+        for (int j = 0; j < 5; ++j) p[j * cs] = acc[j];
 #pragma unroll
         for (int k = 0; k < IRS_MAX_COMPONENTS; ++k) {
-            p[5 + k] = k < KMAX ? acc[5 + (k < KMAX ? k : 0)] : 0.0;
-            p[5 + IRS_MAX_COMPONENTS + k] = k < KMAX ? acc[5 + KMAX + (k < KMAX ? k : 0)] : 0.0;
+            p[(5 + k) * cs] = k < KMAX ? acc[5 + (k < KMAX ? k : 0)] : 0.0;
+            p[(5 + IRS_MAX_COMPONENTS + k) * cs] = k < KMAX ? acc[5 + KMAX + (k < KMAX ? k : 0)] : 0.0;
         }
     }
 }

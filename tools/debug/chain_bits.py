@@ -1,0 +1,29 @@
+"""Digest of a short chain (velocity, hyper-parameter state, scalars) on fixed inputs: run once per library build (IRS_LIB) and compare --
+builds that differ only in scheduling, load batching or which lane computes a scalar must print the same digests."""
+import hashlib
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from bench import engine_config
+from ir_sgmcmc_amd.data_loader import synthetic_pair
+from ir_sgmcmc_amd.engine import TransitionEngine
+
+dev = torch.device('cuda', 0)
+for N, loss, chains in ((48, 'gmm', 2), (64, 'ssd', 1), (128, 'gmm', 1)):
+    f1, m1 = synthetic_pair((N, N, N), seed=0)
+    eng = TransitionEngine(engine_config(N, loss, 1, chains=chains), dev)
+    fd, md = eng.prepare({k: v.unsqueeze(0).to(dev) for k, v in f1.items() if k != 'seg'},
+                         {k: v.unsqueeze(0).to(dev) for k, v in m1.items() if k != 'seg'})
+    if loss == 'gmm':
+        eng.gmm_init(fd, md)
+    v = torch.zeros(chains, 3, N, N, N, device=dev)
+    for _ in range(8):
+        eng.transition(fd, md, v)
+    eng.flush()
+    torch.cuda.synchronize()
+    st = eng.state()
+    sc = eng.scalars()
+    h = lambda b: hashlib.sha256(b).hexdigest()[:16]
+    print(N, loss, chains, 'v', h(v.cpu().numpy().tobytes()), 'state', h(bytes(st) if not isinstance(st, dict) else repr(sorted(st.items())).encode()),
+          'scalars', h(bytes(sc) if not isinstance(sc, dict) else repr(sorted(sc.items())).encode()))
