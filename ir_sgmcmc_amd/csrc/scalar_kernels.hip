@@ -10,6 +10,15 @@ namespace irs {
 #ifndef IRS_REDUCE_U
 #define IRS_REDUCE_U 4
 #endif
+#ifdef IRS_SCALAR_TRACE
+__device__ unsigned long long g_scalar_trace[8];
+extern "C" int irs_debug_scalar_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scalar_trace), sizeof(g_scalar_trace)) == hipSuccess ? 0 : 1;
+}
+#define IRS_ST(i) do { if (threadIdx.x == 0) g_scalar_trace[i] = wall_clock64(); } while (0)
+#else
+#define IRS_ST(i)
+#endif
 // out[j] (j < nvals) = sum_b partials[b][j], same order every run.  All threads must call.  BY_COLUMN: the partials are stored
 // [nvals][nblocks] (the statistics kernel writes them that way): consecutive lanes then read consecutive doubles.  With [nblocks][21]
 // rows every load instruction touched ~45 cache lines, and reading 2048 rows was 11 of chain_scalar_kernel's 22 us.
@@ -39,6 +48,7 @@ __device__ void reduce_partials(const double* __restrict__ partials, int nblocks
                     if (j < nvals) acc[j] += tmp[u][j];
             }
     }
+    if (NV > 3) IRS_ST(6);
     block_sum<NV>(acc, smem);
 #pragma unroll
     for (int j = 0; j < NV; ++j) out[j] = acc[j];  // valid in thread 0
@@ -102,15 +112,6 @@ void launch_refresh_derived(DevState* s, DevCfg cfg, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // per chain: VD factor (utils/util.py:446-485) and one _step_GMM (trainer.py:68-77)
 // ------------------------------------------------------------------------------------------------
-#ifdef IRS_SCALAR_TRACE
-__device__ unsigned long long g_scalar_trace[8];
-extern "C" int irs_debug_scalar_trace(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scalar_trace), sizeof(g_scalar_trace)) == hipSuccess ? 0 : 1;
-}
-#define IRS_ST(i) do { if (threadIdx.x == 0) g_scalar_trace[i] = wall_clock64(); } while (0)
-#else
-#define IRS_ST(i)
-#endif
 __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const double* __restrict__ partials,
                                                               int nblocks, int chain, int op, DevCfg cfg, Verdict vd) {
     __shared__ double smem[kStatVals * (kBlock / kWave)];

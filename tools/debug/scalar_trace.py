@@ -28,4 +28,6 @@ for it in range(6):
     buf = (C.c_ulonglong * 8)()
     assert fn(buf) == 0
     t = [buf[i] for i in range(6)]
+    if buf[6]:
+        print('   of the reduce phase: loads + adds %.2f us, block sum %.2f us' % ((buf[6] - t[1]) / 100, (t[2] - buf[6]) / 100))
     print('transition', it, ' '.join('%s %.2f us' % (n, (t[i + 1] - t[i]) / 100) for i, n in enumerate(['verdict', 'reduce', 'alpha', 'adam', 'write+refresh'])), ' total %.2f' % ((t[5] - t[0]) / 100))
