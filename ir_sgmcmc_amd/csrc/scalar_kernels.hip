@@ -40,6 +40,7 @@ __device__ void reduce_partials(const double* __restrict__ partials, int nblocks
             for (int j = 0; j < NV; ++j)
                 tmp[u][j] = (b < nblocks && j < nvals) ? (BY_COLUMN ? partials[(int64_t)j * nblocks + b] : partials[(int64_t)b * nvals + j]) : 0.0;
         }
+
 #pragma unroll
         for (int u = 0; u < kU; ++u)
             if (b0 + u * kBlock < nblocks) {
@@ -90,15 +91,27 @@ __device__ void refresh_derived(DevState* s, const DevCfg& cfg) {
 
 // optimizers/adam_rate_decay.py:32-99 for one scalar parameter (the state is never re-initialised on this path):
 // clr = lr / (1 + step * lr_decay); bias corrections count from step 0
-__device__ double adam_step_decay(double p, double g, double& m, double& v, int64_t step_before, double lr,
-                                  double lr_decay, double b1, double b2, double eps) {
-    const double clr = lr / (1.0 + (double)step_before * lr_decay);
+// the part that depends on the step count only: chain_scalar_kernel forms it while the partial sums are still on their way
+struct AdamCoef {
+    double clr, bc1, bc2;
+};
+__device__ __forceinline__ AdamCoef adam_coef(int64_t step_before, double lr, double lr_decay, double b1, double b2) {
+    AdamCoef a;
+    a.clr = lr / (1.0 + (double)step_before * lr_decay);
     const double t = (double)(step_before + 1);
-    const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+    a.bc1 = 1.0 - pow(b1, t);
+    a.bc2 = 1.0 - pow(b2, t);
+    return a;
+}
+__device__ __forceinline__ double adam_step_with(double p, double g, double& m, double& v, const AdamCoef& a, double b1, double b2, double eps) {
     m = b1 * m + (1.0 - b1) * g;
     v = b2 * v + (1.0 - b2) * g * g;
-    const double denom = sqrt(v) / sqrt(bc2) + eps;
-    return p - (clr / bc1) * m / denom;
+    const double denom = sqrt(v) / sqrt(a.bc2) + eps;
+    return p - (a.clr / a.bc1) * m / denom;
+}
+__device__ double adam_step_decay(double p, double g, double& m, double& v, int64_t step_before, double lr,
+                                  double lr_decay, double b1, double b2, double eps) {
+    return adam_step_with(p, g, m, v, adam_coef(step_before, lr, lr_decay, b1, b2), b1, b2, eps);
 }
 
 __global__ __launch_bounds__(kBlock) void refresh_kernel(DevState* s, DevCfg cfg) {
@@ -126,6 +139,15 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
     }
     __shared__ double rs[kStatVals];
     __shared__ double alpha_s;
+    // step-count part of the Adam update (two fp64 pow), one lane per parameter, BEFORE the reduction: it overlaps the memory
+    // round trips of the partial sums instead of following them (same expressions, same values)
+    // (computed before the reduction rather than after it: 19.0 -> 16.6 us; placed between the issue of the first loads and their
+    // use it gains nothing more -- the reduction is not waiting on memory)
+    AdamCoef coef = {0.0, 1.0, 1.0};
+    if (cfg.mode == IRS_DATA_GMM_LCC && (op & 2) && (int)threadIdx.x < 2 * cfg.K) {
+        const bool ls = (int)threadIdx.x < cfg.K;
+        coef = adam_coef(s->st.gmm_adam_step[ls ? 0 : 1], ls ? cfg.gmm_lr_log_std : cfg.gmm_lr_logits, cfg.gmm_lr_decay, cfg.beta1, cfg.beta2);
+    }
     double r[kStatVals];
     IRS_ST(1);
     reduce_partials<kStatVals, true>(partials, nblocks, kStatVals, r, smem);
@@ -169,12 +191,17 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
         const double n = rs[0], alpha = alpha_s;
         const double* Gs = rs + 5;
         const double* Gl = rs + 5 + IRS_MAX_COMPONENTS;
+        // gradient and parameter per lane, then ONE call of the update for both kinds (in two divergent branches the fp64 square
+        // roots and divisions of the update ran twice, one after the other)
+        double g_par, p_old;
+        double *mp, *vp;
         if (t < K) {
             const double sp2 = (double)cfg.scale_prior_scale * (double)cfg.scale_prior_scale;
             // d/dlog_std_k [alpha NLL - log N(log_std; loc, scale)]
-            const double g_ls = alpha * Gs[k] + ((double)old_ls[k] - (double)cfg.scale_prior_loc) / sp2;
-            newv = (float)adam_step_decay((double)old_ls[k], g_ls, s->st.gmm_adam_m[0][k], s->st.gmm_adam_v[0][k],
-                                          s->st.gmm_adam_step[0], cfg.gmm_lr_log_std, cfg.gmm_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
+            g_par = alpha * Gs[k] + ((double)old_ls[k] - (double)cfg.scale_prior_loc) / sp2;
+            p_old = (double)old_ls[k];
+            mp = &s->st.gmm_adam_m[0][k];
+            vp = &s->st.gmm_adam_v[0][k];
         } else {
             // proportions pi = softmax(logits + 1e-2)
             double mx = -1e300, sum = 0.0, csum = 0.0;
@@ -185,10 +212,12 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
             }
             const double pik = exp((double)old_lg[k] - mx) / sum;
             // d/dlogit_k [alpha NLL - log Dir(log pi)]
-            const double g_lg = alpha * (-Gl[k] + pik * n) + (-((double)cfg.conc[k] - 1.0) + pik * csum);
-            newv = (float)adam_step_decay((double)old_lg[k], g_lg, s->st.gmm_adam_m[1][k], s->st.gmm_adam_v[1][k],
-                                          s->st.gmm_adam_step[1], cfg.gmm_lr_logits, cfg.gmm_lr_decay, cfg.beta1, cfg.beta2, cfg.eps);
+            g_par = alpha * (-Gl[k] + pik * n) + (-((double)cfg.conc[k] - 1.0) + pik * csum);
+            p_old = (double)old_lg[k];
+            mp = &s->st.gmm_adam_m[1][k];
+            vp = &s->st.gmm_adam_v[1][k];
         }
+        newv = (float)adam_step_with(p_old, g_par, *mp, *vp, coef, cfg.beta1, cfg.beta2, cfg.eps);
     }
     __syncthreads();
     IRS_ST(4);
