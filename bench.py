@@ -278,12 +278,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.transition(fixed, moving, v)
+    # a transition dropped by a failed kernel-variant / ghost-width prediction is re-run by the library; the last two of a run only
+    # when asked: inside the timed region, so that the K steps timed are K VALID transitions whatever happened (normally a no-op)
+    eng.flush()
     sync()
     elapsed = par.max_over_ranks(time.perf_counter() - t0)
     assert bool(torch.isfinite(v).all()), 'chain diverged'
     if slab:
-        slab_status = eng.status()
-        assert slab_status['mispredictions'] == 0, slab_status
+        slab_status = eng.status()   # mispredictions are reported in the output line (`slab`), not fatal: the chain was repaired
 
     # ---- side measurements on rank 0 (outside the timed region) ------------------------------------------------------------
     extras = {}
