@@ -43,6 +43,7 @@ static Knobs knobs_from_env() {
     k.fwd_rows1 = env_or("IRS_FWD_ROWS1", k.fwd_rows1);
     k.coarse_box = env_or("IRS_COARSE_BOX", k.coarse_box);
     k.lds_from = env_or("IRS_LDS_FROM", k.lds_from);
+    k.seg_fit = env_or("IRS_SEG_FIT", k.seg_fit);
     k.fwd_pf = env_or("IRS_FWD_PF", k.fwd_pf);
     k.fwd_r2_rows1 = env_or("IRS_FWD_R2_ROWS1", k.fwd_r2_rows1);
     const char* tile = getenv("IRS_SOBOLEV_TILE");
@@ -75,7 +76,7 @@ int knob_set(Knobs& k, const char* name, int value) {
     static const Entry table[] = {
         {"predict_variants", &Knobs::predict_variants}, {"run_ahead", &Knobs::run_ahead}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd},
         {"energy_in_update", &Knobs::energy_in_update}, {"fuse_noise", &Knobs::fuse_noise},
-        {"recover", &Knobs::recover}, {"fwd_rows1", &Knobs::fwd_rows1}, {"coarse_box", &Knobs::coarse_box}, {"lds_from", &Knobs::lds_from}, {"fwd_pf", &Knobs::fwd_pf}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1}, {"sobolev_tile", &Knobs::sobolev_tile},
+        {"recover", &Knobs::recover}, {"fwd_rows1", &Knobs::fwd_rows1}, {"coarse_box", &Knobs::coarse_box}, {"lds_from", &Knobs::lds_from}, {"seg_fit", &Knobs::seg_fit}, {"fwd_pf", &Knobs::fwd_pf}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1}, {"sobolev_tile", &Knobs::sobolev_tile},
         {"march_seg", &Knobs::march_seg}, {"march_seg_fwd", &Knobs::march_seg_fwd}, {"swz_run", &Knobs::swz_run},
         {"seg_min_blocks", &Knobs::seg_min_blocks}, {"seg_min_len", &Knobs::seg_min_len}, {"sobolev_seg", &Knobs::sobolev_seg},
         {"lcc_seg", &Knobs::lcc_seg}, {"stats_seg", &Knobs::stats_seg}, {"update_seg", &Knobs::update_seg},

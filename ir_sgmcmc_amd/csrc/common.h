@@ -91,6 +91,7 @@ struct Knobs {
     int lds_from = 3;          // IRS_LDS_FROM          adjoint: smallest source halo (floor(max|d_k|) + 1) the any-radius kernel takes; 3 = radius-2 gather in front of it, 2 = not
     int fwd_r2_rows1 = 1;      // IRS_FWD_R2_ROWS1      radius-2 forward squaring step with one output row per thread (512 threads)
     int fwd_pf = 2;            // IRS_FWD_PF            one-row forward variant (small launches): planes of global loads in flight ahead of the commit (1 / 2)
+    int seg_fit = 1;           // IRS_SEG_FIT           squaring-step kernels: segment length from the resident-set cost model (0: power-of-two rule)
     int coarse_box = 1;        // IRS_COARSE_BOX        any-radius adjoint: source boxes from the coarse displacement extrema
     int sobolev_tile = 0;      // IRS_SOBOLEV_TILE      0: by size; 1: 32 x 16; 2: 64 x 32 ("small" / "big")
     int march_seg = 0, march_seg_fwd = 0, swz_run = -1, seg_min_blocks = 0, seg_min_len = 0;  // IRS_MARCH_SEG, _FWD, IRS_SWZ_RUN, IRS_SEG_MIN_*
@@ -113,6 +114,29 @@ inline int pick_seg_len(int nz, int64_t tiles_per_layer, int min_len, int forced
     int len = 32;
     while (len > min_len && tiles_per_layer * ((nz + len - 1) / len) < want) len >>= 1;
     return len < 1 ? 1 : len;
+}
+
+// Segment length from a cost model of the launch: workgroups run in rounds of `resident` (what the chip holds at once), a
+// workgroup marches seg_len + run_in planes, so a launch costs about ceil(blocks / resident) * (seg_len + run_in) plane steps.
+// The power-of-two rule above can land badly on sizes that are not powers of two: two chains at 192^3 are 1728 adjoint workgroups
+// of 34 plane steps on 1024 slots (two rounds, the second 70 % full) where 7 segments of 28 planes are 2016 workgroups of 30 steps
+// -- config 5 runs 454 -> 474 samples/s.  At 256^3, 128^3 and on a slab rank of eight the two rules agree or measure the same.
+inline int pick_seg_len_fit(int nz, int nzb, int64_t tiles_per_layer, int min_len, int run_in, int64_t resident, int forced) {
+    if (forced > 0) return forced;
+    const int longest = nz > nzb ? nz : nzb;
+    int best = 32;
+    int64_t best_cost = -1;
+    for (int len = 32; len >= min_len; --len) {
+        if (len > longest && len != 32) continue;
+        const int64_t nseg = (nz + len - 1) / len + (nzb + len - 1) / len;
+        const int64_t rounds = (tiles_per_layer * nseg + resident - 1) / resident;
+        const int64_t cost = rounds * ((len < longest ? len : longest) + run_in);
+        if (best_cost < 0 || cost < best_cost) {  // ties: the longer segment (less run-in traffic)
+            best_cost = cost;
+            best = len;
+        }
+    }
+    return best;
 }
 
 inline dim3 vox_grid(const Vol& vol, int planes) {

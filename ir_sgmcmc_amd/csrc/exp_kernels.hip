@@ -1107,11 +1107,30 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
 
 constexpr int kRareGrid = 512;  // persistent grid of the rarely selected variants (two workgroups per CU)
 
+// workgroups of `kernel` the chip holds at once (asked from the runtime once per kernel; 0 if it cannot be had)
+static int64_t resident_blocks(const void* kernel, int block, int* cache) {
+    if (*cache == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) == hipSuccess && per_cu > 0 && cus > 0)
+            *cache = per_cu * cus;
+        else
+            *cache = -1;
+    }
+    return *cache > 0 ? *cache : 0;
+}
+
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
                                hipEvent_t after_primary, hipStream_t st) {
     const int seg_env = global_knobs().march_seg;
-    const int seg_len = pick_seg_len(vol.nz + vol.nzb, (int64_t)((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * C, 8, seg_env);
+    const int64_t per_layer = (int64_t)((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * C;
+    int seg_len = pick_seg_len(vol.nz + vol.nzb, per_layer, 8, seg_env);
+    if (global_knobs().seg_fit && seg_env <= 0) {
+        static int cache = 0;
+        const int64_t res = resident_blocks((const void*)exp_bwd_march_kernel<false, 1>, kMarchBlock, &cache);
+        if (res > 0) seg_len = pick_seg_len_fit(vol.nz, vol.nzb, per_layer, 8, 2, res, 0);
+    }
     const int nseg = vol_nseg(vol, seg_len);  // segments of both windows
     const dim3 tiles((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
     const int total = (int)(tiles.x * tiles.y * tiles.z);
@@ -1444,7 +1463,18 @@ __global__ __launch_bounds__(FTX * FTY / FROWS, R == 1 ? IRS_FWD_WAVES : 1) void
 void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, int no_steps, int C, Vol vol, Lin lin,
                                const unsigned* dmax_in, unsigned* dmax_out, bool only_r1, int lay, hipStream_t st) {
     const int seg_env = global_knobs().march_seg_fwd;
-    const int seg_len = pick_seg_len(vol.nz + vol.nzb, (int64_t)((vol.W + FTX - 1) / FTX) * ((vol.H + FTY - 1) / FTY) * C, 8, seg_env);
+    const int64_t per_layer = (int64_t)((vol.W + FTX - 1) / FTX) * ((vol.H + FTY - 1) / FTY) * C;
+    int seg_len = pick_seg_len(vol.nz + vol.nzb, per_layer, 8, seg_env);
+    // small launches (at most two workgroups of tiles per CU under the power-of-two rule): the radius-1 kernel with one output row
+    // per thread
+    const int small_env = global_knobs().fwd_rows1;
+    const bool small = FROWS_BIG != 1 && (small_env >= 0 ? small_env != 0 : per_layer * vol_nseg(vol, seg_len) <= 640);
+    if (global_knobs().seg_fit && seg_env <= 0) {
+        static int cache_big = 0, cache_small = 0;
+        const int64_t res = small ? resident_blocks((const void*)exp_fwd_march_kernel<false, 1, 1, 2>, FTX * FTY, &cache_small)
+                                  : resident_blocks((const void*)exp_fwd_march_kernel<false, 1, FROWS_BIG, 1>, FTX * FTY / FROWS_BIG, &cache_big);
+        if (res > 0) seg_len = pick_seg_len_fit(vol.nz, vol.nzb, per_layer, 8, 2, res, 0);
+    }
     const int nseg = vol_nseg(vol, seg_len);  // segments of both windows
     const dim3 tiles((vol.W + FTX - 1) / FTX, (vol.H + FTY - 1) / FTY, (unsigned)(nseg * C));
     const int total = (int)(tiles.x * tiles.y * tiles.z);
@@ -1458,9 +1488,6 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     else IRS_FWS_(P, 1, LO, HI)
 #define IRS_FWS_(P, PFF, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 1, 1, PFF>), dim3(total), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run, tiles, lay)
     const int rare = total < kRareGrid ? total : kRareGrid;
-    // small launches (at most two workgroups of tiles per CU): the radius-1 kernel with one output row per thread
-    const int small_env = global_knobs().fwd_rows1;
-    const bool small = FROWS_BIG != 1 && (small_env >= 0 ? small_env != 0 : total <= 640);
     if (!dmax_in || only_r1) {  // no bound / predicted small: the radius-1 ring is correct for any displacement (far taps go to global memory)
         if (small) { if (prescale_in) IRS_FWS(true, -1, 1 << 30); else IRS_FWS(false, -1, 1 << 30); }
         else if (prescale_in) IRS_FWM(true, 1, -1, 1 << 30, total); else IRS_FWM(false, 1, -1, 1 << 30, total);
