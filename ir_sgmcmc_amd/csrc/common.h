@@ -139,6 +139,19 @@ inline int pick_seg_len_fit(int nz, int nzb, int64_t tiles_per_layer, int min_le
     return best;
 }
 
+// workgroups of `kernel` the chip holds at once (asked from the runtime once per kernel; 0 if it cannot be had)
+inline int64_t resident_blocks(const void* kernel, int block, int* cache) {
+    if (*cache == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) == hipSuccess && per_cu > 0 && cus > 0)
+            *cache = per_cu * cus;
+        else
+            *cache = -1;
+    }
+    return *cache > 0 ? *cache : 0;
+}
+
 inline dim3 vox_grid(const Vol& vol, int planes) {
     return dim3((unsigned)((vol.W + 63) / 64), (unsigned)((vol.H + 3) / 4), (unsigned)(vol.nz * planes));
 }

@@ -1107,18 +1107,6 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
 
 constexpr int kRareGrid = 512;  // persistent grid of the rarely selected variants (two workgroups per CU)
 
-// workgroups of `kernel` the chip holds at once (asked from the runtime once per kernel; 0 if it cannot be had)
-static int64_t resident_blocks(const void* kernel, int block, int* cache) {
-    if (*cache == 0) {
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) == hipSuccess && per_cu > 0 && cus > 0)
-            *cache = per_cu * cus;
-        else
-            *cache = -1;
-    }
-    return *cache > 0 ? *cache : 0;
-}
 
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,

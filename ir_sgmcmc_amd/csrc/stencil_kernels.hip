@@ -604,15 +604,28 @@ __global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __
 
 // the LCC kernels re-read 4S planes per segment; measured at 128^3: 8-plane segments (1.5x staging, 4x the workgroups)
 // still beat 16 and 32
-static int lcc_seg_len(Vol vol, int C) {
+template <int S, bool G>
+__global__ void lcc_data_bwd_march_kernel(const float*, const float*, const float*, const uint8_t*, const float*, const DevState*, int,
+                                          float*, double*, Vol, int, int);
+static int lcc_seg_len(Vol vol, int C, bool bwd) {
     const int seg_env = global_knobs().lcc_seg;
+    const int64_t per_layer = (int64_t)((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * C;
     // measured at 256^3: 2048 workgroups beat 1024; at 128^3: 4-plane segments beat 8 (data stage 0.144 -> 0.132 ms)
-    return pick_seg_len(vol.nz, (int64_t)((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * C, 4, seg_env, 2048);
+    int len = pick_seg_len(vol.nz, per_layer, 4, seg_env, 2048);
+    // ... and, with the resident-set cost model of the squaring steps (common.h: pick_seg_len_fit; run-in 4 S planes), per kernel:
+    // 192^3 data stage 0.267 -> 0.248 ms, 256^3 0.511 -> 0.496, 128^3 unchanged (the rule's 4-plane segments)
+    if (global_knobs().seg_fit && seg_env <= 0) {
+        static int cache_f = 0, cache_b = 0;
+        const int64_t res = bwd ? resident_blocks((const void*)lcc_data_bwd_march_kernel<1, false>, kStBlock, &cache_b)
+                                : resident_blocks((const void*)lcc_fwd_march_kernel<1, true>, kStBlock, &cache_f);
+        if (res > 0) len = pick_seg_len_fit(vol.nz, 0, per_layer, 4, 4, res, 0);
+    }
+    return len;
 }
 
 void launch_lcc_fwd_march(const float* fhat, int64_t fhat_stride, const float* im, float* z, float* sigma_out, int s, int C,
                           Vol vol, hipStream_t st) {
-    const int seg_len = lcc_seg_len(vol, C);
+    const int seg_len = lcc_seg_len(vol, C, false);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + LMX - 1) / LMX, (vol.H + LMY - 1) / LMY, (unsigned)(nseg * C));
     const bool map = fhat != nullptr;
@@ -864,14 +877,14 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
 }
 
 int lcc_data_bwd_march_blocks(Vol vol) {
-    const int seg_len = lcc_seg_len(vol, 1);
+    const int seg_len = lcc_seg_len(vol, 1, true);
     return ((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * ((vol.nz + seg_len - 1) / seg_len);
 }
 
 void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* sigma_m, const uint8_t* mask,
                                const float* g_z_override, const void* dev_state, int chain, float* g_warped,
                                double* nll_partials, int s, Vol vol, hipStream_t st) {
-    const int seg_len = lcc_seg_len(vol, 1);
+    const int seg_len = lcc_seg_len(vol, 1, true);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + LMX - 1) / LMX, (vol.H + LMY - 1) / LMY, (unsigned)nseg);
     const DevState* state = (const DevState*)dev_state;
