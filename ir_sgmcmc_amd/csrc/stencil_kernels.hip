@@ -161,8 +161,8 @@ __global__ __launch_bounds__(kStBlock) void sobolev_march_kernel(const float* __
 void launch_sobolev_march(const float* in, float* out, const Taps& taps, int planes, Vol vol, unsigned* dmax0, int no_steps,
                           hipStream_t st) {
     const int seg_env = global_knobs().sobolev_seg;
-    const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + 31) / 32) * ((vol.H + 15) / 16) * planes, 4, seg_env);
-    const int nseg = (vol.nz + seg_len - 1) / seg_len;
+    int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + 31) / 32) * ((vol.H + 15) / 16) * planes, 4, seg_env);
+    int nseg = (vol.nz + seg_len - 1) / seg_len;
     const float inv_pow = 1.0f / (float)(1 << no_steps);
     // big tiles (64 x 32, eight outputs per thread: 1.33x halo work in the z pass, a quarter of the barriers per output)
     // when they still fill the GPU, 32 x 16 otherwise
@@ -170,6 +170,15 @@ void launch_sobolev_march(const float* in, float* out, const Taps& taps, int pla
     const int force = global_knobs().sobolev_tile;  // 1 small / 2 big: used by the parity test of the two shapes
     const bool big = force ? force == 2 : big_blocks >= 512;
     const int tx = big ? 64 : 32, ty = big ? 32 : 16;
+    if (global_knobs().seg_fit && seg_env <= 0) {  // segment length for the chosen shape from the resident-set cost model (run-in 2 s planes)
+        static int cache_b = 0, cache_s = 0;
+        const int64_t res = big ? resident_blocks((const void*)sobolev_march_kernel<3, 64, 32>, kStBlock, &cache_b)
+                                : resident_blocks((const void*)sobolev_march_kernel<3, 32, 16>, kStBlock, &cache_s);
+        if (res > 0) {
+            seg_len = pick_seg_len_fit(vol.nz, 0, (int64_t)((vol.W + tx - 1) / tx) * ((vol.H + ty - 1) / ty) * planes, 4, 2 * taps.s, res, 0);
+            nseg = (vol.nz + seg_len - 1) / seg_len;
+        }
+    }
     const dim3 grid((vol.W + tx - 1) / tx, (vol.H + ty - 1) / ty, (unsigned)(nseg * planes));
 #define IRS_SOB(SS)                                                                                                        \
     if (big) hipLaunchKernelGGL((sobolev_march_kernel<SS, 64, 32>), grid, dim3(kStBlock), 0, st, in, out, taps, vol, dmax0, \
@@ -394,7 +403,12 @@ void launch_perturb_sobolev_march(const float* v, const float* sigma, const floa
                                   int C, Vol vol, unsigned* dmax0, int no_steps, uint64_t seed, uint64_t iteration,
                                   const uint64_t* dev_iteration, hipStream_t st) {
     const int ntx = (vol.W + PSX - 1) / PSX, nty = (vol.H + PSY - 1) / PSY;
-    const int seg_len = pick_seg_len(vol.nz, (int64_t)ntx * nty * C, 4, global_knobs().sobolev_seg, 512);
+    int seg_len = pick_seg_len(vol.nz, (int64_t)ntx * nty * C, 4, global_knobs().sobolev_seg, 512);
+    if (global_knobs().seg_fit && global_knobs().sobolev_seg <= 0) {
+        static int cache = 0;
+        const int64_t res = resident_blocks((const void*)perturb_sobolev_march_kernel<3, false, false>, kPsBlock, &cache);
+        if (res > 0) seg_len = pick_seg_len_fit(vol.nz, 0, (int64_t)ntx * nty * C, 4, 2 * taps.s, res, 0);
+    }
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const float inv_pow = 1.0f / (float)(1 << no_steps);
     const dim3 grid(ntx, nty, (unsigned)(nseg * C));
