@@ -1290,7 +1290,14 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
 
 static int update_seg_len(Vol vol, int C) {
     const int seg_env = global_knobs().update_seg;
-    return pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY) * C, 4, seg_env);
+    const int64_t per_layer = (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + QTY - 1) / QTY) * C;
+    int len = pick_seg_len(vol.nz, per_layer, 4, seg_env);
+    if (global_knobs().seg_fit && seg_env <= 0) {  // resident-set cost model (common.h), run-in 2 planes: 224^3 0.133 -> 0.125 ms
+        static int cache = 0;
+        const int64_t res = resident_blocks((const void*)sgld_update_march_kernel<false>, kStBlock, &cache);
+        if (res > 0) len = pick_seg_len_fit(vol.nz, 0, per_layer, 4, 2, res, 0);
+    }
+    return len;
 }
 
 int sgld_update_blocks_per_chain(Vol vol, int C) {
