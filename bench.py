@@ -185,6 +185,15 @@ def main():
     ap.add_argument('--decomp', choices=['slab', 'chains'], default='slab',
                     help='N > 1: ONE chain split into z-slabs with ghost-plane exchange over RCCL (strong scaling, default) or '
                          'independent chains per rank (weak scaling)')
+    ap.add_argument('--transport', choices=['auto', 'rccl', 'ipc', 'rehearsal'], default=None,
+                    help='slab mode: how ghost planes travel.  rccl: ncclSend / ncclRecv groups (csrc/comm.hip); ipc: peer-mapped landing '
+                         'buffers written by the producer, sequence flags (csrc/ipc.hip); auto (default on a node): bring up both, time a '
+                         'few transitions with each, keep the faster; rehearsal: Python callbacks with host staging (one-GPU tests only). '
+                         'IRS_BENCH_BACKEND=ipc|gloo in the environment selects ipc / rehearsal as well')
+    ap.add_argument('--allow-chain-fallback', action='store_true',
+                    help='slab mode: when no slab transport comes up, measure independent chains per rank instead ("scaling": "weak") '
+                         'and exit 0; without this flag that is an error (exit 3): a weak-scaling number must not pass for a point of the '
+                         'strong-scaling curve')
     ap.add_argument('--ghost-max', type=int, default=0, help='slab mode: widest ghost zone of one exchange (0 = library default)')
     ap.add_argument('--watchdog', type=int, default=420, help='N > 1: seconds after which a run that has not finished dumps its stacks and exits (0 = off)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -212,9 +221,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    # IRS_BENCH_DEVICE / IRS_BENCH_BACKEND exist only to rehearse the multi-rank path on a 1-GPU box (gloo, shared device)
+    # IRS_BENCH_DEVICE puts every rank on ONE device (a 1-GPU box): torch's own group then runs over gloo (RCCL refuses two
+    # ranks on a device) and the slab transport is ipc (asynchronous, the product transport) or the synchronous rehearsal one
+    shared_device = 'IRS_BENCH_DEVICE' in os.environ
     dev_index = int(os.environ.get('IRS_BENCH_DEVICE', local_rank))
-    backend = os.environ.get('IRS_BENCH_BACKEND', 'nccl')
+    env_backend = os.environ.get('IRS_BENCH_BACKEND', '')
+    transport = args.transport or {'ipc': 'ipc', 'gloo': 'rehearsal', 'rehearsal': 'rehearsal', 'nccl': 'rccl'}.get(env_backend, 'ipc' if shared_device else 'auto')
+    backend = 'gloo' if (shared_device or transport == 'rehearsal') else 'nccl'
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     if world > 1:
@@ -236,28 +249,80 @@ def main():
     f1, m1 = synthetic_pair(dims, seed=0)
     fixed = {k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'}
     moving = {k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'}
-    slab_status, slab_failure = None, None
+    slab_status, slab_failure, trials = None, None, {}
     if slab:
         from ir_sgmcmc_amd.slab import SlabComm, SlabEngine
-        # The library's own RCCL communicator + a verified all-reduce of each kind and ring exchange.  A transport that cannot
-        # be brought up (on ANY rank: the verdict is all-reduced) does not take the run down with it: the bench then measures
-        # the chain decomposition and SAYS SO in its output (`slab_transport_failure`, "scaling": "weak").
-        comm = None
-        try:
-            comm = SlabComm.rccl() if backend == 'nccl' else SlabComm.rehearsal(dev)
-            comm.selftest()
-        except Exception as e:  # noqa: BLE001
-            slab_failure = f'{type(e).__name__}: {e}'
-            print(f'[bench] rank {rank}: slab transport failed: {slab_failure}', file=sys.stderr, flush=True)
-        ok = torch.tensor([0 if slab_failure else 1], device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            slab, slab_failure = False, slab_failure or 'transport failed on another rank'
+
+        def agree(ok):  # a verdict every rank shares
+            t = torch.tensor([1 if ok else 0], device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        def bring_up(name):
+            """communicator + the library's self-test (all-reduces of each kind and neighbour exchanges of several sizes, checked
+            word by word) + a slab engine with the mixture initialised + a short trial; None when it fails on ANY rank"""
+            comm_, eng_, err = None, None, None
+            try:
+                comm_ = SlabComm.create(name, dev)
+                comm_.selftest()
+            except Exception as e:  # noqa: BLE001
+                err = f'{name}: {type(e).__name__}: {e}'
+            if not agree(err is None):
+                print(f'[bench] rank {rank}: slab transport {name} failed: {err or "on another rank"}', file=sys.stderr, flush=True)
+                return None, err or f'{name}: failed on another rank'
+            try:
+                eng_ = SlabEngine(engine_config(N, args.loss, 1234), dev, comm_, ghost_max=args.ghost_max)
+                f_l, m_l = eng_.prepare(fixed, moving)   # fixed image / mask cut to the held planes; the moving image stays whole
+                eng_.gmm_init(f_l, m_l)
+                v_l = eng_.local(initial_velocity(args.init, args.init_amp, N, dev))
+                for _ in range(3):
+                    eng_.transition(f_l, m_l, v_l)
+                eng_.flush()
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+                t0_ = time.perf_counter()
+                for _ in range(8):
+                    eng_.transition(f_l, m_l, v_l)
+                eng_.flush()
+                torch.cuda.synchronize(dev)
+                ms = par.max_over_ranks(time.perf_counter() - t0_) * 1e3 / 8
+            except Exception as e:  # noqa: BLE001
+                err = f'{name}: {type(e).__name__}: {e}'
+            if not agree(err is None):
+                print(f'[bench] rank {rank}: slab trial over {name} failed: {err or "on another rank"}', file=sys.stderr, flush=True)
+                return None, err or f'{name}: trial failed on another rank'
+            return (comm_, eng_, f_l, m_l, ms), None
+
+        # Every transport that comes up is verified and timed on a few transitions; the fastest carries the measurement.  One
+        # that cannot be brought up (on ANY rank) does not take the run down with it as long as another one works.
+        best, failures = None, []
+        for name in (['ipc', 'rccl'] if transport == 'auto' else [transport]):
+            got, err = bring_up(name)
+            if got is None:
+                failures.append(err)
+                continue
+            trials[name] = got[4]
+            if best is not None and got[4] >= best[1][4]:
+                loser, got = got, None
+            else:
+                loser, best = (best[1] if best is not None else None), (name, got)
+            if loser is not None:  # engine first (its streams drain), then its communicator (collective)
+                comm_l, eng_l = loser[0], loser[1]
+                eng_l.flush()
+                del loser, eng_l
+                torch.cuda.synchronize(dev)
+                comm_l.close()
+        if failures:
+            slab_failure = '; '.join(failures)
+        if best is None:
+            if not args.allow_chain_fallback:
+                print(f'[bench] rank {rank}: no slab transport came up ({slab_failure}); --allow-chain-fallback would measure '
+                      f'independent chains instead', file=sys.stderr, flush=True)
+                sys.exit(3)
+            slab = False
     if slab:
-        cfg = engine_config(N, args.loss, 1234)  # one chain: every rank draws the Philox noise of ITS planes of the same field
-        eng = SlabEngine(cfg, dev, comm, ghost_max=args.ghost_max)
-        fixed, moving = eng.prepare(fixed, moving)   # fixed image / mask cut to the held planes; the moving image stays whole
-        eng.gmm_init(fixed, moving)
+        transport, (comm, eng, fixed, moving, _) = best
+        cfg = eng.cfg
         v = eng.local(initial_velocity(args.init, args.init_amp, N, dev))
     else:
         cfg = engine_config(N, args.loss, par.chain_seed(1234))
@@ -351,7 +416,8 @@ def main():
         achieved = BWD_STEP_BYTES_PER_VOXEL * V / (bwd_kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = traffic_from_profile(N)
         if slab:
-            via = 'RCCL send/recv' if backend == 'nccl' else f'{backend} with host staging (one-GPU REHEARSAL of the schedule, not a measurement)'
+            via = {'rccl': 'RCCL send/recv', 'ipc': 'peer-mapped landing buffers (producer-side stores, sequence flags)' + (' -- all ranks on ONE device' if shared_device else ''),
+                   'rehearsal': 'gloo with host staging (one-GPU REHEARSAL of the schedule, not a measurement)'}[transport]
             para = f'1 chain in {world} z-slabs, ghost planes over {via}, {slab_status["last_fwd_rounds"]}+{slab_status["last_bwd_rounds"]} exchange rounds for 2x12 squaring steps'
         else:
             para = f'{world} independent chain(s)'
@@ -380,7 +446,7 @@ def main():
             out['slab_transport_failure'] = slab_failure
         if slab:
             st = slab_status
-            out['slab'] = {'planes_owned': eng.b - eng.a, 'planes_held': eng.hi - eng.lo, 'ghost_max': eng.ghost_max,
+            out['slab'] = {'transport': transport, 'transport_trials_ms': trials, 'planes_owned': eng.b - eng.a, 'planes_held': eng.hi - eng.lo, 'ghost_max': eng.ghost_max,
                            'exchange_rounds_per_transition': st['exchanges'] / max(st['transitions'], 1),
                            'MB_sent_per_transition_rank0': st['exchanged_bytes'] / max(st['transitions'], 1) / 1e6,
                            'exact_transitions': st['exact_transitions'], 'mispredictions': st['mispredictions']}

@@ -26,6 +26,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these are its only exports */
 
 #define IRS_MAX_COMPONENTS 8
 #define IRS_MAX_CHAINS 8
@@ -273,6 +274,16 @@ typedef struct irs_comm irs_comm;
 int irs_comm_unique_id(uint8_t id[IRS_COMM_ID_BYTES]);
 /* ncclCommInitRank on the CURRENT device; collective over the `world` ranks, blocking. */
 int irs_comm_create_rccl(const uint8_t id[IRS_COMM_ID_BYTES], int rank, int world, irs_comm** out);
+/* Peer-mapped transport: every rank exports ONE device allocation (its landing area for ghost planes and all-reduce
+ * contributions) with hipIpcGetMemHandle and maps its peers' (hipIpcOpenMemHandle); an exchange is a kernel of the PRODUCER storing
+ * its strips into the consumer's landing area (xGMI stores on a node), ordered across processes by sequence flags -- no host or
+ * stream synchronisation, no rendezvous.  `name` names a POSIX shared-memory segment through which the handles (and, by default,
+ * the flags) travel: the same string on every rank, distributed by the caller like the id above; rank 0 creates the segment and
+ * unlinks the name once every rank has attached.  Ranks may share a device (several processes on one GPU: how the asynchronous
+ * schedule is exercised on a one-GPU box) or own one each (world <= 8, one node).  Collective, blocking.  Environment:
+ * IRS_IPC_FLAGS=device keeps the flags in the landing areas instead of the host segment; IRS_IPC_TIMEOUT_S (20) bounds every wait
+ * of a kernel for a peer -- a rank that waits longer raises an error that the next irs_slab_transition / irs_flush returns. */
+int irs_comm_create_ipc(const char* name, int rank, int world, irs_comm** out);
 /* The same two transport operations as caller-supplied functions: rehearsal of the schedule with several ranks sharing ONE
  * GPU, which RCCL refuses (tests).  A callback must leave the data in place when it returns or enqueue its work on `stream`. */
 typedef struct irs_xfer {
@@ -369,6 +380,7 @@ int irs_option_set(irs_ctx* ctx, const char* name, int value);
 const char* irs_last_error(void);
 const char* irs_version(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

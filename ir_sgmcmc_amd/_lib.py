@@ -137,6 +137,7 @@ SIGNATURES = {
     'irs_transition_timed': [_P, C.POINTER(IrsIO), _P, C.POINTER(IrsTimings)],
     'irs_comm_unique_id': [C.POINTER(C.c_uint8 * IRS_COMM_ID_BYTES)],
     'irs_comm_create_rccl': [C.POINTER(C.c_uint8 * IRS_COMM_ID_BYTES), _I, _I, C.POINTER(_P)],
+    'irs_comm_create_ipc': [C.c_char_p, _I, _I, C.POINTER(_P)],
     'irs_comm_create_callbacks': [EXCHANGE_FN, ALLREDUCE_FN, _P, _I, _I, C.POINTER(_P)],
     'irs_comm_destroy': [_P],
     'irs_comm_rank': [_P],

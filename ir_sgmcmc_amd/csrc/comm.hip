@@ -5,6 +5,8 @@
 //               communication stream of slab.hip) -- xGMI point-to-point between the neighbouring GPUs of one node.  librccl
 //               is bound at RUN time (dlopen): the library an application already has in its process (PyTorch ships one) is
 //               reused, and a host without RCCL can still load this library for everything that is not multi-GPU.
+//   ipc         peer-mapped landing buffers written by the producer, sequence flags instead of a rendezvous (ipc.hip): xGMI stores
+//               on a node, and the one transport with which several ranks can share a device ASYNCHRONOUSLY.
 //   callbacks   the same two operations handed to caller-supplied functions.  Exists so that the slab schedule can be
 //               rehearsed with several ranks SHARING one GPU (RCCL refuses two ranks on one device); tests only.
 #include <dlfcn.h>
@@ -78,6 +80,7 @@ int comm_exchange(irs_comm* cm, const irs_xfer* x, int n, hipStream_t st) {
         if (cm->ex(cm->user, x, n, (void*)st)) return fail("exchange callback failed");
         return 0;
     }
+    if (cm->kind == 2) return ipc_exchange(cm, x, n, st);
     NCCL_TRY(g_rccl.GroupStart());
     for (int i = 0; i < n; ++i) {
         if (x[i].peer < 0 || x[i].peer >= cm->world || x[i].peer == cm->rank) {
@@ -102,11 +105,19 @@ int comm_allreduce(irs_comm* cm, void* buf, size_t count, int max_u32, hipStream
         if (cm->ar(cm->user, buf, count, max_u32, (void*)st)) return fail("all-reduce callback failed");
         return 0;
     }
+    if (cm->kind == 2) return ipc_allreduce(cm, buf, count, max_u32, st);
     if (max_u32 == 1) NCCL_TRY(g_rccl.AllReduce(buf, buf, count, ncclUint32, ncclMax, (ncclComm_t)cm->nccl, st));
     else if (max_u32 == 2) NCCL_TRY(g_rccl.AllReduce(buf, buf, count, ncclFloat32, ncclSum, (ncclComm_t)cm->nccl, st));
     else NCCL_TRY(g_rccl.AllReduce(buf, buf, count, ncclFloat64, ncclSum, (ncclComm_t)cm->nccl, st));
     return 0;
 }
+
+int comm_reserve(irs_comm* cm, size_t xbytes, size_t arbytes) {
+    if (!cm || cm->kind != 2 || cm->world == 1) return 0;
+    return ipc_reserve(cm, xbytes, arbytes);
+}
+
+int comm_check(irs_comm* cm) { return cm && cm->kind == 2 ? ipc_check(cm) : 0; }
 
 }  // namespace irs
 
@@ -155,8 +166,11 @@ int irs_comm_create_callbacks(irs_exchange_fn ex, irs_allreduce_fn ar, void* use
     return 0;
 }
 
+int irs_comm_create_ipc(const char* name, int rank, int world, irs_comm** out) { return ipc_create(name, rank, world, out); }
+
 void irs_comm_destroy(irs_comm* c) {
     if (!c) return;
+    if (c->kind == 2) ipc_destroy(c);
     if (c->kind == 0 && c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->nccl);
     delete c;
 }
@@ -164,60 +178,85 @@ void irs_comm_destroy(irs_comm* c) {
 int irs_comm_rank(const irs_comm* c) { return c ? c->rank : -1; }
 int irs_comm_world(const irs_comm* c) { return c ? c->world : -1; }
 
-// One all-reduce (SUM of doubles, MAX of uint32) and one grouped exchange with the ring neighbours on device scratch, checked
-// on the host: the first thing a multi-GPU run executes, so that a broken transport fails here and not as a wrong chain.
-// With one rank the exchange is skipped (RCCL has no self send in a group of one) and the all-reduce is the identity.  blocking.
+// All-reduces (SUM of doubles, MAX of uint32) and grouped exchanges with the slab neighbours (rank - 1 and rank + 1, a send and a
+// receive with each: the shape of every ghost-plane exchange) on device scratch, checked word by word on the host: the first thing
+// a multi-GPU run executes, so that a broken transport fails here and not as a wrong chain.  Several passes of different sizes
+// back to back with no synchronisation in between but the final one of each pass: warm caches, both landing slots of the
+// peer-mapped transport, its 16-byte and its 4-byte copy paths, one and many workgroups per run.  With one rank the exchange is
+// skipped and the all-reduce is the identity.  blocking.
 int irs_comm_selftest(irs_comm* c, void* stream) {
     if (!c) return fail("irs_comm_selftest: null communicator");
     hipStream_t st = (hipStream_t)stream;
-    const int n = 1024;
+    const int sizes[5] = {1024, 1001, 1 << 18, 333, 1024};  // doubles per message
+    const int nmax = 1 << 18;
+    if (comm_reserve(c, 2 * (size_t)nmax * sizeof(double), (size_t)nmax * sizeof(double))) return 1;
     char* dev = nullptr;
-    HIP_TRY(hipMalloc((void**)&dev, 4 * n * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&dev, 5 * (size_t)nmax * sizeof(double)));
     double* d = (double*)dev;
-    unsigned* u = (unsigned*)(d + n);
-    double* sendb = d + 2 * n;
-    double* recvb = d + 3 * n;
-    double hd[n];
-    unsigned hu[n];
-    for (int i = 0; i < n; ++i) {
-        hd[i] = (double)(c->rank + 1) * (i + 1);
-        hu[i] = (unsigned)(c->rank * 7 + i);
-    }
-    int rc = 0;
+    unsigned* u = (unsigned*)(d + nmax);
+    double* sendb = d + 2 * (size_t)nmax;
+    double* recv_lo = d + 3 * (size_t)nmax;
+    double* recv_hi = d + 4 * (size_t)nmax;
+    double* hd = (double*)malloc(3 * (size_t)nmax * sizeof(double));
+    unsigned* hu = (unsigned*)malloc((size_t)nmax * sizeof(unsigned));
     auto done = [&](int code) {
+        (void)hipStreamSynchronize(st);
         (void)hipFree(dev);
+        free(hd);
+        free(hu);
         return code;
     };
-    if (hipMemcpyAsync(d, hd, sizeof(hd), hipMemcpyHostToDevice, st) != hipSuccess) return done(fail("selftest: copy failed"));
-    (void)hipMemcpyAsync(u, hu, sizeof(hu), hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(sendb, hd, sizeof(hd), hipMemcpyHostToDevice, st);
-    (void)hipMemsetAsync(recvb, 0, sizeof(hd), st);
-    if (c->kind == 0) {  // through RCCL even with one rank (comm_allreduce short-cuts that case): the bound entry points get used
-        if (g_rccl.AllReduce(d, d, n, ncclFloat64, ncclSum, (ncclComm_t)c->nccl, st) != ncclSuccess ||
-            g_rccl.AllReduce(u, u, n, ncclUint32, ncclMax, (ncclComm_t)c->nccl, st) != ncclSuccess)
-            return done(fail("selftest: ncclAllReduce failed"));
-    } else {
-        rc |= comm_allreduce(c, d, n, 0, st);
-        rc |= comm_allreduce(c, u, n, 1, st);
-    }
-    if (c->world > 1) {  // ring: send to rank + 1, receive from rank - 1
-        irs_xfer x[2] = {{sendb, sizeof(hd), (c->rank + 1) % c->world, 0},
-                         {recvb, sizeof(hd), (c->rank + c->world - 1) % c->world, 1}};
-        rc |= comm_exchange(c, x, 2, st);
-    }
-    if (rc) return done(1);
-    double rd[n], rr[n];
-    unsigned ru[n];
-    (void)hipMemcpyAsync(rd, d, sizeof(rd), hipMemcpyDeviceToHost, st);
-    (void)hipMemcpyAsync(ru, u, sizeof(ru), hipMemcpyDeviceToHost, st);
-    (void)hipMemcpyAsync(rr, recvb, sizeof(rr), hipMemcpyDeviceToHost, st);
-    if (hipStreamSynchronize(st) != hipSuccess) return done(fail("selftest: stream failed"));
-    const double tri = 0.5 * c->world * (c->world + 1);
-    const int prev = (c->rank + c->world - 1) % c->world;
-    for (int i = 0; i < n; ++i) {
-        if (rd[i] != tri * (i + 1)) return done(fail("selftest: all-reduce SUM wrong at %d (%g, expected %g)", i, rd[i], tri * (i + 1)));
-        if (ru[i] != (unsigned)((c->world - 1) * 7 + i)) return done(fail("selftest: all-reduce MAX wrong at %d", i));
-        if (c->world > 1 && rr[i] != (double)(prev + 1) * (i + 1)) return done(fail("selftest: exchange wrong at %d", i));
+    if (!hd || !hu) return done(fail("selftest: out of host memory"));
+    double *rl = hd + nmax, *rh = hd + 2 * (size_t)nmax;
+    const bool has_hi = c->rank + 1 < c->world, has_lo = c->rank > 0;
+    for (int pass = 0; pass < 5; ++pass) {
+        const int n = sizes[pass];
+        const size_t nb = (size_t)n * sizeof(double);
+        for (int i = 0; i < n; ++i) {
+            hd[i] = (double)(c->rank + 1 + pass) * (i + 1);
+            hu[i] = (unsigned)(c->rank * 7 + i + pass);
+        }
+        if (hipMemcpyAsync(d, hd, nb, hipMemcpyHostToDevice, st) != hipSuccess) return done(fail("selftest: copy failed"));
+        (void)hipMemcpyAsync(u, hu, n * sizeof(unsigned), hipMemcpyHostToDevice, st);
+        (void)hipMemcpyAsync(sendb, hd, nb, hipMemcpyHostToDevice, st);
+        (void)hipMemsetAsync(recv_lo, 0, nb, st);
+        (void)hipMemsetAsync(recv_hi, 0, nb, st);
+        int rc = 0;
+        if (c->kind == 0) {  // through RCCL even with one rank (comm_allreduce short-cuts that case): the bound entry points get used
+            if (g_rccl.AllReduce(d, d, n, ncclFloat64, ncclSum, (ncclComm_t)c->nccl, st) != ncclSuccess ||
+                g_rccl.AllReduce(u, u, n, ncclUint32, ncclMax, (ncclComm_t)c->nccl, st) != ncclSuccess)
+                return done(fail("selftest: ncclAllReduce failed"));
+        } else {
+            rc |= comm_allreduce(c, d, n, 0, st);
+            rc |= comm_allreduce(c, u, n, 1, st);
+        }
+        if (c->world > 1) {  // the order of exchange_planes (slab.hip): the same on both sides of a link
+            irs_xfer x[4];
+            int m = 0;
+            if (has_hi) {
+                x[m++] = irs_xfer{sendb, nb, c->rank + 1, 0};
+                x[m++] = irs_xfer{recv_hi, nb, c->rank + 1, 1};
+            }
+            if (has_lo) {
+                x[m++] = irs_xfer{sendb, nb, c->rank - 1, 0};
+                x[m++] = irs_xfer{recv_lo, nb, c->rank - 1, 1};
+            }
+            rc |= comm_exchange(c, x, m, st);
+        }
+        if (rc) return done(1);
+        (void)hipMemcpyAsync(hd, d, nb, hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(hu, u, n * sizeof(unsigned), hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(rl, recv_lo, nb, hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(rh, recv_hi, nb, hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess) return done(fail("selftest: stream failed"));
+        if (comm_check(c)) return done(1);
+        const double tri = 0.5 * c->world * (c->world + 1) + (double)pass * c->world;
+        for (int i = 0; i < n; ++i) {
+            if (hd[i] != tri * (i + 1)) return done(fail("selftest pass %d: all-reduce SUM wrong at %d (%g, expected %g)", pass, i, hd[i], tri * (i + 1)));
+            if (hu[i] != (unsigned)((c->world - 1) * 7 + i + pass)) return done(fail("selftest pass %d: all-reduce MAX wrong at %d", pass, i));
+            if (has_lo && rl[i] != (double)(c->rank + pass) * (i + 1)) return done(fail("selftest pass %d: exchange with rank %d wrong at %d", pass, c->rank - 1, i));
+            if (has_hi && rh[i] != (double)(c->rank + 2 + pass) * (i + 1)) return done(fail("selftest pass %d: exchange with rank %d wrong at %d", pass, c->rank + 1, i));
+        }
     }
     return done(0);
 }

@@ -820,6 +820,19 @@ int irs_slab_create(const irs_config* cfg, const irs_slab_config* scfg, irs_comm
     irs_ctx* c = nullptr;
     if (create_ctx(cfg, &s, &c)) return 1;
     c->comm = comm;
+    if (comm && world > 1) {
+        // the peer-mapped transport sizes its landing area here (collective): the widest exchange is `margin` planes of a
+        // three-channel field per chain and side; the largest all-reduce is the control-grid gradient (SVFFD) or the bounds
+        const size_t xbytes = (size_t)3 * c->C * s.margin * c->vol.H * c->vol.W * sizeof(float);
+        size_t arbytes = sizeof(double) * (kStatVals > 2 * IRS_MAX_CHAINS ? kStatVals : 2 * IRS_MAX_CHAINS);
+        const size_t bounds = sizeof(unsigned) * 4 * c->C * (cfg->no_steps + 1);
+        arbytes = bounds > arbytes ? bounds : arbytes;
+        if (c->ffd && sizeof(float) * c->C * 3 * c->volv.V > arbytes) arbytes = sizeof(float) * c->C * 3 * c->volv.V;
+        if (comm_reserve(comm, xbytes, arbytes)) {
+            irs_destroy(c);
+            return 1;
+        }
+    }
     // the communication stream gets the HIGHEST priority: its send / recv kernels are enqueued while interior launches of a
     // thousand workgroups occupy every CU, and the overlap the schedule is built on needs them to be dispatched ahead of those
     int prio_least = 0, prio_greatest = 0;
@@ -962,6 +975,7 @@ int slab_flush(irs_ctx* c, hipStream_t st) {
     for (int guard = 0; guard < 8; ++guard) {
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipStreamSynchronize(c->cs));
+        if (comm_check(c->comm)) return 1;
         slab_poll(c, 0);  // everything enqueued has finished: both slots are final
         slab_poll(c, 1);
         if (!c->makeup) return 0;
@@ -991,6 +1005,7 @@ int irs_slab_transition(irs_ctx* c, const irs_io* io_in, void* stream) {
         // every rank reads the same count at the same call: all of them re-run it here, measuring instead of predicting.
         slab_poll(c, (int)(c->n_enqueued % 2));
     }
+    if (comm_check(c->comm)) return 1;
     if (c->makeup && !c->kn.recover)
         return fail("irs_slab_transition: a transition ran with ghost zones narrower than its displacement needed and was dropped (recover = 0)");
     while (c->makeup > 0) {

@@ -11,9 +11,10 @@ single-device loop body of the reference, trainer/trainer.py:291-356.
     v_l = eng.local(v)                           # (C, 3, hi - lo, H, W)
     eng.transition(fixed_l, moving, v_l)
 
+`SlabComm.ipc()` is the peer-mapped transport (landing buffers exported with hipIpcGetMemHandle, written by the producer,
+ordered by sequence flags): asynchronous like RCCL, and several ranks may share ONE GPU, which RCCL refuses.
 `SlabComm.rehearsal()` is the same schedule over a transport of Python callbacks (torch.distributed point-to-point with
-host staging): several ranks can then share ONE GPU, which RCCL refuses -- the tests' way of exercising the multi-rank
-path on a single-GPU box.
+host staging, synchronous): tests only.
 """
 import ctypes as C
 
@@ -54,6 +55,35 @@ class SlabComm:
         h = C.c_void_p()
         L.check(lib.irs_comm_create_rccl(C.byref(uid), rank, world, C.byref(h)))
         return cls(h, rank, world)
+
+    @classmethod
+    def ipc(cls, name=None):
+        """peer-mapped transport (csrc/ipc.hip): every rank exports a landing area with hipIpcGetMemHandle, producers store ghost
+        planes straight into their neighbours' (xGMI stores on a node), sequence flags order the processes -- no host or stream
+        synchronisation inside an exchange.  Ranks may share a device: the asynchronous schedule then runs for real on a one-GPU
+        box.  Rank 0 picks the name of the bootstrap segment, the initialised torch.distributed group (any backend) carries it."""
+        import os
+        lib = L.load()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [name or f'irs_ipc_{os.getpid()}_{int.from_bytes(os.urandom(4), "little"):08x}'] if rank == 0 else [None]
+        if dist.get_backend() == 'nccl':  # (object collectives of the nccl backend stage through the current device)
+            dist.broadcast_object_list(box, src=0, device=torch.device('cuda', torch.cuda.current_device()))
+        else:
+            dist.broadcast_object_list(box, src=0)
+        h = C.c_void_p()
+        L.check(lib.irs_comm_create_ipc(box[0].encode(), rank, world, C.byref(h)))
+        return cls(h, rank, world)
+
+    @classmethod
+    def create(cls, transport, device=None):
+        """by name: 'rccl' | 'ipc' | 'rehearsal'"""
+        if transport in ('rccl', 'nccl'):
+            return cls.rccl(device)
+        if transport == 'ipc':
+            return cls.ipc()
+        if transport == 'rehearsal':
+            return cls.rehearsal(device or torch.device('cuda', torch.cuda.current_device()))
+        raise L.IrsError(f'unknown slab transport {transport!r}')
 
     @classmethod
     def rehearsal(cls, device):

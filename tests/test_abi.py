@@ -28,6 +28,14 @@ def test_library_exports_every_declared_symbol():
     assert b'gfx950' in lib.irs_version()
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """-fvisibility=hidden + the version script csrc/exports.map: no internal C++ symbol leaves the library"""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert names and sorted(names) == _header_functions(), sorted(set(names) ^ set(_header_functions()))
+
+
 def test_struct_layouts_match_the_header():
     import ctypes as C
     # sizes computed by hand from the header (natural alignment)

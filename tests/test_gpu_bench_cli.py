@@ -1,7 +1,7 @@
 """bench.py as the driver runs it: the N = 1 line, and the N = 2 script path (spawn -> torch.distributed.run -> slab engine)
-rehearsed on ONE GPU over the gloo / host-staging transport, so that the first real multi-GPU SCALE run is not the script's
-first execution.  (The rehearsal exercises everything except RCCL itself: rank bring-up, the slab layout, the schedule, ghost
-exchanges, all-reduces, status read-back, the JSON contract, tear-down.)"""
+on ONE GPU over the peer-mapped `ipc` transport (asynchronous: what a node runs, minus xGMI) and over the synchronous gloo /
+host-staging rehearsal, so that the first real multi-GPU SCALE run is not the script's first execution; and the exit code
+when no slab transport comes up."""
 import json
 import os
 import subprocess
@@ -13,11 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(args, env_extra, timeout=420):
-    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID')}
-    env.update(env_extra)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    assert p.returncode == 0, f'rc {p.returncode}\n--- stdout\n{p.stdout[-2000:]}\n--- stderr\n{p.stderr[-4000:]}'
+XX
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, p.stdout[-2000:]   # exactly ONE JSON line
     return json.loads(lines[0])
@@ -32,12 +28,37 @@ def test_bench_one_gpu_line_contract():
     assert d['config']['volume'] == [64, 64, 64] and 'workload' in d['config']
 
 
+def test_bench_two_ranks_ipc():
+    """the N = 2 path over the PRODUCT transport that allows two ranks on one device: asynchronous exchanges, the library's own
+    communication stream and events -- what `bench.py --gpus 2` runs on a node, minus xGMI"""
+    d = _run(['--gpus', '2', '--size', '64', '--steps', '5', '--warmup', '2', '--no-cpu-baseline'], {'IRS_BENCH_DEVICE': '0'})
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['steps'] == 5
+    assert 'slab_transport_failure' not in d
+    s = d['slab']
+    assert s['transport'] == 'ipc' and 'ipc' in s['transport_trials_ms']
+    assert s['mispredictions'] == 0 and s['planes_owned'] == 32 and s['planes_held'] > 32
+    assert s['exchange_rounds_per_transition'] > 0 and d['value'] > 0
+    assert '2 z-slabs' in d['config']['parallelism'] and 'peer-mapped' in d['config']['parallelism']
+
+
+def test_bench_exits_non_zero_without_a_slab_transport():
+    """RCCL refuses two ranks on one device: with that the only transport asked for, the run must FAIL (a weak-scaling number must
+    not pass for a point of the strong-scaling curve); --allow-chain-fallback turns it into the chain decomposition, which says
+    so in its line"""
+    args = ['--gpus', '2', '--size', '32', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--transport', 'rccl']
+    p = _run(args, {'IRS_BENCH_DEVICE': '0'}, expect_rc=1)
+    assert 'no slab transport came up' in p.stderr
+    d = _run(args + ['--allow-chain-fallback'], {'IRS_BENCH_DEVICE': '0'})
+    assert d['scaling'] == 'weak' and 'slab_transport_failure' in d and 'slab' not in d
+
+
 def test_bench_two_ranks_rehearsal():
     d = _run(['--gpus', '2', '--size', '64', '--steps', '3', '--warmup', '2', '--no-cpu-baseline'],
              {'IRS_BENCH_BACKEND': 'gloo', 'IRS_BENCH_DEVICE': '0'})
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['steps'] == 3
     assert 'slab_transport_failure' not in d
     s = d['slab']
+    assert s['transport'] == 'rehearsal'
     assert s['mispredictions'] == 0 and s['planes_owned'] == 32 and s['planes_held'] > 32
     assert s['exchange_rounds_per_transition'] > 0 and d['value'] > 0
     assert '2 z-slabs' in d['config']['parallelism']

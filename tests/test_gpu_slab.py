@@ -3,9 +3,12 @@ single-GPU transition.
 
 1 rank      the slab context over the whole volume == irs_transition.
 2 / 3 ranks processes SHARING cuda:0 run the library's schedule -- slab-local arrays, ghost-plane exchanges in rounds,
-            interior / boundary split, all-reduces -- over the rehearsal transport (callbacks carried by gloo with host
-            staging; RCCL refuses two ranks on one device).  On a multi-GPU node the only thing that changes is the leaf
-            that moves the bytes (csrc/comm.hip).  The assembled result must match the single-engine transition.
+            interior / boundary split, all-reduces -- over BOTH transports that allow several ranks on one device (RCCL
+            refuses that): `ipc`, the peer-mapped product transport (csrc/ipc.hip: landing buffers exported with
+            hipIpcGetMemHandle, producer-side stores, sequence flags; nothing synchronises a stream or the host inside an
+            exchange, so the hipStreamWaitEvent plumbing between the compute and the communication stream runs for real,
+            with the ranks drifting against each other), and `rehearsal` (callbacks carried by gloo with host staging,
+            synchronous).  The assembled result must match the single-engine transition.
 BASELINE.json config 4 (256^3, SSD, z-slabs) runs at its own size on two ranks."""
 import os
 import socket
@@ -95,13 +98,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max, cps=None, transitions=T):
+def _worker(rank, world, port, q, transport, data_loss, C, N, vd, amp, reg, ghost_max, cps=None, transitions=T):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from ir_sgmcmc_amd.slab import SlabComm
         torch.cuda.set_device(0)
-        comm = SlabComm.rehearsal(DEV)
+        comm = SlabComm.create(transport, DEV)
         comm.selftest()
         D = N if isinstance(N, int) else N[0]
         cfg, fixed, moving, v0, noise = _setup(N, C, data_loss, vd=vd, amp=amp, reg=reg, with_noise=D < 128, cps=cps, transitions=transitions)
@@ -118,6 +121,9 @@ def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max, cps=
             ds = max(abs(a[k][c] - b[k][c]) / max(abs(b[k][c]), 1e-30) for a, b in zip(s, s_ref)
                      for k in ('alpha', 'data_term', 'reg_term') for c in range(C))
             q.put((dv, dd, ds, st))
+        dist.barrier()
+        del eng
+        comm.close()  # (collective for the peer-mapped transport: a landing area is freed when nobody maps it any more)
     except BaseException:  # leave at once: the peers then fail on their next message instead of waiting for this rank
         import traceback
         traceback.print_exc()
@@ -126,11 +132,11 @@ def _worker(rank, world, port, q, data_loss, C, N, vd, amp, reg, ghost_max, cps=
     dist.destroy_process_group()
 
 
-def _launch(world, *args):
+def _launch(world, *args, transport='rehearsal'):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q) + args) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, transport) + args) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -142,16 +148,20 @@ def _launch(world, *args):
     return q.get(timeout=10)
 
 
+TRANSPORTS = ['rehearsal', 'ipc']
+
+
+@pytest.mark.parametrize('transport', TRANSPORTS)
 @pytest.mark.parametrize('data_loss,C,N,world,ghost_max,amp', [
     ('GMM', 1, 32, 2, 4, 9.0), ('SSD', 2, 24, 2, 2, 9.0), ('GMM', 1, 48, 3, 4, 9.0), ('SSD', 1, 40, 2, 1, 9.0),
     ('GMM', 1, 30, 3, 6, 12.0),   # thin slabs (10 planes) under a displacement of several voxels: late steps are all boundary, no interior
     ('GMM', 1, (38, 21, 45), 2, 4, 9.0),   # D != H != W, none a multiple of a tile edge: ragged tiles inside slab windows
     ('GMM', 2, 28, 2, 4, 9.0),             # two chains: the mixture's statistics are all-reduced and stepped per chain, serially
 ])
-def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max, amp):
-    dv, dd, ds, st = _launch(world, data_loss, C, N, True, amp, 'RegLoss_LogNormal', ghost_max)
+def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max, amp, transport):
+    dv, dd, ds, st = _launch(world, data_loss, C, N, True, amp, 'RegLoss_LogNormal', ghost_max, transport=transport)
     from tests._report import check
-    name = f'slab/{data_loss}_C{C}_N{N if isinstance(N, int) else "x".join(map(str, N))}_ranks{world}_g{ghost_max}_amp{amp:g}'
+    name = f'slab_{transport}/{data_loss}_C{C}_N{N if isinstance(N, int) else "x".join(map(str, N))}_ranks{world}_g{ghost_max}_amp{amp:g}'
     check(name, 'v_new (rel to max)', dv, 0.0, 1e-5)
     check(name, 'displacement [voxels]', dd, 0.0, 1e-5)
     check(name, 'loss terms (rel)', ds, 0.0, 1e-6)
@@ -159,47 +169,51 @@ def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max, amp
     assert st['last_fwd_rounds'] < 12 or ghost_max == 1, st
 
 
-def test_slab_long_run_replans_every_transition():
+@pytest.mark.parametrize('transport', TRANSPORTS)
+def test_slab_long_run_replans_every_transition(transport):
     """40 consecutive transitions on two ranks: after the first (measuring) transition every plan comes from the bounds of
     two transitions earlier, while the field keeps moving (lr 0.4, Langevin noise on); no misprediction, no second exact
     transition, and the chain stays on the fused engine's trajectory."""
-    dv, dd, ds, st = _launch(2, 'GMM', 1, 32, True, 4.0, 'RegLoss_LogNormal', 4, None, 40)
+    dv, dd, ds, st = _launch(2, 'GMM', 1, 32, True, 4.0, 'RegLoss_LogNormal', 4, None, 40, transport=transport)
     from tests._report import check
-    name = 'slab/GMM_C1_N32_ranks2_g4_40_transitions'
+    name = f'slab_{transport}/GMM_C1_N32_ranks2_g4_40_transitions'
     check(name, 'v_new (rel to max)', dv, 0.0, 1e-4)
     check(name, 'displacement [voxels]', dd, 0.0, 1e-4)
     check(name, 'loss terms (rel)', ds, 0.0, 1e-5)
 
 
+@pytest.mark.parametrize('transport', TRANSPORTS)
 @pytest.mark.parametrize('data_loss,C,N,world,cps', [('GMM', 1, 32, 2, (4, 4, 4)), ('SSD', 2, 36, 3, (2, 2, 2))])
-def test_slab_svffd(data_loss, C, N, world, cps):
+def test_slab_svffd(data_loss, C, N, world, cps, transport):
     """SVFFD_3D (utils/transformation.py:126-164; the experiment5 configs): control grid whole on every rank, dense velocity
     up-sampled per slab, control-grid gradient all-reduced"""
-    dv, dd, ds, st = _launch(world, data_loss, C, N, True, 20.0, 'RegLoss_LogNormal', 4, cps)
+    dv, dd, ds, st = _launch(world, data_loss, C, N, True, 20.0, 'RegLoss_LogNormal', 4, cps, transport=transport)
     from tests._report import check
-    name = f'slab/svffd{cps[0]}_{data_loss}_C{C}_N{N}_ranks{world}'
+    name = f'slab_{transport}/svffd{cps[0]}_{data_loss}_C{C}_N{N}_ranks{world}'
     check(name, 'v_new (rel to max)', dv, 0.0, 1e-5)
     check(name, 'displacement [voxels]', dd, 0.0, 1e-5)
     check(name, 'loss terms (rel)', ds, 0.0, 1e-6)
 
 
-def test_config4_256_cubed_ssd_two_slabs():
+@pytest.mark.parametrize('transport', TRANSPORTS)
+def test_config4_256_cubed_ssd_two_slabs(transport):
     """BASELINE.json config 4 at its own size: 256^3, SSD + RegLoss_L2, one chain in two z-slabs vs the fused engine."""
-    dv, dd, ds, st = _launch(2, 'SSD', 1, 256, False, 3.0, 'RegLoss_L2', 4)
+    dv, dd, ds, st = _launch(2, 'SSD', 1, 256, False, 3.0, 'RegLoss_L2', 4, transport=transport)
     from tests._report import check
-    check('slab/config4_256_ssd_ranks2', 'v_new (rel to max)', dv, 0.0, 1e-5)
-    check('slab/config4_256_ssd_ranks2', 'displacement [voxels]', dd, 0.0, 2e-5)
-    check('slab/config4_256_ssd_ranks2', 'loss terms (rel)', ds, 0.0, 1e-6)
+    check(f'slab_{transport}/config4_256_ssd_ranks2', 'v_new (rel to max)', dv, 0.0, 1e-5)
+    check(f'slab_{transport}/config4_256_ssd_ranks2', 'displacement [voxels]', dd, 0.0, 2e-5)
+    check(f'slab_{transport}/config4_256_ssd_ranks2', 'loss terms (rel)', ds, 0.0, 1e-6)
 
 
-def test_bench_workload_256_cubed_gmm_four_slabs():
+@pytest.mark.parametrize('transport', TRANSPORTS)
+def test_bench_workload_256_cubed_gmm_four_slabs(transport):
     """The workload bench.py times (256^3, GMM / LCC with virtual decimation, RegLoss_L2, in-kernel noise) as one chain in FOUR
     z-slabs of 64 planes (middle ranks with two neighbours, ghost exchanges in both directions) vs the fused engine."""
-    dv, dd, ds, st = _launch(4, 'GMM', 1, 256, True, 3.0, 'RegLoss_L2', 4)
+    dv, dd, ds, st = _launch(4, 'GMM', 1, 256, True, 3.0, 'RegLoss_L2', 4, transport=transport)
     from tests._report import check
-    check('slab/bench_256_gmm_ranks4', 'v_new (rel to max)', dv, 0.0, 1e-5)
-    check('slab/bench_256_gmm_ranks4', 'displacement [voxels]', dd, 0.0, 2e-5)
-    check('slab/bench_256_gmm_ranks4', 'loss terms (rel)', ds, 0.0, 1e-6)
+    check(f'slab_{transport}/bench_256_gmm_ranks4', 'v_new (rel to max)', dv, 0.0, 1e-5)
+    check(f'slab_{transport}/bench_256_gmm_ranks4', 'displacement [voxels]', dd, 0.0, 2e-5)
+    check(f'slab_{transport}/bench_256_gmm_ranks4', 'loss terms (rel)', ds, 0.0, 1e-6)
 
 
 def test_rccl_transport_single_rank():
