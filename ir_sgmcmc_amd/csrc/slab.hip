@@ -312,10 +312,9 @@ struct Sched {
             *energy_ar = -1;
             launch(noise ? IRS_SG_PERTURB : IRS_SG_COPY_V, 0, volv, -1, -1, 0, -1);
             launch(IRS_SG_SMOOTH, 0, volv, -1, -1, 0, -1);
-            if (energy) {
-                launch(IRS_SG_ENERGY, 0, volv, -1, -1, 0, -1);
-                launch(IRS_SG_REG_SCALAR, 0, volv, -1, -1, 0, -1);
-            }
+            // (the regulariser's scalar stage steps hyper-parameters: it runs behind the verdict about this transition's plan, in
+            // backward_and_update -- here the all-reduced bounds it is judged by do not exist yet)
+            if (energy) launch(IRS_SG_ENERGY, 0, volv, -1, -1, 0, -1);
             launch(IRS_SG_FFD_UP, 0, W(e0), -1, -1, 0, IRS_SB_DENSE);
             return;
         }
@@ -391,6 +390,9 @@ struct Sched {
             }
             launch(IRS_SG_DATA_BWD, ch, W(0), IRS_SB_Z, -1, 2 * ls, IRS_SB_GM);
         }
+        // SVFFD: the energy is whole on every rank (head); its scalar stage -- an Adam step on the regulariser's parameters -- must
+        // see the verdict, which the stages above have waited for: a dropped transition then leaves them alone
+        if (ffd) launch(IRS_SG_REG_SCALAR, 0, volv, -1, -1, 0, -1);
         const int nll_ar = allreduce(IRS_AR_NLL);
         launch(IRS_SG_WARP_BWD, 0, W(0), IRS_SB_GM, step_buf_id(n - 1), 0, IRS_SB_GRAD_A);
         for (int r = 0; r < p.nb; ++r) {

@@ -13,7 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-XX
+def _run(args, env_extra, timeout=420, expect_rc=0):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID')}
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    if expect_rc:
+        assert p.returncode != 0, f'expected a failure\n--- stdout\n{p.stdout[-2000:]}\n--- stderr\n{p.stderr[-2000:]}'
+        return p
+    assert p.returncode == 0, f'rc {p.returncode}\n--- stdout\n{p.stdout[-2000:]}\n--- stderr\n{p.stderr[-4000:]}'
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, p.stdout[-2000:]   # exactly ONE JSON line
     return json.loads(lines[0])

@@ -237,13 +237,16 @@ def test_rccl_transport_single_rank():
         dist.destroy_process_group()
 
 
-def test_misprediction_is_recovered():
+@pytest.mark.parametrize('cps,amp', [(None, 20.0), ((4, 4, 4), 60.0)])
+def test_misprediction_is_recovered(cps, amp):
     """A plan with ghost zones narrower than the displacement needs (forced here) must neither pass silently nor end the chain:
     the device-side verdict (all-reduced bounds against the planned widths) turns the transition into a no-op on every rank,
     the count of such transitions reaches the host two calls later -- at the same call on every rank -- and the transition is
-    re-run in measuring mode.  The chain equals the one that measured its ghost widths all along."""
+    re-run in measuring mode.  The chain equals the one that measured its ghost widths all along -- the velocity AND the
+    learnable regulariser's parameters and Adam moments (SVFFD_3D: its scalar stage used to run ahead of the verdict and stepped
+    them on the dropped transition as well)."""
     from ir_sgmcmc_amd.slab import SlabEngine
-    cfg, fixed, moving, v0, noise = _setup(24, 1, 'GMM', amp=20.0, with_noise=False)  # several voxels of displacement
+    cfg, fixed, moving, v0, noise = _setup(24, 1, 'GMM', amp=amp, with_noise=False, cps=cps)  # several voxels of displacement
     res = {}
     for forced in (0, 1):
         eng = SlabEngine(cfg, DEV)
@@ -263,7 +266,11 @@ def test_misprediction_is_recovered():
             eng.transition(fd, md, v)              # the verdicts arrive here; the dropped transitions are re-run, measuring
         eng.flush()
         st = eng.status()
-        res[forced] = (v.clone(), eng.state().iteration, st['mispredictions'])
+        state = eng.state()
+        res[forced] = (v.clone(), state.iteration, st['mispredictions'],
+                       (list(state.reg_param), list(state.reg_adam_m), list(state.reg_adam_v), list(state.reg_adam_step),
+                        list(state.gmm_log_std), list(state.gmm_logits)))
     assert res[0][1] == res[1][1] == 6
     assert res[0][2] == 0 and res[1][2] >= 1
+    assert res[0][3] == res[1][3]
     assert torch.equal(res[0][0], res[1][0])
