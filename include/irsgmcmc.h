@@ -211,7 +211,13 @@ int irs_gmm_init(irs_ctx* ctx, const irs_io* io, const float* v_sample, int warm
  * the previous one -- the kernel-variant prediction reads bounds no older than that).  Under stream capture that wait is
  * skipped, so the call stays graph-capturable.  Which variants of the squaring-step kernels get launched is predicted from
  * the displacement bounds of earlier transitions; the device checks the prediction, and a transition that was launched
- * without a variant it turned out to need leaves everything untouched and is re-run by a later call (irs_flush). */
+ * without a variant it turned out to need leaves everything untouched and is re-run by a later call (irs_flush).
+ * Consequences for a caller that reads per-call results: the output arrays of irs_io (and grad_v, and the timings of
+ * irs_transition_timed) belong to transition t only once irs_flush has returned -- until then a dropped transition leaves them
+ * holding an earlier sample.  A re-run draws the in-kernel Philox noise of the transition it repeats (the counter did not
+ * advance), but INJECTED eps / unif are taken from the irs_io of the call that performs the re-run: parity runs with injected
+ * noise set predict_variants = 0.  Under stream capture no prediction is made and nothing is re-run (the captured sequence
+ * launches every variant), so a replayed graph never depends on host state. */
 int irs_transition(irs_ctx* ctx, const irs_io* io, void* stream);
 
 /* Wait for everything enqueued on `stream` and complete the chain: a transition whose kernel-variant (or, on a slab, ghost-width)

@@ -68,23 +68,41 @@ Knobs& global_knobs() {
     return k;
 }
 
-int knob_set(Knobs& k, const char* name, int value) {
+static int g_live_contexts = 0;  // contexts alive in this process (a context is not thread-safe, and neither is this count)
+void context_born() { ++g_live_contexts; }
+void context_gone() { --g_live_contexts; }
+
+// Scope of a switch.  CTX: copied into a context at creation and read from there (`irs_option_set(ctx, ...)` changes that copy,
+// `irs_option_set(NULL, ...)` the default of contexts created later -- and the stateless operators).  GLOBAL: the launchers read
+// the process-wide value at every launch; naming a context for it is an error (it used to be accepted and ignored).  LAYOUT:
+// GLOBAL, and the value also sizes the per-block partial sums a context lays out when it is created (irs_ctx::nll_blocks ...):
+// changing it while a context is alive would make launches disagree with that layout, so it is refused then.
+enum { KN_CTX = 0, KN_GLOBAL = 1, KN_LAYOUT = 2 };
+
+int knob_set(Knobs& k, const char* name, int value, bool on_context) {
     struct Entry {
         const char* name;
         int Knobs::*field;
+        int scope;
     };
     static const Entry table[] = {
-        {"predict_variants", &Knobs::predict_variants}, {"run_ahead", &Knobs::run_ahead}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd},
-        {"energy_in_update", &Knobs::energy_in_update}, {"fuse_noise", &Knobs::fuse_noise},
-        {"recover", &Knobs::recover}, {"fwd_rows1", &Knobs::fwd_rows1}, {"coarse_box", &Knobs::coarse_box}, {"lds_from", &Knobs::lds_from}, {"seg_fit", &Knobs::seg_fit}, {"fwd_pf", &Knobs::fwd_pf}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1}, {"sobolev_tile", &Knobs::sobolev_tile},
-        {"march_seg", &Knobs::march_seg}, {"march_seg_fwd", &Knobs::march_seg_fwd}, {"swz_run", &Knobs::swz_run},
-        {"seg_min_blocks", &Knobs::seg_min_blocks}, {"seg_min_len", &Knobs::seg_min_len}, {"sobolev_seg", &Knobs::sobolev_seg},
-        {"lcc_seg", &Knobs::lcc_seg}, {"stats_seg", &Knobs::stats_seg}, {"update_seg", &Knobs::update_seg},
-        {"slab_split", &Knobs::slab_split}, {"slab_exact", &Knobs::slab_exact}, {"slab_force_h", &Knobs::slab_force_h},
+        {"predict_variants", &Knobs::predict_variants, KN_CTX}, {"run_ahead", &Knobs::run_ahead, KN_CTX}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd, KN_CTX},
+        {"energy_in_update", &Knobs::energy_in_update, KN_CTX}, {"fuse_noise", &Knobs::fuse_noise, KN_CTX}, {"recover", &Knobs::recover, KN_CTX},
+        {"slab_split", &Knobs::slab_split, KN_CTX}, {"slab_exact", &Knobs::slab_exact, KN_CTX}, {"slab_force_h", &Knobs::slab_force_h, KN_CTX},
+        {"fwd_rows1", &Knobs::fwd_rows1, KN_GLOBAL}, {"coarse_box", &Knobs::coarse_box, KN_GLOBAL}, {"lds_from", &Knobs::lds_from, KN_GLOBAL},
+        {"fwd_pf", &Knobs::fwd_pf, KN_GLOBAL}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1, KN_GLOBAL}, {"sobolev_tile", &Knobs::sobolev_tile, KN_GLOBAL},
+        {"march_seg", &Knobs::march_seg, KN_GLOBAL}, {"march_seg_fwd", &Knobs::march_seg_fwd, KN_GLOBAL}, {"swz_run", &Knobs::swz_run, KN_GLOBAL},
+        {"sobolev_seg", &Knobs::sobolev_seg, KN_GLOBAL},
+        {"seg_fit", &Knobs::seg_fit, KN_LAYOUT}, {"seg_min_blocks", &Knobs::seg_min_blocks, KN_LAYOUT}, {"seg_min_len", &Knobs::seg_min_len, KN_LAYOUT},
+        {"lcc_seg", &Knobs::lcc_seg, KN_LAYOUT}, {"stats_seg", &Knobs::stats_seg, KN_LAYOUT}, {"update_seg", &Knobs::update_seg, KN_LAYOUT},
     };
     if (!name) return fail("irs_option_set: null name");
     for (const Entry& e : table)
         if (!strcmp(e.name, name)) {
+            if (on_context && e.scope != KN_CTX)
+                return fail("irs_option_set: '%s' is a process-wide switch (the launchers read it at every launch): set it with ctx == NULL", name);
+            if (!on_context && e.scope == KN_LAYOUT && g_live_contexts > 0 && k.*(e.field) != value)
+                return fail("irs_option_set: '%s' sizes the partial-sum layout of a context at creation; %d context(s) are alive -- set it before irs_create", name, g_live_contexts);
             k.*(e.field) = value;
             return 0;
         }
@@ -126,7 +144,7 @@ const char* irs_last_error(void) { return irs::g_err; }
 const char* irs_version(void) { return "ir-sgmcmc-amd 0.1 (gfx950)"; }
 size_t irs_reduce_scratch_doubles(void) { return (size_t)kMaxPartialBlocks * IRS_MAX_CHAINS; }
 
-int irs_option_set(irs_ctx* ctx, const char* name, int value) { return knob_set(ctx ? ctx->kn : global_knobs(), name, value); }
+int irs_option_set(irs_ctx* ctx, const char* name, int value) { return knob_set(ctx ? ctx->kn : global_knobs(), name, value, ctx != nullptr); }
 
 // ================================================================================================
 // stateless operators
@@ -459,6 +477,7 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     irs_ctx* c = new (std::nothrow) irs_ctx();
     if (!c) return fail("irs_create: out of host memory");
     memset((void*)c, 0, sizeof(*c));
+    context_born();
     c->kn = global_knobs();
     c->cfg = *cfg;
     c->C = C;
@@ -472,6 +491,7 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
                      : c->vol;
     if (cfg->sobolev_s > 0 && (2 * cfg->sobolev_s >= c->volv.D || 2 * cfg->sobolev_s >= c->volv.H || 2 * cfg->sobolev_s >= c->volv.W)) {
         delete c;
+        context_gone();
         return fail("irs_create: velocity grid smaller than the Sobolev kernel");
     }
     c->sob.s = cfg->sobolev_s;
@@ -536,6 +556,7 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     c->slab_bytes = off;
     if (hipMalloc((void**)&c->slab, off) != hipSuccess) {
         delete c;
+        context_gone();
         return fail("irs_create: hipMalloc of %zu workspace bytes failed", off);
     }
     if (c->sl.on) (void)hipMemset(c->slab, 0, off);  // ghost planes nobody has written yet must hold finite values
@@ -564,6 +585,7 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     if (ensure_lin_tables(c->lin, D, H, W, nullptr)) {
         (void)hipFree(c->slab);
         delete c;
+        context_gone();
         return fail("irs_create: identity grid allocation failed");
     }
     // initial hyper-parameters as the reference constructors set them (model/loss.py:49-50,191-192,298-303)
@@ -589,6 +611,7 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     if (e != hipSuccess) {
         (void)hipFree(c->slab);
         delete c;
+        context_gone();
         return fail("irs_create: state initialisation failed: %s", hipGetErrorString(e));
     }
     *out = c;
@@ -613,6 +636,7 @@ void irs_destroy(irs_ctx* c) {
     if (c->hint) (void)hipHostFree(c->hint);
     if (c->slab) (void)hipFree(c->slab);
     delete c;
+    context_gone();
 }
 
 size_t irs_workspace_bytes(const irs_ctx* c) { return c ? c->slab_bytes : 0; }
@@ -651,8 +675,15 @@ int irs_get_state(irs_ctx* c, irs_state* out, void* stream) {
     return 0;
 }
 
+static void drop_pending(irs_ctx* c);
+
 int irs_set_state(irs_ctx* c, const irs_state* in, void* stream) {
     if (!c || !in) return fail("irs_set_state: null argument");
+    // The chain is being replaced (resume, hand-over from the VI stage): transitions of the OLD chain that were dropped by a
+    // failed prediction and not re-run yet must not be re-run on the restored one.  Wait, take note of the count, forget them.
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (c->sl.on) irs::slab_drop_pending(c);
+    else drop_pending(c);
     HIP_TRY(hipMemcpyAsync(&c->state->st, in, sizeof(irs_state), hipMemcpyHostToDevice, (hipStream_t)stream));
     launch_refresh_derived(c->state, c->dcfg, (hipStream_t)stream);
     LAUNCH_CHECK();
@@ -799,7 +830,7 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
     vd.n = cfg.no_steps;
     vd.C = C;
     for (int k = 0; k < cfg.no_steps && k < 32; ++k) {
-        skip_any[k] = predicted_below(c, k, c->kn.lds_from <= 2 ? 0.75f : 1.5f);
+        skip_any[k] = predicted_below(c, k, global_knobs().lds_from <= 2 ? 0.75f : 1.5f);
         skip_r2[k] = skip_any[k] && predicted_tiny(c, k);
         if (skip_r2[k]) vd.need_lt1 |= 1u << k;
     }
@@ -863,7 +894,7 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
             // timed mode: the end event of step k closes right after the radius-1 kernel, so that exp_bwd_kernel_ms is the time
             // of the dominant kernel alone (as rocprofv3 reports it), not of the idle variants after it
             // lds_from 2: the any-radius kernel, when launched, takes every step beyond the radius-1 gather (no radius-2 gather then)
-            const int gr = c->kn.lds_from <= 2 ? 1 : 2;
+            const int gr = global_knobs().lds_from <= 2 ? 1 : 2;
             launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, (s2 || (gr == 1 && !sa)) ? 1 : 2, sa, gscale, lay,
                                       timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
             if (!sa) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, gr, gscale, lay, c->cmm, st);
@@ -901,7 +932,7 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
 static void poll_failures(irs_ctx* c) {
     if (!c->hint) return;
     const unsigned f = ((volatile unsigned*)c->hint)[kHintWords - 7];
-    if (f == c->fails_seen) return;
+    if (f == c->fails_seen || (int)(f - c->fails_seen) < 0) return;  // (a count that went backwards is not 4e9 failures)
     c->makeup += (uint64_t)(f - c->fails_seen);
     c->fails_total += (uint64_t)(f - c->fails_seen);
     c->fails_seen = f;
@@ -909,9 +940,21 @@ static void poll_failures(irs_ctx* c) {
     c->force_all_until = c->n_enqueued + c->makeup + 3;
 }
 
+static void drop_pending(irs_ctx* c) {
+    poll_failures(c);
+    c->makeup = 0;
+}
+
 static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int timed) {
     if (check_io(c, io, "irs_transition")) return 1;
     if (!io->v) return fail("irs_transition: v is required");
+    {
+        // Under stream capture the launch sequence becomes a graph that is replayed without this host code: no prediction may be
+        // baked into it (a replay whose verdict failed would stay a no-op on every replay) and no pending re-run belongs in it.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) return enqueue_transition(c, io, st, 0, true);
+    }
     // Bounded run-ahead: the host may be at most IRS_RUN_AHEAD (default 2) transitions ahead of the device.  The variant
     // prediction reads bounds the device published at the end of an earlier transition; a host that has queued twenty
     // transitions would predict from a state twenty transitions old, and while the displacement is still growing (burn-in)

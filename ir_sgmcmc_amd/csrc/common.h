@@ -101,7 +101,7 @@ struct Knobs {
     int slab_force_h = 0;      // IRS_SLAB_FORCE_H      test hook: a deliberately wrong ghost-width plan
 };
 Knobs& global_knobs();                                   // api.hip; initialised from the environment on first use
-int knob_set(Knobs& k, const char* name, int value);     // 0 on success
+int knob_set(Knobs& k, const char* name, int value, bool on_context);  // 0 on success (api.hip: scopes)
 
 // Segment length of the z-marching kernels.  32 planes amortise the run-in of a segment (2R .. 4S extra planes) when the
 // launch still has enough workgroups to fill 256 CUs; smaller volumes trade run-in overhead for parallelism, down to

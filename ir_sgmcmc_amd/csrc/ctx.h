@@ -149,6 +149,7 @@ int create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out);
 int check_io(const irs_ctx* c, const irs_io* io, const char* who);
 void slab_release(irs_ctx* c);  // slab.hip
 int slab_flush(irs_ctx* c, hipStream_t st);  // slab.hip
+void slab_drop_pending(irs_ctx* c);          // slab.hip
 // cubic B-spline FFD up-sampling / adjoint over the three axes (api.hip); the window arguments are for slab-local dense arrays
 int ffd_up(const float* v_cp, float* dense, float* tmp, int C, Vol vol, const int G[3], const SplineTaps spl[3], hipStream_t st,
            int w_lo = 0, int w_n = -1, int store_lo = 0, int store_n = -1);

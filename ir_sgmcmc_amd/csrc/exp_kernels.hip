@@ -451,8 +451,9 @@ __global__ __launch_bounds__(kExpBlock, H == 0 ? 4 : 2) void exp_bwd_lds_kernel(
     // ahead of its scatter.
     const int ex = max(hi[0] - lo[0] + 1, 0), ey = max(hi[1] - lo[1] + 1, 0), ez = max(hi[2] - lo[2] + 1, 0);
     const unsigned exy = (unsigned)(ex * ey), nsrc = exy * (unsigned)ez;
-    // idx / exy and rem / ex by multiply-high with m = floor(2^32 / d) + 1: exact while idx * d < 2^32
-    const bool magic_ok = exy > 0 && (unsigned long long)nsrc * exy < (1ull << 32);
+    // idx / exy and rem / ex by multiply-high with m = floor(2^32 / d) + 1: exact while idx * d < 2^32 -- and for d >= 2: with
+    // d == 1 the multiplier wraps to 0 (a clipped edge tile whose box is one column wide: plain division then)
+    const bool magic_ok = ex > 1 && exy > 1 && (unsigned long long)nsrc * exy < (1ull << 32);
     const unsigned m_xy = magic_ok ? 0xFFFFFFFFu / exy + 1u : 0u, m_x = magic_ok ? 0xFFFFFFFFu / (unsigned)ex + 1u : 0u;
     const int nitems = (int)((nsrc + kWave - 1) / kWave);
     constexpr int kWaves = kExpBlock / kWave, kPipe = 2;

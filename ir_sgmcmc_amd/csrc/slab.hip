@@ -973,6 +973,12 @@ void slab_poll(irs_ctx* c, int slot) {
 }  // namespace
 
 namespace irs {
+void slab_drop_pending(irs_ctx* c) {  // irs_set_state: the chain is being replaced, dropped transitions of the old one are not re-run
+    if (c->cs) (void)hipStreamSynchronize(c->cs);
+    slab_poll(c, 0);
+    slab_poll(c, 1);
+    c->makeup = 0;
+}
 int slab_flush(irs_ctx* c, hipStream_t st) {
     for (int guard = 0; guard < 8; ++guard) {
         HIP_TRY(hipStreamSynchronize(st));

@@ -305,6 +305,10 @@ class Trainer(VIMixin, BaseTrainer):
                     self.metrics.update(f'MCMC/chain_{idx}/VD/alpha', aux['alpha'][idx].item())
                     self.metrics.update(f'MCMC/chain_{idx}/reg/energy', aux['reg_energy'][idx].item())
             if sample_no > self.no_iters_burn_in and (sample_no % self.log_period_MCMC == 0 or sample_no == self.no_samples_MCMC):
+                # The outputs of a call are only those of sample `sample_no` once nothing is pending: a transition dropped by a failed
+                # kernel-variant prediction is re-run by a LATER call, and until then the output buffers hold an earlier sample
+                # (one sync per log_period; normally a no-op)
+                self.engine.flush()
                 transformation, displacement = output['transformation'], output['displacement']
                 no_folds, log_det_J = calc_no_non_diffeomorphic_voxels(transformation, self.diff_op)
                 if 'seg' in moving and 'seg' in fixed and self.structures_dict:
