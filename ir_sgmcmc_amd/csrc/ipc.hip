@@ -12,13 +12,13 @@
 //               landing area instead: polled locally, written by the peer).
 //   exchange    push kernel: packs this rank's strips into slot (seq & 1) of each neighbour's landing area; when its last
 //               workgroup has drained its stores (system-scope release) it stores `seq` into the neighbours' flags.
-//               drain kernel: polls its own flag until `seq` has arrived (bounded: a timeout raises an error word), system-scope
-//               acquire, unpacks the landing slot into the ghost planes.  Two slots suffice without credits because every
+//               wait kernel (ONE wavefront): polls this rank's flags until `seq` has arrived (bounded: a timeout raises an error
+//               word); drain kernel behind it: unpacks the landing slot into the ghost planes.  Two slots suffice without credits because every
 //               exchange is symmetric on a link: a rank's push of seq + 2 follows its own drain of seq + 1, which waited for the
 //               neighbour's push of seq + 1, which that neighbour enqueued behind ITS drain of seq (checked: comm_exchange
 //               refuses an asymmetric list for this transport).
 //   all-reduce  push kernel: this rank's contribution into slot [seq & 1][rank] of EVERY rank's landing area (its own too), then
-//               the flags; reduce kernel: waits for all contributions, combines them IN RANK ORDER (every rank obtains the same
+//               the flags; wait kernel, then the reduce kernel: combines the contributions IN RANK ORDER (every rank obtains the same
 //               bits) and writes the result in place.  An all-reduce is a barrier, so two slots suffice here as well.
 #include <errno.h>
 #include <fcntl.h>
@@ -132,7 +132,6 @@ struct Run {
     const char* src;
     char* dst;
     uint64_t bytes;
-    const unsigned* wait;  // drain: the flag that announces this run's bytes (null: nothing to wait for)
 };
 struct Runs {
     int n;
@@ -207,14 +206,23 @@ __global__ void __launch_bounds__(256) ipc_push_kernel(Runs runs, Signals sig, u
     publish(done, gridDim.x * gridDim.y, sig, seq);
 }
 
-__global__ void __launch_bounds__(256) ipc_drain_kernel(Runs runs, unsigned seq, unsigned long long timeout, unsigned* err, unsigned code) {
+// Waiting is ONE wavefront's business: a kernel of its own in front of the consumer, so that what spins while a peer is late is
+// 64 lanes with a handful of registers -- not the consumer's whole grid parked on every CU, taking registers and wave slots from
+// the interior launches the wait is supposed to overlap with.  The consumer kernel then starts behind it in stream order (its
+// kernel-start acquire sees what the producer released before it raised the flag).
+struct Waits {
+    int n;
+    const unsigned* flag[kMaxWorld];
+};
+__global__ void __launch_bounds__(64) ipc_wait_kernel(Waits w, unsigned seq, unsigned long long timeout, unsigned* err, unsigned code) {
+    for (int i = 0; i < w.n; ++i)  // one lane per flag, all polling at once (uniform index: the pointers stay scalar)
+        if ((int)threadIdx.x == i) wait_flag(w.flag[i], seq, timeout, err, code | (unsigned)i);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ void __launch_bounds__(256) ipc_drain_kernel(Runs runs) {
     const Run r = runs.r[blockIdx.y];
-    if (threadIdx.x == 0 && r.wait) {
-        wait_flag(r.wait, seq, timeout, err, code);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
     copy_bytes(r.src, r.dst, r.bytes, blockIdx.x, gridDim.x);
 }
 
@@ -227,19 +235,8 @@ __global__ void __launch_bounds__(256) ipc_ar_push_kernel(const char* buf, uint6
     publish(done, gridDim.x * gridDim.y, sig, seq);
 }
 
-struct ArSrc {
-    const unsigned* flag[kMaxWorld];  // my flags, one per contributing rank (null: my own contribution -- same stream, nothing to wait for)
-};
-// kind 0: SUM of doubles, 1: MAX of uint32, 2: SUM of floats; contributions combined in rank order
-__global__ void __launch_bounds__(256) ipc_ar_reduce_kernel(void* buf, uint64_t count, int kind, const char* slot, uint64_t stride, int world,
-                                                            ArSrc from, unsigned seq, unsigned long long timeout, unsigned* err, unsigned code) {
-    for (int r = 0; r < world; ++r)  // one lane per contributing rank, all polling at once (uniform index: the flag pointers stay scalar)
-        if ((int)threadIdx.x == r && from.flag[r]) wait_flag(from.flag[r], seq, timeout, err, code | (unsigned)r);
-    if (threadIdx.x < 64) {  // the polling lanes sit in the first wavefront
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
+// kind 0: SUM of doubles, 1: MAX of uint32, 2: SUM of floats; contributions combined in rank order (launched behind ipc_wait_kernel)
+__global__ void __launch_bounds__(256) ipc_ar_reduce_kernel(void* buf, uint64_t count, int kind, const char* slot, uint64_t stride, int world) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
         if (kind == 0) {
             double a = ((const double*)slot)[i];
@@ -315,11 +312,8 @@ int ipc_reserve(irs_comm* cm, size_t xbytes, size_t arbytes) {
     if (e != hipSuccess) return give_up(s, fail("ipc_reserve: hipMalloc of %zu bytes failed: %s", s->land_bytes, hipGetErrorString(e)));
     HIP_TRY(hipMemset(s->land, 0, kLandHeader));
     if (s->dev_flags) {  // the flags restart in the new area: at the sequence numbers every rank has reached
-        ShmFlags init;
-        memset(&init, 0, sizeof(init));
-        for (int i = 0; i < 2; ++i) init.x[i].v = s->xseq;
-        for (int i = 0; i < kMaxWorld; ++i) init.ar[i].v = s->arseq;
-        HIP_TRY(hipMemcpy(s->land, &init, sizeof(init), hipMemcpyHostToDevice));
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipMemsetD32((hipDeviceptr_t)(s->land + xflag_off(i)), (int)s->xseq, 1));
+        for (int i = 0; i < kMaxWorld; ++i) HIP_TRY(hipMemsetD32((hipDeviceptr_t)(s->land + arflag_off(i)), (int)s->arseq, 1));
     }
     HIP_TRY(hipDeviceSynchronize());
     ShmRank& me = s->shm->rank[s->rank];
@@ -359,6 +353,8 @@ int ipc_exchange(irs_comm* cm, const irs_xfer* x, int n, hipStream_t st) {
     push.n = drain.n = 0;
     Signals sig;
     sig.n = 0;
+    Waits wt;
+    wt.n = 0;
     // my neighbours: side 0 = the lower one (rank - 1), side 1 = the upper one.  At the UPPER neighbour I am its lower side (0).
     for (int side = 0; side < 2; ++side) {
         const int peer = side == 0 ? s->rank - 1 : s->rank + 1;
@@ -371,20 +367,23 @@ int ipc_exchange(irs_comm* cm, const irs_xfer* x, int n, hipStream_t st) {
             if (!x[i].recv) {
                 if (push.n >= kMaxRuns) return fail("ipc exchange: too many sends");
                 if (so + x[i].bytes > s->peer_x_slot[peer]) return fail("ipc exchange: %zu bytes for a landing slot of %llu (rank %d)", so + x[i].bytes, (unsigned long long)s->peer_x_slot[peer], peer);
-                push.r[push.n++] = Run{(const char*)x[i].ptr, s->peer[peer] + x_off(s->peer_x_slot[peer], slot, 1 - side) + so, x[i].bytes, nullptr};
+                push.r[push.n++] = Run{(const char*)x[i].ptr, s->peer[peer] + x_off(s->peer_x_slot[peer], slot, 1 - side) + so, x[i].bytes};
                 so += align16(x[i].bytes);
                 ++ns;
             } else {
                 if (drain.n >= kMaxRuns) return fail("ipc exchange: too many receives");
                 if (ro + x[i].bytes > s->x_slot) return fail("ipc exchange: %zu bytes from a landing slot of %zu", ro + x[i].bytes, s->x_slot);
-                drain.r[drain.n++] = Run{s->land + x_off(s->x_slot, slot, side) + ro, (char*)x[i].ptr, x[i].bytes, flag_ptr(s, s->rank, xflag_off(side))};
+                drain.r[drain.n++] = Run{s->land + x_off(s->x_slot, slot, side) + ro, (char*)x[i].ptr, x[i].bytes};
                 ro += align16(x[i].bytes);
                 ++nr;
             }
         }
         // two landing slots need no credits only while every exchange is symmetric on a link (header of this file)
         if (ns != nr || so != ro) return fail("ipc exchange: %d sends (%zu bytes) but %d receives (%zu bytes) with rank %d: this transport carries symmetric neighbour exchanges", ns, so, nr, ro, peer);
-        if (ns) sig.flag[sig.n++] = flag_ptr(s, peer, xflag_off(1 - side));
+        if (ns) {
+            sig.flag[sig.n++] = flag_ptr(s, peer, xflag_off(1 - side));
+            wt.flag[wt.n++] = flag_ptr(s, s->rank, xflag_off(side));
+        }
     }
     for (int i = 0; i < n; ++i)
         if (x[i].peer != s->rank - 1 && x[i].peer != s->rank + 1) return fail("ipc exchange: rank %d is not a neighbour of rank %d", x[i].peer, s->rank);
@@ -393,7 +392,8 @@ int ipc_exchange(irs_comm* cm, const irs_xfer* x, int n, hipStream_t st) {
     for (int i = 0; i < push.n; ++i) most = push.r[i].bytes > most ? push.r[i].bytes : most;
     const unsigned parts = parts_for(most);
     hipLaunchKernelGGL(ipc_push_kernel, dim3(parts, push.n), dim3(256), 0, st, push, sig, seq, done_ptr(s, 0));
-    hipLaunchKernelGGL(ipc_drain_kernel, dim3(parts, drain.n), dim3(256), 0, st, drain, seq, s->timeout_ticks, s->err_dev, (1u << 28) | ((seq & 0xffffffu) << 4));
+    hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, st, wt, seq, s->timeout_ticks, s->err_dev, (1u << 28) | ((seq & 0xffffffu) << 4));
+    hipLaunchKernelGGL(ipc_drain_kernel, dim3(parts, drain.n), dim3(256), 0, st, drain);
     LAUNCH_CHECK();
     ++s->exchanges;
     return 0;
@@ -409,27 +409,24 @@ int ipc_allreduce(irs_comm* cm, void* buf, size_t count, int kind, hipStream_t s
     const uint32_t seq = ++s->arseq;
     const int slot = (int)(seq & 1u);
     ArDst to;
-    ArSrc from;
+    Waits wt;
     Signals sig;
-    sig.n = 0;
-    for (int r = 0; r < kMaxWorld; ++r) {
-        to.dst[r] = nullptr;
-        from.flag[r] = nullptr;
-    }
+    sig.n = wt.n = 0;
+    for (int r = 0; r < kMaxWorld; ++r) to.dst[r] = nullptr;
     for (int r = 0; r < s->world; ++r) {
         to.dst[r] = s->peer[r] + ar_off(s->peer_x_slot[r], s->peer_ar_slot[r], s->world, slot, s->rank);
         if (r == s->rank) continue;
         sig.flag[sig.n++] = flag_ptr(s, r, arflag_off(s->rank));
-        from.flag[r] = flag_ptr(s, s->rank, arflag_off(r));
+        wt.flag[wt.n++] = flag_ptr(s, s->rank, arflag_off(r));
     }
     const unsigned parts = parts_for(bytes);
     hipLaunchKernelGGL(ipc_ar_push_kernel, dim3(parts, s->world), dim3(256), 0, st, (const char*)buf, (uint64_t)bytes, to, sig, seq, done_ptr(s, 1));
     const uint64_t per_block = 256 * 8;
     unsigned blocks = (unsigned)((count + per_block - 1) / per_block);
     blocks = blocks < 1 ? 1 : (blocks > 128 ? 128 : blocks);
+    hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, st, wt, seq, s->timeout_ticks, s->err_dev, (2u << 28) | ((seq & 0xffffffu) << 4));
     hipLaunchKernelGGL(ipc_ar_reduce_kernel, dim3(blocks), dim3(256), 0, st, buf, (uint64_t)count, kind,
-                       (const char*)(s->land + ar_off(s->x_slot, s->ar_slot, s->world, slot, 0)), (uint64_t)s->ar_slot, s->world, from, seq,
-                       s->timeout_ticks, s->err_dev, (2u << 28) | ((seq & 0xffffffu) << 4));
+                       (const char*)(s->land + ar_off(s->x_slot, s->ar_slot, s->world, slot, 0)), (uint64_t)s->ar_slot, s->world);
     LAUNCH_CHECK();
     ++s->allreduces;
     return 0;

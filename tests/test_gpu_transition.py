@@ -333,11 +333,12 @@ def test_variant_prediction_never_changes_the_result(amp):
             eng.transition(fd, md, v, eps=eps, outputs=out)
         torch.cuda.synchronize()
         res[mode] = (v.clone(), out['grad_v'].clone(), out['displacement'].clone())
+    # Every variant is deterministic and the device selects per step from the same bounds whatever was launched, so the modes run
+    # IDENTICAL kernels on every step (a variant that was launched and not selected exits at once): bit-equal, not "close"
+    # (tools/debug/variant_bits.py prints the comparison per mode and amplitude).
     for mode in (1, 2):
-        assert float((res[mode][2] - res[0][2]).abs().max()) < 1e-5                       # displacement [voxels]
-        scale = float(res[0][1].abs().max())
-        assert float((res[mode][1] - res[0][1]).abs().max()) < 1e-4 * scale                # gradient (summation order only)
-        assert float((res[mode][0] - res[0][0]).abs().max()) < 1e-5 * float(res[0][0].abs().max())
+        for i, what in enumerate(('v', 'grad_v', 'displacement')):
+            assert torch.equal(res[mode][i], res[0][i]), (mode, what, float((res[mode][i] - res[0][i]).abs().max()))
 
 
 def test_misprediction_is_recovered_not_fatal():
