@@ -18,8 +18,8 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the adjoi
 bytes per launch (36 B/voxel: read dL/dd_{k+1} 12 + read d_k 12 + write dL/dd_k 12) over its average duration measured
 with HIP events on the launch stream inside `irs_transition_timed`.  `cpu_baseline` times the CPU oracle (torch, all
 host cores) on a bounded sample and is a reported baseline, not a target.  `also` carries what a registration costs away
-from the headline's best case (N = 1 only): the SSD loss of config 4, a chain started from a displaced field, 128^3 with its
-own roofline fraction, and a sustained run of >= 500 transitions.
+from the headline's best case (N = 1 only): the SSD loss of config 4, a chain started from a displaced field, a chain with a
+sigma-field preconditioner (pSGLD, MCMC_init 'VI'), 128^3 with its own roofline fraction, and a sustained run of >= 500 transitions.
 """
 import argparse
 import json
@@ -134,8 +134,9 @@ def workload_name(N, loss):
             + ', RegLoss_L2 w=1.4, Sobolev s=3, uniform noise 0.1, SGLD lr 0.4, Philox noise')
 
 
-def side_run(N, loss, init, amp, steps, warmup, dev, timed_reps=0, chains=1):
-    """one fused single-GPU workload outside the headline: ms per transition (+ the per-stage events when asked)"""
+def side_run(N, loss, init, amp, steps, warmup, dev, timed_reps=0, chains=1, sigma=None):
+    """one fused single-GPU workload outside the headline: ms per transition (+ the per-stage events when asked); `sigma`: the value
+    of a preconditioner FIELD (a chain started from the VI posterior, MCMC_init 'VI' -- 14 of the reference's 16 configs)"""
     import torch
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from ir_sgmcmc_amd.engine import TransitionEngine
@@ -145,12 +146,14 @@ def side_run(N, loss, init, amp, steps, warmup, dev, timed_reps=0, chains=1):
                                 {k: v.unsqueeze(0).to(dev) for k, v in m1.items() if k != 'seg'})
     eng.gmm_init(fixed, moving)
     v = initial_velocity(init, amp, N, dev).expand(chains, 3, N, N, N).contiguous()
+    sig = torch.full_like(v, float(sigma)) if sigma is not None else None
     for _ in range(warmup):
-        eng.transition(fixed, moving, v)
+        eng.transition(fixed, moving, v, sig)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
-        eng.transition(fixed, moving, v)
+        eng.transition(fixed, moving, v, sig)
+    eng.flush()
     torch.cuda.synchronize(dev)
     ms = 1e3 * (time.perf_counter() - t0) / steps / chains  # per chain: every chain of the batch makes one transition per call
     assert bool(torch.isfinite(v).all()), 'chain diverged'
@@ -160,7 +163,7 @@ def side_run(N, loss, init, amp, steps, warmup, dev, timed_reps=0, chains=1):
     if timed_reps:
         acc = None
         for _ in range(timed_reps):
-            tm = eng.transition(fixed, moving, v, timed=True)
+            tm = eng.transition(fixed, moving, v, sig, timed=True)
             acc = tm if acc is None else {k: acc[k] + tm[k] for k in tm}
         out['stage_ms'] = {k: x / timed_reps for k, x in acc.items()}
         bk = out['stage_ms']['exp_bwd_primary_avg_ms']
@@ -460,6 +463,8 @@ def main():
                                         note='BASELINE.json config 4 names the SSD loss' if other == 'ssd' else '')
             also['displaced_init'] = dict(side_run(N, args.loss, 'wave', 6.0, 20, 5, dev), init='wave amp 6.0 voxels',
                                           note='last squaring steps leave the radius-1 kernels (DESIGN.md section 4)')
+            also[f'sigma_field_{N}'] = dict(side_run(N, args.loss, 'identity', 0.0, 20, 5, dev, timed_reps=3, sigma=0.5), sigma='field, 0.5 everywhere',
+                                            note="pSGLD: the Langevin noise preconditioned by a sigma field (MCMC_init 'VI', utils/functions.py:78-84)")
             if N != 128:
                 also['size_128'] = dict(side_run(128, args.loss, 'identity', 0.0, 50, 10, dev, timed_reps=5), workload=workload_name(128, args.loss))
             if N != 128:  # the reference runs C = 2 chains of a pair (configs/*/config.json): batched in one engine they fill the GPU at 128^3

@@ -46,6 +46,7 @@ static Knobs knobs_from_env() {
     k.seg_fit = env_or("IRS_SEG_FIT", k.seg_fit);
     k.fwd_pf = env_or("IRS_FWD_PF", k.fwd_pf);
     k.fwd_r2_rows1 = env_or("IRS_FWD_R2_ROWS1", k.fwd_r2_rows1);
+    k.ps_rows = env_or("IRS_PS_ROWS", k.ps_rows);
     const char* tile = getenv("IRS_SOBOLEV_TILE");
     if (tile && *tile) k.sobolev_tile = tile[0] == 'b' ? 2 : (tile[0] == 's' ? 1 : atoi(tile));
     k.march_seg = env_or("IRS_MARCH_SEG", k.march_seg);
@@ -92,7 +93,7 @@ int knob_set(Knobs& k, const char* name, int value, bool on_context) {
         {"fwd_rows1", &Knobs::fwd_rows1, KN_GLOBAL}, {"coarse_box", &Knobs::coarse_box, KN_GLOBAL}, {"lds_from", &Knobs::lds_from, KN_GLOBAL},
         {"fwd_pf", &Knobs::fwd_pf, KN_GLOBAL}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1, KN_GLOBAL}, {"sobolev_tile", &Knobs::sobolev_tile, KN_GLOBAL},
         {"march_seg", &Knobs::march_seg, KN_GLOBAL}, {"march_seg_fwd", &Knobs::march_seg_fwd, KN_GLOBAL}, {"swz_run", &Knobs::swz_run, KN_GLOBAL},
-        {"sobolev_seg", &Knobs::sobolev_seg, KN_GLOBAL},
+        {"sobolev_seg", &Knobs::sobolev_seg, KN_GLOBAL}, {"ps_rows", &Knobs::ps_rows, KN_GLOBAL},
         {"seg_fit", &Knobs::seg_fit, KN_LAYOUT}, {"seg_min_blocks", &Knobs::seg_min_blocks, KN_LAYOUT}, {"seg_min_len", &Knobs::seg_min_len, KN_LAYOUT},
         {"lcc_seg", &Knobs::lcc_seg, KN_LAYOUT}, {"stats_seg", &Knobs::stats_seg, KN_LAYOUT}, {"update_seg", &Knobs::update_seg, KN_LAYOUT},
     };
@@ -730,9 +731,9 @@ static int forward_pass(irs_ctx* c, const irs_io* io, const float* v, bool with_
     //    never materialised); the two-kernel form for the mixture initialisation (no noise) and the small SVFFD control grid
     bool have_dmax0 = false;
     const float amp = (float)sqrt(2.0 * (double)cfg.lr);
-    // (with a sigma FIELD -- the preconditioner of a chain started from the VI posterior -- the one-kernel form holds 149 VGPRs,
-    // one workgroup per CU, and measured 2 % slower end to end than the two kernels: config 5 at 192^3, 408-411 against 415-417 samples/s)
-    if (with_noise && cfg.sobolev_s > 0 && !c->ffd && c->kn.fuse_noise && !io->sigma) {
+    // (a sigma FIELD -- the preconditioner of a chain started from the VI posterior -- takes the kernel's 32 x 16 tile: 99 VGPRs, two
+    // workgroups per CU; only sigma together with INJECTED noise, which tests use, keeps the two-kernel form)
+    if (with_noise && cfg.sobolev_s > 0 && !c->ffd && c->kn.fuse_noise && !(io->sigma && io->eps)) {
         have_dmax0 = true;
         launch_perturb_sobolev_march(v, io->sigma, io->eps, amp, vs, c->sob, C, c->volv, c->dmax, cfg.no_steps, cfg.seed, 0, it, st);
     } else {

@@ -94,6 +94,7 @@ struct Knobs {
     int seg_fit = 1;           // IRS_SEG_FIT           squaring-step kernels: segment length from the resident-set cost model (0: power-of-two rule)
     int coarse_box = 1;        // IRS_COARSE_BOX        any-radius adjoint: source boxes from the coarse displacement extrema
     int sobolev_tile = 0;      // IRS_SOBOLEV_TILE      0: by size; 1: 32 x 16; 2: 64 x 32 ("small" / "big")
+    int ps_rows = 0;           // IRS_PS_ROWS           fused perturbation + smoothing: rows per tile, 0: 16 with a sigma field, 32 without; 16 / 32
     int march_seg = 0, march_seg_fwd = 0, swz_run = -1, seg_min_blocks = 0, seg_min_len = 0;  // IRS_MARCH_SEG, _FWD, IRS_SWZ_RUN, IRS_SEG_MIN_*
     int sobolev_seg = 0, lcc_seg = 0, stats_seg = 0, update_seg = 0;                          // IRS_*_SEG
     int slab_split = 1;        // IRS_SLAB_SPLIT        interior / boundary split around an exchange

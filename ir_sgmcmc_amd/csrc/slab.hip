@@ -925,7 +925,7 @@ int slab_transition_once(irs_ctx* c, const irs_io* io_in, hipStream_t st) {
     ex.planned_ = planned;
     Sched sch(s, cfg, C);
     sch.want_split_ = c->kn.slab_split != 0;
-    sch.fuse_noise_ = c->kn.fuse_noise != 0 && !io.sigma;  // (a sigma field: the two-kernel form, as in the fused engine)
+    sch.fuse_noise_ = c->kn.fuse_noise != 0 && !(io.sigma && io.eps);  // (sigma field AND injected noise, tests only: the two-kernel form, as in the fused engine)
     if (!c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));
     c->dmax_clean = false;
     int energy_ar = -1;

@@ -204,7 +204,7 @@ void launch_sobolev_march(const float* in, float* out, const Taps& taps, int pla
 // column outside the volume is a copy of the border one INCLUDING its noise (it is the perturbed field that is padded), which
 // the clamped coordinates of the counter give for free.  Same tap order as sobolev_march_kernel: bit-identical results.
 // ------------------------------------------------------------------------------------------------
-constexpr int kPsBlock = 512, PSX = 32, PSY = 32;
+constexpr int kPsBlock = 512, PSX = 32;
 
 struct NoiseSrc {
     const float* sigma;       // (C,3,D,H,W) or nullptr (= 1)
@@ -214,7 +214,11 @@ struct NoiseSrc {
     const uint64_t* dev_iter; // device-side Philox counter (overrides `iteration`)
 };
 
-template <int S, bool SIGMA, bool EPS>
+// PSY rows per tile: 32, or -- a sigma FIELD with generated noise, chains started from the VI posterior (MCMC_init 'VI',
+// utils/functions.py:78-84) -- 16: on the 32 x 32 tile that variant needs 149 VGPRs (nine more live values across the Philox
+// rounds, and 64-bit column pointers for one more array), one workgroup per CU; two columns per thread instead of three bring it
+// to the register count of the sigma = 1 kernel (two workgroups per CU) for 16 % more staged elements per output.
+template <int S, bool SIGMA, bool EPS, int PSY>
 __global__ __launch_bounds__(kPsBlock) void perturb_sobolev_march_kernel(const float* __restrict__ v, NoiseSrc ns,
                                                                          float* __restrict__ out, Taps taps, Vol vol,
                                                                          unsigned* __restrict__ dmax0, float inv_pow,
@@ -402,23 +406,30 @@ __global__ __launch_bounds__(kPsBlock) void perturb_sobolev_march_kernel(const f
 void launch_perturb_sobolev_march(const float* v, const float* sigma, const float* eps, float amp, float* out, const Taps& taps,
                                   int C, Vol vol, unsigned* dmax0, int no_steps, uint64_t seed, uint64_t iteration,
                                   const uint64_t* dev_iteration, hipStream_t st) {
-    const int ntx = (vol.W + PSX - 1) / PSX, nty = (vol.H + PSY - 1) / PSY;
+    // the sigma-field variant runs on 32 x 16 tiles (see the kernel); IRS_PS_ROWS = 16 / 32 forces one shape for both (measurements)
+    const int forced_rows = global_knobs().ps_rows;
+    const bool half = !eps && (forced_rows == 16 || (forced_rows != 32 && sigma));
+    const int psy = half ? 16 : 32;
+    const int ntx = (vol.W + PSX - 1) / PSX, nty = (vol.H + psy - 1) / psy;
     int seg_len = pick_seg_len(vol.nz, (int64_t)ntx * nty * C, 4, global_knobs().sobolev_seg, 512);
     if (global_knobs().seg_fit && global_knobs().sobolev_seg <= 0) {
-        static int cache = 0;
-        const int64_t res = resident_blocks((const void*)perturb_sobolev_march_kernel<3, false, false>, kPsBlock, &cache);
+        static int cache = 0, cache_half = 0;
+        const int64_t res = half ? resident_blocks(sigma ? (const void*)perturb_sobolev_march_kernel<3, true, false, 16> : (const void*)perturb_sobolev_march_kernel<3, false, false, 16>, kPsBlock, &cache_half)
+                                 : resident_blocks((const void*)perturb_sobolev_march_kernel<3, false, false, 32>, kPsBlock, &cache);
         if (res > 0) seg_len = pick_seg_len_fit(vol.nz, 0, (int64_t)ntx * nty * C, 4, 2 * taps.s, res, 0);
     }
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const float inv_pow = 1.0f / (float)(1 << no_steps);
     const dim3 grid(ntx, nty, (unsigned)(nseg * C));
     const NoiseSrc ns{sigma, eps, amp, seed, iteration, dev_iteration};
-#define IRS_PS(SS, SG, EP) hipLaunchKernelGGL((perturb_sobolev_march_kernel<SS, SG, EP>), grid, dim3(kPsBlock), 0, st, v, ns, out, taps, vol, dmax0, inv_pow, seg_len, nseg)
+#define IRS_PS(SS, SG, EP, PY) hipLaunchKernelGGL((perturb_sobolev_march_kernel<SS, SG, EP, PY>), grid, dim3(kPsBlock), 0, st, v, ns, out, taps, vol, dmax0, inv_pow, seg_len, nseg)
 #define IRS_PS2(SS)                                   \
-    if (sigma && eps) IRS_PS(SS, true, true);         \
-    else if (sigma) IRS_PS(SS, true, false);          \
-    else if (eps) IRS_PS(SS, false, true);            \
-    else IRS_PS(SS, false, false)
+    if (sigma && eps) IRS_PS(SS, true, true, 32);             \
+    else if (sigma && half) IRS_PS(SS, true, false, 16);      \
+    else if (sigma) IRS_PS(SS, true, false, 32);              \
+    else if (eps) IRS_PS(SS, false, true, 32);                \
+    else if (half) IRS_PS(SS, false, false, 16);              \
+    else IRS_PS(SS, false, false, 32)
     switch (taps.s) {
         case 1: IRS_PS2(1); break;
         case 2: IRS_PS2(2); break;

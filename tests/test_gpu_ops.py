@@ -82,14 +82,19 @@ def test_noise_generated_while_staging_is_the_same_noise(dims, s):
              dict(tau=0.4, eps=eps, sigma=sigma)]
     outs = {}
     try:
-        for fuse in (0, 1):
+        # ps_rows: the fused kernel's tile, 32 x 32 (three columns per thread) or 32 x 16 (two: what a sigma field with generated noise
+        # takes by default -- the 32-row form of that variant needs 149 VGPRs); 0 = that default
+        for fuse, rows in ((0, 0), (1, 0), (1, 16), (1, 32)):
             option_set('fuse_noise', fuse)
-            outs[fuse] = [G.perturb_smooth(v, k, **kw) for kw in cases]
+            option_set('ps_rows', rows)
+            outs[fuse, rows] = [G.perturb_smooth(v, k, **kw) for kw in cases]
     finally:
         option_set('fuse_noise', 1)
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
-    assert not torch.equal(outs[1][0], outs[1][2])   # (different noise sources do differ)
+        option_set('ps_rows', 0)
+    for key in ((1, 0), (1, 16), (1, 32)):
+        for a, b in zip(outs[0, 0], outs[key]):
+            assert torch.equal(a, b), key
+    assert not torch.equal(outs[1, 0][0], outs[1, 0][2])   # (different noise sources do differ)
 
 
 def test_philox_noise_statistics():

@@ -281,6 +281,33 @@ def test_larger_sizes_of_the_less_common_configurations(case):
           torch.tensor(0.0), oc.lr * GRAD_RTOL * gmax + 1e-5)
 
 
+def test_sigma_field_runs_the_fused_stage_a():
+    """A chain started from the VI posterior (MCMC_init 'VI', utils/functions.py:78-84: 14 of the reference's 16 configs) carries a
+    sigma FIELD as the preconditioner of its Langevin noise.  With in-kernel noise that path now takes the one-kernel stage A too
+    (its 32 x 16 tile); the chain is bit-identical to the two-kernel form."""
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    N = 40
+    f1, m1 = synthetic_pair((N, N, N), seed=0)
+    fixed = to_dev({k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'})
+    moving = to_dev({k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'})
+    g = torch.Generator().manual_seed(11)
+    sigma = (0.25 + torch.rand(2, 3, N, N, N, generator=g)).to(DEV)
+    res = []
+    for fuse in (1, 0):
+        eng = TransitionEngine(EngineConfig(dims=(N, N, N), no_chains=2, seed=3), DEV)
+        eng.option('fuse_noise', fuse)
+        fd, md = eng.prepare({k: v.expand(2, *v.shape[1:]).contiguous() for k, v in fixed.items()},
+                             {k: v.expand(2, *v.shape[1:]).contiguous() for k, v in moving.items()})
+        eng.gmm_init(fd, md)
+        v = torch.zeros(2, 3, N, N, N, device=DEV)
+        for _ in range(3):
+            eng.transition(fd, md, v, sigma)
+        eng.flush()
+        assert bool(torch.isfinite(v).all())
+        res.append(v.clone())
+    assert torch.equal(res[0], res[1])
+
+
 def test_in_kernel_noise_path_runs_and_is_reproducible():
     """eps / unif = NULL -> Philox noise keyed by (seed, iteration): same seed -> same chain, other seed -> other chain."""
     from ir_sgmcmc_amd.data_loader import synthetic_pair
