@@ -287,8 +287,9 @@ int irs_comm_create_rccl(const uint8_t id[IRS_COMM_ID_BYTES], int rank, int worl
  * the flags) travel: the same string on every rank, distributed by the caller like the id above; rank 0 creates the segment and
  * unlinks the name once every rank has attached.  Ranks may share a device (several processes on one GPU: how the asynchronous
  * schedule is exercised on a one-GPU box) or own one each (world <= 8, one node).  Collective, blocking.  Environment:
- * IRS_IPC_FLAGS=device keeps the flags in the landing areas instead of the host segment; IRS_IPC_TIMEOUT_S (20) bounds every wait
- * of a kernel for a peer -- a rank that waits longer raises an error that the next irs_slab_transition / irs_flush returns. */
+ * IRS_IPC_SLOT_MB (8) sizes the first landing area (MiB per neighbour and slot; it grows when a context needs more);
+ * IRS_IPC_TIMEOUT_S (20) bounds every wait of a kernel for a peer -- a rank that waits longer raises an error that the next
+ * irs_slab_transition / irs_flush returns. */
 int irs_comm_create_ipc(const char* name, int rank, int world, irs_comm** out);
 /* The same two transport operations as caller-supplied functions: rehearsal of the schedule with several ranks sharing ONE
  * GPU, which RCCL refuses (tests).  A callback must leave the data in place when it returns or enqueue its work on `stream`. */

@@ -8,8 +8,10 @@
 //
 //   bootstrap   a POSIX shared-memory segment named by the caller: every rank publishes the hipIpcMemHandle_t of ONE device
 //               allocation (its landing area) there and opens its peers'.  The same segment, page-locked and mapped into every
-//               rank's device address space (hipHostRegister), holds the sequence flags (IRS_IPC_FLAGS=device puts them into the
-//               landing area instead: polled locally, written by the peer).
+//               rank's device address space (hipHostRegister), holds the sequence flags: uncached system memory, so a store
+//               of one process's kernel is what the next poll of another's reads.  (Flags inside the landing areas -- polled
+//               locally, written through the peer mapping -- were built and do NOT work: on this driver a system-scope poll of
+//               hipMalloc memory never saw the other process's store, even with both ranks on one device.)
 //   exchange    push kernel: packs this rank's strips into slot (seq & 1) of each neighbour's landing area; when its last
 //               workgroup has drained its stores (system-scope release) it stores `seq` into the neighbours' flags.
 //               wait kernel (ONE wavefront): polls this rank's flags until `seq` has arrived (bounded: a timeout raises an error
@@ -87,7 +89,8 @@ struct IpcState {
     size_t land_bytes = 0, x_slot = 0, ar_slot = 0;
     char* peer[kMaxWorld] = {};    // peers' landing areas as mapped here (peer[rank] == land)
     uint64_t peer_x_slot[kMaxWorld] = {}, peer_ar_slot[kMaxWorld] = {};
-    bool dev_flags = false;
+    char* retired[8] = {};         // landing areas outgrown by a later reservation (freed with the communicator)
+    int n_retired = 0;
     uint32_t xseq = 0, arseq = 0;
     unsigned* err = nullptr;       // pinned, device-visible: first timeout (code) raised by a waiting kernel
     unsigned* err_dev = nullptr;
@@ -122,10 +125,7 @@ int give_up(IpcState* s, int rc) {  // tell the peers before returning an error 
 // flag words: where this rank POLLS (its own, written by `src`) and where it SIGNALS (the peer's, naming itself)
 inline size_t xflag_off(int side) { return offsetof(ShmFlags, x) + (size_t)side * kLine; }
 inline size_t arflag_off(int src) { return offsetof(ShmFlags, ar) + (size_t)src * kLine; }
-unsigned* flag_ptr(IpcState* s, int owner, size_t off) {
-    if (s->dev_flags) return (unsigned*)(s->peer[owner] + off);  // the landing header starts with a ShmFlags
-    return (unsigned*)((char*)&s->shm_dev->flags[owner] + off);
-}
+unsigned* flag_ptr(IpcState* s, int owner, size_t off) { return (unsigned*)((char*)&s->shm_dev->flags[owner] + off); }
 
 // ---- device side -----------------------------------------------------------------------------------------------------------
 struct Run {
@@ -295,6 +295,15 @@ int ipc_reserve(irs_comm* cm, size_t xbytes, size_t arbytes) {
     if (!s) return fail("ipc_reserve: not an ipc communicator");
     xbytes = align16(xbytes + 16 * kMaxRuns);  // every run starts on a 16-byte boundary of its slot
     arbytes = align16(arbytes < 256 ? 256 : arbytes);
+    if (!s->land) {
+        // The first reservation is generous -- 8 MiB per side and slot (a 256^3 slab with the widest ghost zone needs 6.3), 2 MiB per
+        // all-reduce contribution; IRS_IPC_SLOT_MB overrides -- so that a run normally never reserves twice: exporting a SECOND
+        // allocation after the first one was freed has failed here now and then (hipIpcGetMemHandle: invalid argument).
+        const char* mb = getenv("IRS_IPC_SLOT_MB");
+        const size_t first = (size_t)(mb && atoi(mb) > 0 ? atoi(mb) : 8) << 20;
+        if (xbytes < first) xbytes = first;
+        if (arbytes < ((size_t)2 << 20)) arbytes = (size_t)2 << 20;
+    }
     // every rank must take the same decision: the sizes come from the (identical) configuration, and a rank that already holds
     // enough still takes part in the barriers of one that does not -- so all of them re-publish whenever ANY call grows
     const bool grow = xbytes > s->x_slot || arbytes > s->ar_slot || !s->land;
@@ -303,7 +312,11 @@ int ipc_reserve(irs_comm* cm, size_t xbytes, size_t arbytes) {
     if (give_up(s, host_barrier(s))) return 1;  // nobody is still writing into an old area
     close_peers(s);
     if (give_up(s, host_barrier(s))) return 1;  // nobody still maps an old area
-    if (s->land) HIP_TRY(hipFree(s->land));
+    // an outgrown area is retired, not freed: a fresh allocation must not land on the address range of one that was exported
+    if (s->land) {
+        if (s->n_retired >= 8) return give_up(s, fail("ipc_reserve: the landing area was outgrown %d times", s->n_retired));
+        s->retired[s->n_retired++] = s->land;
+    }
     s->land = nullptr;
     s->x_slot = xbytes > s->x_slot ? xbytes : s->x_slot;
     s->ar_slot = arbytes > s->ar_slot ? arbytes : s->ar_slot;
@@ -311,10 +324,6 @@ int ipc_reserve(irs_comm* cm, size_t xbytes, size_t arbytes) {
     hipError_t e = hipMalloc((void**)&s->land, s->land_bytes);
     if (e != hipSuccess) return give_up(s, fail("ipc_reserve: hipMalloc of %zu bytes failed: %s", s->land_bytes, hipGetErrorString(e)));
     HIP_TRY(hipMemset(s->land, 0, kLandHeader));
-    if (s->dev_flags) {  // the flags restart in the new area: at the sequence numbers every rank has reached
-        for (int i = 0; i < 2; ++i) HIP_TRY(hipMemsetD32((hipDeviceptr_t)(s->land + xflag_off(i)), (int)s->xseq, 1));
-        for (int i = 0; i < kMaxWorld; ++i) HIP_TRY(hipMemsetD32((hipDeviceptr_t)(s->land + arflag_off(i)), (int)s->arseq, 1));
-    }
     HIP_TRY(hipDeviceSynchronize());
     ShmRank& me = s->shm->rank[s->rank];
     e = hipIpcGetMemHandle(&me.handle, s->land);
@@ -444,6 +453,7 @@ void ipc_destroy(irs_comm* cm) {
         (void)munmap(s->shm, kShmBytes);
     }
     if (s->land) (void)hipFree(s->land);
+    for (int i = 0; i < s->n_retired; ++i) (void)hipFree(s->retired[i]);
     if (s->err) (void)hipHostFree(s->err);
     delete s;
     cm->ipc = nullptr;
@@ -522,8 +532,6 @@ int ipc_create(const char* name, int rank, int world, irs_comm** out) {
         e = hipHostGetDevicePointer((void**)&s->err_dev, s->err, 0);
     }
     if (e != hipSuccess) return bail(give_up(s, fail("ipc transport: pinned host memory failed: %s", hipGetErrorString(e))));
-    const char* fl = getenv("IRS_IPC_FLAGS");
-    s->dev_flags = fl && !strcmp(fl, "device");
     const char* to = getenv("IRS_IPC_TIMEOUT_S");
     const double secs = to && atof(to) > 0.0 ? atof(to) : 20.0;
     s->timeout_ticks = (unsigned long long)(secs * 100.0e6);  // wall_clock64: 100 MHz

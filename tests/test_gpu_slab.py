@@ -196,8 +196,11 @@ def test_slab_svffd(data_loss, C, N, world, cps, transport):
 
 
 @pytest.mark.parametrize('transport', TRANSPORTS)
-def test_config4_256_cubed_ssd_two_slabs(transport):
-    """BASELINE.json config 4 at its own size: 256^3, SSD + RegLoss_L2, one chain in two z-slabs vs the fused engine."""
+def test_config4_256_cubed_ssd_two_slabs(transport, monkeypatch):
+    """BASELINE.json config 4 at its own size: 256^3, SSD + RegLoss_L2, one chain in two z-slabs vs the fused engine.
+    (ipc: with a first landing area of 1 MiB per slot, so that the context outgrows it and the communicator re-exports a larger
+    one -- the path a run normally never takes.)"""
+    monkeypatch.setenv('IRS_IPC_SLOT_MB', '1')  # (inherited by the spawned ranks)
     dv, dd, ds, st = _launch(2, 'SSD', 1, 256, False, 3.0, 'RegLoss_L2', 4, transport=transport)
     from tests._report import check
     check(f'slab_{transport}/config4_256_ssd_ranks2', 'v_new (rel to max)', dv, 0.0, 1e-5)
