@@ -56,6 +56,8 @@ struct irs_ctx {
     double *stat_partials, *energy_partials, *nll_partials;
     double *stat_sum, *energy_sum, *nll_sum;  // reduced partial sums (staged / slab path)
     unsigned* dmax;  // [no_steps + 1][C][4] max |d_k| in voxels per axis (float bits), by-product of the forward steps
+    float* tile_bound;          // per 8^3 cell: max over axes of |d_k| in voxels  } tile-level variant selection of the
+    unsigned char* tile_class;  // per gather tile: floor(local bound) + 1           } adjoint (exp_kernels.hip)
     float* cmm;      // coarse (8^3 cells) min / max of d_k for the source boxes of the any-radius adjoint (kernels.h)
     unsigned* hint = nullptr;  // pinned host copy of dmax as of the last finished transition (written by finalize_kernel, read
                      // by the host WITHOUT synchronisation: a hint that only decides which variants are launched)

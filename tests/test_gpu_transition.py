@@ -169,6 +169,57 @@ def test_transition_matches_oracle_builder_variants(variant):
         v.copy_(o['v_new'].to(DEV))
 
 
+@pytest.mark.parametrize('amp', [1.6, 3.5, 9.0])
+def test_adjoint_variants_are_selected_per_tile(amp):
+    """A velocity field whose large displacements sit in ONE region of the volume -- what a converged registration looks like --
+    makes the adjoint of a squaring step pick its variant per gather tile (radius-1 gather where every source of a tile stays below
+    one voxel, radius-2 gather below two, the any-radius scatter above; csrc/exp_kernels.hip: tile_class_kernel) instead of per
+    chain.  Against the oracle at the usual tolerances, and against the same engine deciding per chain (tile_select 0).  The
+    volume is several tiles wide on every axis and ragged; the bump sits off-centre so that classes change across tile and
+    segment boundaries."""
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    dims = (70, 52, 84)  # D, H, W
+    oc = OracleConfig(dims=dims, lr=0.05)
+    f1, m1 = synthetic_pair(dims, seed=3)
+    fixed = {k: v.unsqueeze(0).contiguous() for k, v in f1.items() if k != 'seg'}
+    moving = {k: v.unsqueeze(0).contiguous() for k, v in m1.items() if k != 'seg'}
+    zz, yy, xx = torch.meshgrid(*[torch.arange(n, dtype=torch.float32) for n in dims], indexing='ij')
+    bump = torch.exp(-(((zz - 40.0) / 11.0) ** 2 + ((yy - 20.0) / 9.0) ** 2 + ((xx - 50.0) / 13.0) ** 2))
+    v0 = (amp * torch.stack([bump, -0.8 * bump, 0.6 * bump])).unsqueeze(0).contiguous()
+    gen = torch.Generator().manual_seed(5)
+    eps = torch.randn(1, 3, *dims, generator=gen)
+    unif = torch.rand(1, 3, *dims, generator=gen)
+    orc = OracleChain(oc, v0=v0)
+    orc.init_gmm(fixed, moving)
+    o = orc.transition(fixed, moving, eps, unif)
+    cfg = engine_config(oc)
+    res = {}
+    for sel in (1, 0):
+        eng = TransitionEngine(cfg, DEV)
+        eng.option('tile_select', sel)
+        eng.option('predict_variants', 0)   # every variant launched: only the per-tile / per-chain decision differs
+        fd, md = eng.prepare(to_dev(fixed), to_dev(moving))
+        eng.gmm_init(fd, md)
+        v = v0.to(DEV).contiguous()
+        out = outputs_for(cfg)
+        eng.transition(fd, md, v, None, eps.to(DEV), unif.to(DEV), out)
+        eng.flush()
+        res[sel] = (v.clone(), out['grad_v'].clone())
+        if sel:
+            T = f'oracle/tile_select_bump_amp{amp:g}'
+            sc = eng.scalars()
+            check(T, 'data_term (rel)', torch.tensor(sc['data_term']) / torch.tensor(o['data']).abs(), torch.sign(torch.tensor(o['data'])), 1e-5)
+            check(T, 'displacement [voxels]', out['displacement'], o['displacement'], 1e-4)
+            gmax = float(o['grad_v'].abs().max())
+            check(T, 'grad_v (rel to max)', out['grad_v'].cpu() / gmax, o['grad_v'] / gmax, GRAD_RTOL)
+            check(T, 'v_new', v, o['v_new'], oc.lr * GRAD_RTOL * gmax + 1e-5)
+    gmax = float(res[0][1].abs().max())
+    # the variants sum the same contributions in different orders (the any-radius one in fixed point): rounding apart
+    check(f'tile_select_vs_per_chain/amp{amp:g}', 'grad_v (rel to max)', res[1][1] / gmax, res[0][1] / gmax, 2e-6)
+    # and the field does leave the radius-1 regime somewhere: with tile_select the result is NOT bit-identical to the per-chain one
+    assert float(v0.abs().max()) > 1.0
+
+
 @pytest.mark.parametrize('N,loss', [(128, 'gmm'), (128, 'ssd'), (256, 'gmm')])
 def test_transition_matches_oracle_at_full_size(N, loss):
     """BASELINE.json configs 2 / 3 at their own size: 128^3, SSD + RegLoss_L2 (config 2; SSD is builder-defined, SURVEY.md
