@@ -57,8 +57,10 @@ def traffic_from_profile(n):
     return None, None
 
 
-def cpu_baseline(n, reps, loss):
-    """the CPU oracle (op-for-op the reference's ATen sequence) on a bounded sample, all host cores"""
+def cpu_baseline(n, reps, loss, warmup=None):
+    """the CPU oracle (op-for-op the reference's ATen sequence) on a bounded sample, all host cores: `warmup` untimed transitions
+    (default: 3 up to 128^3, where they cost seconds; above that one 64^3 transition warms the thread pool and the allocator),
+    then `reps` timed ones.  Returns (seconds per transition, cores, per-repetition seconds)."""
     import torch
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from oracle import OracleChain, OracleConfig
@@ -80,17 +82,20 @@ def cpu_baseline(n, reps, loss):
         g = torch.Generator().manual_seed(0)
         return ch, fixed, moving, torch.randn(1, 3, *dims, generator=g), torch.rand(1, 3, *dims, generator=g)
 
-    # warm-up (thread pool, allocator): at the measured size when that is cheap, else at 64^3
-    ch, fixed, moving, eps, unif = setup(n if n <= 128 else 64)
-    ch.transition(fixed, moving, eps, unif)
-    if n > 128:
-        ch, fixed, moving, eps, unif = setup(n)
-    t0 = time.perf_counter()
-    for i in range(reps):
+    if warmup is None:
+        warmup = 3 if n <= 128 else 0
+    ch, fixed, moving, eps, unif = setup(n if warmup else 64)
+    for _ in range(max(warmup, 1)):
         ch.transition(fixed, moving, eps, unif)
-        print(f'[bench] cpu baseline: {i + 1}/{reps} after {time.perf_counter() - t0:.1f} s', file=sys.stderr, flush=True)
-    dt = (time.perf_counter() - t0) / reps
-    return dt, cores
+    if not warmup:
+        ch, fixed, moving, eps, unif = setup(n)
+    each = []
+    for i in range(reps):
+        t0 = time.perf_counter()
+        ch.transition(fixed, moving, eps, unif)
+        each.append(time.perf_counter() - t0)
+        print(f'[bench] cpu baseline: {n}^3 {i + 1}/{reps}: {each[-1]:.1f} s', file=sys.stderr, flush=True)
+    return sum(each) / reps, cores, each
 
 
 def spawn_ranks(n):
@@ -203,6 +208,7 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the `also` workloads (SSD, displaced start, 128^3, sustained run)')
     ap.add_argument('--cpu-size', type=int, default=256, help='edge of the CPU-baseline volume (capped at --size); 256: one transition takes ~25 s on 16 cores')
     ap.add_argument('--cpu-reps', type=int, default=1)
+    ap.add_argument('--cpu-reps-128', type=int, default=5, help='timed 128^3 transitions of the CPU oracle (after 3 warm-up) reported next to the bench-size one; 0 = skip')
     args = ap.parse_args()
 
     # no launcher (or a stale single-process WORLD_SIZE = 1 in the environment): start the ranks ourselves
@@ -473,12 +479,18 @@ def main():
             also['sustained'] = dict(side_run(N, args.loss, 'identity', 0.0, 500, 5, dev), note='500 consecutive transitions from the identity')
             out['also'] = also
         if not args.no_cpu_baseline and world == 1:
+            # 3 warm-up + >= 5 timed transitions at 128^3 and >= 1 at 256^3 (the workload itself): both reported,
+            # `value` is the one measured at the bench size (or the largest size asked for, scaled by the voxel count)
             n_cpu = min(args.cpu_size, N)
-            dt, cores = cpu_baseline(n_cpu, args.cpu_reps, args.loss)
+            dt, cores, each = cpu_baseline(n_cpu, args.cpu_reps, args.loss)
             scale = (N / n_cpu) ** 3
             out['cpu_baseline'] = {'value': 1.0 / (dt * scale), 'unit': 'transitions/s', 'cores': cores, 'kind': 'port',
                                    'sample': f'{args.cpu_reps} transition(s) of the torch-CPU oracle at {n_cpu}^3 '
                                              f'({dt:.2f} s each, {cores} threads)' + (f', scaled by voxel count x{scale:.0f} to {N}^3' if scale != 1 else '')}
+            if n_cpu > 128 and args.cpu_reps_128 > 0:
+                dt128, _, each128 = cpu_baseline(128, args.cpu_reps_128, args.loss, warmup=3)
+                out['cpu_baseline']['at_128'] = {'value': 1.0 / dt128, 'unit': 'transitions/s', 'seconds_each': [round(x, 3) for x in each128],
+                                                 'sample': f'3 warm-up + {args.cpu_reps_128} timed transitions of the torch-CPU oracle at 128^3 ({dt128:.2f} s each, {cores} threads)'}
         print(json.dumps(out), flush=True)
     if world > 1:
         # tear down in order: engine (its streams drain), the library's RCCL communicator, then torch's process group
