@@ -455,7 +455,7 @@ def main():
             out['slab_transport_failure'] = slab_failure
         if slab:
             st = slab_status
-            out['slab'] = {'transport': transport, 'transport_trials_ms': trials, 'planes_owned': eng.b - eng.a, 'planes_held': eng.hi - eng.lo, 'ghost_max': eng.ghost_max,
+            out['slab'] = {'transport': transport, 'transport_info': comm.describe(), 'transport_trials_ms': trials, 'planes_owned': eng.b - eng.a, 'planes_held': eng.hi - eng.lo, 'ghost_max': eng.ghost_max,
                            'exchange_rounds_per_transition': st['exchanges'] / max(st['transitions'], 1),
                            'MB_sent_per_transition_rank0': st['exchanged_bytes'] / max(st['transitions'], 1) / 1e6,
                            'exact_transitions': st['exact_transitions'], 'mispredictions': st['mispredictions']}

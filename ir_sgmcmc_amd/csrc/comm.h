@@ -37,4 +37,5 @@ int ipc_reserve(irs_comm* c, size_t xbytes, size_t arbytes);
 int ipc_exchange(irs_comm* c, const irs_xfer* x, int n, hipStream_t st);
 int ipc_allreduce(irs_comm* c, void* buf, size_t count, int kind, hipStream_t st);
 int ipc_check(irs_comm* c);
+void ipc_describe(const irs_comm* c, char* out, size_t n);
 }  // namespace irs

@@ -175,6 +175,13 @@ void irs_comm_destroy(irs_comm* c) {
     delete c;
 }
 
+int irs_comm_describe(const irs_comm* c, char* out, size_t n) {
+    if (!c || !out || n == 0) return fail("irs_comm_describe: bad arguments");
+    if (c->kind == 2) ipc_describe(c, out, n);
+    else snprintf(out, n, "%s: %d ranks", c->kind == 0 ? "rccl" : "callbacks", c->world);
+    return 0;
+}
+
 int irs_comm_rank(const irs_comm* c) { return c ? c->rank : -1; }
 int irs_comm_world(const irs_comm* c) { return c ? c->world : -1; }
 

@@ -89,6 +89,7 @@ struct IpcState {
     size_t land_bytes = 0, x_slot = 0, ar_slot = 0;
     char* peer[kMaxWorld] = {};    // peers' landing areas as mapped here (peer[rank] == land)
     uint64_t peer_x_slot[kMaxWorld] = {}, peer_ar_slot[kMaxWorld] = {};
+    bool land_uncached = false;    // the landing area is uncached device memory (else plain hipMalloc)
     char* retired[8] = {};         // landing areas outgrown by a later reservation (freed with the communicator)
     int n_retired = 0;
     uint32_t xseq = 0, arseq = 0;
@@ -280,6 +281,13 @@ void close_peers(IpcState* s) {
 
 }  // namespace
 
+void ipc_describe(const irs_comm* cm, char* out, size_t n) {
+    const IpcState* s = cm->ipc;
+    snprintf(out, n, "ipc: %d ranks, landing area %.1f MiB %s, sequence flags in host shared memory, %llu exchanges / %llu all-reduces so far",
+             s->world, (double)s->land_bytes / 1048576.0, s->land ? (s->land_uncached ? "uncached device memory" : "hipMalloc") : "(not reserved yet)",
+             (unsigned long long)s->exchanges, (unsigned long long)s->allreduces);
+}
+
 int ipc_check(irs_comm* cm) {
     IpcState* s = cm->ipc;
     if (!s || !s->err) return 0;
@@ -321,12 +329,30 @@ int ipc_reserve(irs_comm* cm, size_t xbytes, size_t arbytes) {
     s->x_slot = xbytes > s->x_slot ? xbytes : s->x_slot;
     s->ar_slot = arbytes > s->ar_slot ? arbytes : s->ar_slot;
     s->land_bytes = kLandHeader + 4 * s->x_slot + 2 * (size_t)s->world * s->ar_slot;
-    hipError_t e = hipMalloc((void**)&s->land, s->land_bytes);
-    if (e != hipSuccess) return give_up(s, fail("ipc_reserve: hipMalloc of %zu bytes failed: %s", s->land_bytes, hipGetErrorString(e)));
+    // The landing area is written by OTHER devices' kernels (xGMI stores) and read by this one's: asked for as uncached device
+    // memory first (no line of it can sit stale in this device's L2 whatever the fabric does about probes -- what RCCL does with
+    // its own buffers); plain hipMalloc when that kind cannot be allocated or exported (IRS_IPC_LANDING=default skips the attempt).
+    ShmRank& me = s->shm->rank[s->rank];
+    hipError_t e = hipErrorUnknown;
+    const char* kind = getenv("IRS_IPC_LANDING");
+    s->land_uncached = false;
+    if (!(kind && !strcmp(kind, "default"))) {
+        e = hipExtMallocWithFlags((void**)&s->land, s->land_bytes, hipDeviceMallocUncached);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&me.handle, s->land);
+        if (e == hipSuccess) s->land_uncached = true;
+        else {
+            if (s->land) (void)hipFree(s->land);
+            s->land = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    if (!s->land) {
+        e = hipMalloc((void**)&s->land, s->land_bytes);
+        if (e != hipSuccess) return give_up(s, fail("ipc_reserve: hipMalloc of %zu bytes failed: %s", s->land_bytes, hipGetErrorString(e)));
+        e = hipIpcGetMemHandle(&me.handle, s->land);
+    }
     HIP_TRY(hipMemset(s->land, 0, kLandHeader));
     HIP_TRY(hipDeviceSynchronize());
-    ShmRank& me = s->shm->rank[s->rank];
-    e = hipIpcGetMemHandle(&me.handle, s->land);
     if (e != hipSuccess) return give_up(s, fail("hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed where the driver only has dmabuf IPC)", hipGetErrorString(e)));
     me.land_bytes = s->land_bytes;
     me.x_slot = s->x_slot;

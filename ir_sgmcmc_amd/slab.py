@@ -144,6 +144,11 @@ class SlabComm:
         L.check(lib.irs_comm_create_callbacks(ex, ar, None, rank, world, C.byref(h)))
         return cls(h, rank, world, keep=(ex, ar))
 
+    def describe(self):
+        buf = C.create_string_buffer(256)
+        L.check(self.lib.irs_comm_describe(self.handle, buf, 256))
+        return buf.value.decode()
+
     def selftest(self):
         L.check(self.lib.irs_comm_selftest(self.handle, L.stream_ptr()))
 

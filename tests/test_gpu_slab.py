@@ -106,6 +106,8 @@ def _worker(rank, world, port, q, transport, data_loss, C, N, vd, amp, reg, ghos
         torch.cuda.set_device(0)
         comm = SlabComm.create(transport, DEV)
         comm.selftest()
+        if rank == 0:
+            print('[slab transport]', comm.describe(), flush=True)
         D = N if isinstance(N, int) else N[0]
         cfg, fixed, moving, v0, noise = _setup(N, C, data_loss, vd=vd, amp=amp, reg=reg, with_noise=D < 128, cps=cps, transitions=transitions)
         eng, v, d, s = _run_slab(cfg, fixed, moving, v0, noise, comm, ghost_max=ghost_max)

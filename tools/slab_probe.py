@@ -64,6 +64,7 @@ def _concurrent_worker(rank, world, port, q, size, loss, ghost_max, steps):
         eng.gmm_init(fd, md)
         state = eng.state()
         res['ipc_ms'] = timeit(eng, fd, md, eng.new_local(3))
+        res['transport'] = comm.describe()
         st = eng.status()
         res.update(planes=eng.b - eng.a, held=eng.hi - eng.lo, fwd_rounds=st['last_fwd_rounds'], bwd_rounds=st['last_bwd_rounds'],
                    exchanges_per_transition=st['exchanges'] / max(st['transitions'], 1), mispredictions=st['mispredictions'])
