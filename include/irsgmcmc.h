@@ -342,9 +342,10 @@ int irs_slab_status_get(irs_ctx* ctx, irs_slab_status* out, void* stream);
 /* The schedule of the squaring steps as pure host arithmetic (tests, documentation): given the per-step ghost widths
  * h[0..n) (= floor(max|d_k|) + 1), the widest exchange and the smallest slab, fill fwd_round[k] / bwd_round[k] with the index
  * of the exchange round step k belongs to, and fwd_width[r] / bwd_width[r] with the planes that round exchanges (round 0 of
- * the forward pass is fed by the widened smoothing stage and exchanges the perturbed velocity instead).  Returns the
- * number of rounds through n_fwd / n_bwd; non-zero status if a width exceeds the limits. */
-int irs_slab_plan_rounds(const int32_t* h, int n, int ghost_max, int min_slab, int32_t* fwd_round, int32_t* fwd_width,
+ * the forward pass is fed by the widened smoothing stage and exchanges the perturbed velocity instead).  n_buffers: gradient
+ * fields the adjoint rotates through -- 2, or 3 as a context of several ranks has (a backward round then spans up to three
+ * steps).  Returns the number of rounds through n_fwd / n_bwd; non-zero status if a width exceeds the limits. */
+int irs_slab_plan_rounds(const int32_t* h, int n, int ghost_max, int min_slab, int n_buffers, int32_t* fwd_round, int32_t* fwd_width,
                          int32_t* n_fwd, int32_t* bwd_round, int32_t* bwd_width, int32_t* n_bwd);
 
 /* The schedule of one planned transition of rank `rank`, as data -- the list the executor inside irs_slab_transition
@@ -360,6 +361,7 @@ enum {  /* launch stages */
 enum {  /* buffers */
     IRS_SB_V = 0, IRS_SB_NOISY, IRS_SB_VS, IRS_SB_WARPED, IRS_SB_Z, IRS_SB_GM, IRS_SB_GRAD_A, IRS_SB_GRAD_B,
     IRS_SB_DENSE,      /* SVFFD: the dense velocity (V, NOISY, VS then live on the control grid, replicated on every rank) */
+    IRS_SB_GRAD_C,     /* third gradient field of the adjoint (contexts of several ranks) */
     IRS_SB_STEP0 = 16  /* + k: output of squaring step k */
 };
 enum { IRS_AR_ENERGY = 0, IRS_AR_DMAX = 1, IRS_AR_NLL = 2, IRS_AR_STATS = 3, IRS_AR_CPGRAD = 4, IRS_AR_MOMENTS = 7 };

@@ -94,7 +94,7 @@ IRS_OP_LAUNCH, IRS_OP_EXCHANGE, IRS_OP_ALLREDUCE, IRS_OP_WAIT = range(4)
 (IRS_SG_PERTURB, IRS_SG_COPY_V, IRS_SG_SMOOTH, IRS_SG_ENERGY, IRS_SG_EXP_FWD, IRS_SG_OUTPUTS, IRS_SG_WARP, IRS_SG_RESIDUAL, IRS_SG_STATS,
  IRS_SG_DATA_BWD, IRS_SG_WARP_BWD, IRS_SG_EXP_BWD, IRS_SG_UPDATE, IRS_SG_FFD_UP, IRS_SG_FFD_ADJ) = range(15)
 IRS_SG_CHAIN_SCALAR, IRS_SG_REG_SCALAR, IRS_SG_FINALIZE = 32, 33, 34
-(IRS_SB_V, IRS_SB_NOISY, IRS_SB_VS, IRS_SB_WARPED, IRS_SB_Z, IRS_SB_GM, IRS_SB_GRAD_A, IRS_SB_GRAD_B, IRS_SB_DENSE) = range(9)
+(IRS_SB_V, IRS_SB_NOISY, IRS_SB_VS, IRS_SB_WARPED, IRS_SB_Z, IRS_SB_GM, IRS_SB_GRAD_A, IRS_SB_GRAD_B, IRS_SB_DENSE, IRS_SB_GRAD_C) = range(10)
 IRS_SB_STEP0 = 16
 IRS_COMM_ID_BYTES = 128
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(IrsXfer), C.c_int, C.c_void_p)
@@ -151,7 +151,7 @@ SIGNATURES = {
     'irs_slab_gmm_init': [_P, C.POINTER(IrsIO), _P, _I, _P],
     'irs_slab_status_get': [_P, C.POINTER(IrsSlabStatus), _P],
     'irs_slab_trace': [C.POINTER(IrsConfig), C.POINTER(IrsSlabConfig), _I, _I, _I32P, C.POINTER(IrsSlabOp), _I, _I32P],
-    'irs_slab_plan_rounds': [_I32P, _I, _I, _I, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P],
+    'irs_slab_plan_rounds': [_I32P, _I, _I, _I, _I, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P],
     'irs_option_set': [_P, C.c_char_p, _I],
     'irs_last_error': [],
     'irs_version': [],

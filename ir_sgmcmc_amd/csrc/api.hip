@@ -546,6 +546,10 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     const size_t o_tmpB = take(fieldV);
     const size_t o_vs = take(fieldV);
     const size_t o_gA = take(fieldI), o_gB = take(fieldI);
+    // a z-slab of several ranks rotates the adjoint's gradient through THREE fields: a backward exchange round may then span three
+    // squaring steps (slab.hip: plan_rounds) -- held planes only, 1 / world of the volume
+    const bool third = sl && sl->on && sl->world > 1;
+    const size_t o_gC = third ? take(fieldI) : 0;
     const size_t o_warped = take(imageI), o_z = take(imageI), o_sig = take(imageI), o_fhat = take(imageI), o_gM = take(imageI);
     const size_t o_dense = take(c->ffd ? fieldI : 0);
     const size_t o_stat = take(sizeof(double) * kMaxPartialBlocks * kStatVals);
@@ -570,6 +574,7 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     c->vs = (float*)(c->slab + o_vs);
     c->gA = (float*)(c->slab + o_gA);
     c->gB = (float*)(c->slab + o_gB);
+    c->gC = third ? (float*)(c->slab + o_gC) : nullptr;
     c->warped = (float*)(c->slab + o_warped);
     c->z = (float*)(c->slab + o_z);
     c->sigM = (float*)(c->slab + o_sig);

@@ -52,7 +52,7 @@ struct irs_ctx {
     char* slab;
     size_t slab_bytes;
     // workspace views (slab mode: UNSHIFTED bases of slab-local arrays; slab.hip applies the plane shift)
-    float *steps, *tmpA, *tmpB, *vs, *gA, *gB, *warped, *z, *sigM, *fhat, *gM, *dense;
+    float *steps, *tmpA, *tmpB, *vs, *gA, *gB, *gC, *warped, *z, *sigM, *fhat, *gM, *dense;
     double *stat_partials, *energy_partials, *nll_partials;
     double *stat_sum, *energy_sum, *nll_sum;  // reduced partial sums (staged / slab path)
     unsigned* dmax;  // [no_steps + 1][C][4] max |d_k| in voxels per axis (float bits), by-product of the forward steps

@@ -42,7 +42,7 @@ struct Plan {
 //   backward  adjoint step k needs the incoming gradient AND d_k on (its output window) +- h_k.  A round [k0', k1'] (run from
 //             k1' down to k0', output of k0' on the bare slab) needs d_k on slab +- N_k, N_k = sum_{j = k0' .. k} h_j: it can
 //             only be as long as N_k <= E_k holds for all its steps -- the ghost planes of d_k the forward pass computed.
-int plan_rounds(Plan& p, int gmax, int min_slab) {
+int plan_rounds(Plan& p, int gmax, int min_slab, int nbuf = 2) {
     const int n = p.n;
     int r = 0, w = 0, k1_of[kMaxSteps];
     for (int k = 0; k < n; ++k) {
@@ -76,12 +76,21 @@ int plan_rounds(Plan& p, int gmax, int min_slab) {
                 N += p.h[k];
                 ok = N <= E[k];
             }
-            // The adjoint ping-pongs between two gradient buffers: the second step of a round writes its interior into the
-            // buffer the round's exchange carries and the first step's boundary strips still read.  That is safe for at most
-            // two steps (a third interior would reach the strips being sent) and only while the first step's strips, which
-            // read 2 h_first planes into the slab, end before the second interior begins at h_first + h_second: h_first <=
-            // h_second (tests/test_slab_schedule.py replays exactly this).
-            if (!ok || N > gmax || k1 - c0 + 1 > 2 || p.h[k1] > p.h[c0]) break;
+            // The adjoint rotates through `nbuf` gradient buffers (two; three on a slab of several ranks): step i of a round (i = 1
+            // is the top step k1) reads B_{i-1} and writes B_i, indices mod nbuf, B_0 being the buffer the round's exchange carries.
+            //  (1) B_0 is being SENT from its planes [a, a + w) until the wait: a step that writes B_0 must start beyond them -- only
+            //      the last step of the round does (its interior begins at r_m = w): at most nbuf steps.
+            //  (2) the boundary strips of step i run after all interiors and read B_{i-1} up to a + r_i + h_i (r_i = h_1 + .. + h_i);
+            //      step j = i - 1 + nbuf writes the interior of that same buffer from a + r_j on: r_i + h_i <= r_j.  For two buffers
+            //      that is h_1 <= h_2; for three h_1 <= h_2 + h_3 (tests/test_slab_schedule.py replays exactly this).
+            const int m = k1 - c0 + 1;
+            bool hazard = m > nbuf;
+            if (!hazard && m == nbuf) {  // (j = i - 1 + nbuf <= m only for i = 1)
+                int rj = 0;
+                for (int k = k1; k >= c0; --k) rj += p.h[k];
+                hazard = 2 * p.h[k1] > rj;
+            }
+            if (!ok || N > gmax || hazard) break;
             k0 = c0;
         }
         int wsum = 0;
@@ -148,10 +157,14 @@ inline float* step_buf(const irs_ctx* c, const Views& v, int k) {  // output of 
     return (fwd_lay(c, k) & 4) ? aos(raw, v) : planar(raw, v);
 }
 inline bool step_is_aos(const irs_ctx* c, int k) { return (fwd_lay(c, k) & 4) != 0; }
-// dL/d(d_last) lands in A; adjoint step n-1 writes B, the next one A, ...
+// dL/d(d_last) lands in A; adjoint step n-1 writes B, the next one C (or A again where there are only two buffers), ...
+inline int grad_slot(const irs_ctx* c, int k, bool input) {
+    const int nbuf = c->gC ? 3 : 2;
+    return (c->cfg.no_steps - k - (input ? 1 : 0)) % nbuf;
+}
 inline float* grad_raw(const irs_ctx* c, int k, bool input) {
-    const bool odd = ((c->cfg.no_steps - k) & 1) != 0;
-    return (odd == input) ? c->gA : c->gB;
+    const int slot = grad_slot(c, k, input);
+    return slot == 0 ? c->gA : (slot == 1 ? c->gB : c->gC);
 }
 
 // ---- one grouped exchange of `w` ghost planes on both sides of the slab --------------------------------------------------
@@ -211,10 +224,11 @@ struct Sched {
     static int control_points(int n, int cps) { return (int)ceil((double)(n - 1) / (double)cps) + 1 + 2; }  // utils/util.py:61-69
     Vol W(int e) const { return window(vol, s.a - (s.has_lo ? e : 0), s.b + (s.has_hi ? e : 0)); }
     int step_buf_id(int k) const { return k < 0 ? (ffd ? IRS_SB_DENSE : IRS_SB_VS) : IRS_SB_STEP0 + k; }
-    // dL/d(d_last) lands in A; adjoint step n-1 writes B, the next one A, ...
+    int nbuf_ = 2;  // gradient buffers of the adjoint (three on a slab of several ranks: plan_rounds)
+    // dL/d(d_last) lands in A; adjoint step n-1 writes B, the next one C (or A again), ...
     int grad_id(int k, bool input) const {
-        const bool odd = ((cfg.no_steps - k) & 1) != 0;
-        return (odd == input) ? IRS_SB_GRAD_A : IRS_SB_GRAD_B;
+        const int slot = (cfg.no_steps - k - (input ? 1 : 0)) % nbuf_;
+        return slot == 0 ? IRS_SB_GRAD_A : (slot == 1 ? IRS_SB_GRAD_B : IRS_SB_GRAD_C);
     }
     void launch(int stage, int k, Vol w, int in0, int in1, int reach, int out) {
         if (w.nz + w.nzb <= 0 && stage < IRS_SG_SCALARS) return;  // empty window: nothing to launch
@@ -448,9 +462,10 @@ struct Exec {
             case IRS_SB_GM: *kind = F_IMAGE; return planar(c->gM, v);
             case IRS_SB_DENSE: *kind = F_PLANAR3; return planar(c->dense, v);
             case IRS_SB_GRAD_A:
-            case IRS_SB_GRAD_B: {
+            case IRS_SB_GRAD_B:
+            case IRS_SB_GRAD_C: {
                 // the layout of a gradient buffer is that of the adjoint step that READS it next
-                float* raw = id == IRS_SB_GRAD_A ? c->gA : c->gB;
+                float* raw = id == IRS_SB_GRAD_A ? c->gA : (id == IRS_SB_GRAD_B ? c->gB : c->gC);
                 const bool a = cur_bwd_k >= 0 && cur_bwd_k < n && (bwd_lay(c, cur_bwd_k) & 2) != 0;
                 *kind = a ? F_AOS3 : F_PLANAR3;
                 return a ? aos(raw, v) : planar(raw, v);
@@ -584,7 +599,7 @@ struct Exec {
                 float sc3[3];
                 prescale_factors(c->vol, n, sc3);
                 float* g0 = grad_raw(c, 0, false);
-                float* scaled = g0 == c->gA ? c->gB : c->gA;
+                float* scaled = g0 == c->gA ? c->gB : c->gA;  // (any field other than g0)
                 launch_scale_channels(planar(g0, v), planar(scaled, v), sc3[0], sc3[1], sc3[2], C, w, st);
                 const int G[3] = {c->volv.D, c->volv.H, c->volv.W};
                 ffd_adjoint(scaled, c->tmpB, c->tmpA, C, c->vol, G, c->spl, st, w.z0, w.nz, c->sl.lo, c->sl.hi - c->sl.lo);
@@ -781,14 +796,14 @@ void slab_release(irs_ctx* c) {
 
 extern "C" {
 
-int irs_slab_plan_rounds(const int32_t* h, int n, int ghost_max, int min_slab, int32_t* fwd_round, int32_t* fwd_width,
+int irs_slab_plan_rounds(const int32_t* h, int n, int ghost_max, int min_slab, int n_buffers, int32_t* fwd_round, int32_t* fwd_width,
                          int32_t* n_fwd, int32_t* bwd_round, int32_t* bwd_width, int32_t* n_bwd) {
     if (!h || n < 1 || n > kMaxSteps || !fwd_round || !fwd_width || !n_fwd || !bwd_round || !bwd_width || !n_bwd)
         return fail("irs_slab_plan_rounds: bad arguments");
     Plan p;
     p.n = n;
     for (int k = 0; k < n; ++k) p.h[k] = h[k];
-    if (plan_rounds(p, ghost_max > 0 ? ghost_max : 4, min_slab)) return 1;
+    if (plan_rounds(p, ghost_max > 0 ? ghost_max : 4, min_slab, n_buffers >= 3 ? 3 : 2)) return 1;
     for (int k = 0; k < n; ++k) {
         fwd_round[k] = p.fr[k];
         bwd_round[k] = p.br[k];
@@ -914,7 +929,7 @@ int slab_transition_once(irs_ctx* c, const irs_io* io_in, hipStream_t st) {
     const irs_io io = shifted_io(c, io_in);
     Plan plan;
     const bool planned = c->n_enqueued >= c->exact_until && plan_widths(c, plan);
-    if (planned && plan_rounds(plan, s.gmax, s.world > 1 ? s.min_slab : 1 << 30)) return 1;
+    if (planned && plan_rounds(plan, s.gmax, s.world > 1 ? s.min_slab : 1 << 30, c->gC ? 3 : 2)) return 1;
 
     Exec ex{c, st, c->cs, io, io.v, io.curr_state ? io.curr_state : (c->ffd ? c->vs : planar(c->vs, v)), io.im_moving_warped ? io.im_moving_warped : planar(c->warped, v),
             io.residuals ? io.residuals : planar(c->z, v), planned ? &plan : nullptr, cfg.uniform_alpha > 0.0f, C};
@@ -924,6 +939,7 @@ int slab_transition_once(irs_ctx* c, const irs_io* io_in, hipStream_t st) {
     ex.in_transition = true;
     ex.planned_ = planned;
     Sched sch(s, cfg, C);
+    sch.nbuf_ = c->gC ? 3 : 2;
     sch.want_split_ = c->kn.slab_split != 0;
     sch.fuse_noise_ = c->kn.fuse_noise != 0 && !(io.sigma && io.eps);  // (sigma field AND injected noise, tests only: the two-kernel form, as in the fused engine)
     if (!c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));
@@ -1098,8 +1114,9 @@ int irs_slab_trace(const irs_config* cfg, const irs_slab_config* scfg, int rank,
     Plan plan;
     plan.n = cfg->no_steps;
     for (int k = 0; k < plan.n; ++k) plan.h[k] = h[k];
-    if (plan_rounds(plan, s.gmax, world > 1 ? s.min_slab : 1 << 30)) return 1;
+    if (plan_rounds(plan, s.gmax, world > 1 ? s.min_slab : 1 << 30, world > 1 ? 3 : 2)) return 1;
     Sched sch(s, *cfg, cfg->no_chains);
+    sch.nbuf_ = world > 1 ? 3 : 2;
     sch.fuse_noise_ = global_knobs().fuse_noise != 0;
     int energy_ar = -1;
     sch.head(true, true, plan.fw[0] > 1 ? plan.fw[0] : 1, &energy_ar);

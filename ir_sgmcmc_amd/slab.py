@@ -172,14 +172,15 @@ def plan_layout(cfg: EngineConfig, rank, world, ghost_max=0, margin=0):
     return {n: getattr(out, n) for n, _ in out._fields_}
 
 
-def plan_rounds(h, ghost_max=4, min_slab=1 << 30):
-    """exchange rounds of the squaring steps for per-step ghost widths h (pure host arithmetic; csrc/slab.hip: plan_rounds)"""
+def plan_rounds(h, ghost_max=4, min_slab=1 << 30, n_buffers=3):
+    """exchange rounds of the squaring steps for per-step ghost widths h (pure host arithmetic; csrc/slab.hip: plan_rounds);
+    n_buffers: gradient fields the adjoint rotates through (3 in a context of several ranks, 2 otherwise)"""
     lib = L.load()
     n = len(h)
     arr = lambda: (C.c_int32 * 32)()
     hh, fr, fw, br, bw = (C.c_int32 * n)(*h), arr(), arr(), arr(), arr()
     nf, nb = C.c_int32(), C.c_int32()
-    L.check(lib.irs_slab_plan_rounds(hh, n, ghost_max, min_slab, fr, fw, C.byref(nf), br, bw, C.byref(nb)))
+    L.check(lib.irs_slab_plan_rounds(hh, n, ghost_max, min_slab, n_buffers, fr, fw, C.byref(nf), br, bw, C.byref(nb)))
     return {'fwd_round': list(fr[:n]), 'fwd_width': list(fw[:nf.value]), 'bwd_round': list(br[:n]), 'bwd_width': list(bw[:nb.value])}
 
 

@@ -27,8 +27,9 @@ from ir_sgmcmc_amd.slab import plan_layout, plan_rounds, trace
 
 def test_round_plans():
     n = 12
-    for h, gmax in (([1] * n, 4), ([1] * n, 1), ([1] * 8 + [1, 2, 2, 3], 4), ([1] * 6 + [1, 1, 2, 3, 5, 9], 4), ([1] * n, 6)):
-        p = plan_rounds(h, gmax, 64)
+    for h, gmax, nbuf in (([1] * n, 4, 3), ([1] * n, 1, 3), ([1] * 8 + [1, 2, 2, 3], 4, 3), ([1] * 6 + [1, 1, 2, 3, 5, 9], 4, 3), ([1] * n, 6, 3),
+                          ([1] * n, 8, 3), ([1] * n, 12, 3), ([1] * 8 + [1, 2, 2, 3], 8, 3), ([1] * n, 4, 2), ([1] * n, 8, 2)):
+        p = plan_rounds(h, gmax, 64, nbuf)
         fr, fw, br, bw = p['fwd_round'], p['fwd_width'], p['bwd_round'], p['bwd_width']
         assert fr[0] == 0 and all(0 <= b - a <= 1 for a, b in zip(fr, fr[1:]))             # rounds in step order
         for r, w in enumerate(fw):
@@ -38,7 +39,9 @@ def test_round_plans():
         E = [sum(h[j] for j in range(k, max(j for j in range(n) if fr[j] == fr[k]) + 1)) for k in range(n)]
         for r, w in enumerate(bw):
             ks = [k for k in range(n) if br[k] == r]
-            assert w == sum(h[k] for k in ks) and len(ks) <= 2
+            assert w == sum(h[k] for k in ks) and len(ks) <= nbuf
+            if len(ks) == nbuf:  # the round's last interior writes the buffer its first step's strips still read: beyond their reach
+                assert 2 * h[max(ks)] <= w
             for k in ks:  # the ghost planes of d_k the forward pass left behind cover what the adjoint round reads
                 assert sum(h[j] for j in range(min(ks), k + 1)) <= E[k]
     with pytest.raises(L.IrsError):
@@ -202,6 +205,9 @@ def _worker(rank, world, port, q, N, h, ghost_max, loss, cps=None):
     (2, 96, [1] * 8 + [1, 2, 2, 3], 4, 'GMM', None),      # late steps with wider ghost zones
     (3, 96, [1] * 12, 4, 'SSD', None),                    # a middle rank with two neighbours
     (3, 120, [1] * 6 + [1, 1, 2, 2, 4, 7], 4, 'GMM', None),  # a single step wider than ghost_max is a round of its own
+    (2, 64, [1] * 12, 8, 'GMM', None),                    # wide forward rounds leave ghost planes for THREE-step backward rounds (three gradient fields)
+    (3, 96, [1] * 12, 12, 'SSD', None),                   # one forward round: the backward pass in rounds of three throughout
+    (2, 128, [1] * 7 + [1, 1, 2, 3, 2], 8, 'GMM', None),  # three-step rounds with unequal widths (the strips of the first step reach 2 h into the slab)
 ])
 def test_schedule_replay_over_gloo(world, N, h, ghost_max, loss, cps):
     ctx = mp.get_context('spawn')
