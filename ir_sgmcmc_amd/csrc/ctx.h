@@ -33,7 +33,7 @@ struct SlabInfo {
     int a = 0, b = 0;    // owned planes
     int lo = 0, hi = 0;  // held planes
     int margin = 0;      // ghost planes held beyond a neighbour-facing edge
-    int gmax = 4;        // widest ghost zone one exchange may carry (communication-avoiding blocks of squaring steps)
+    int gmax = 8;        // widest ghost zone one exchange may carry (communication-avoiding blocks of squaring steps)
     int min_slab = 0;    // smallest slab of any rank: a rank cannot send more planes than it owns
     bool has_lo = false, has_hi = false;  // neighbours below / above
 };

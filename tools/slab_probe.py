@@ -42,14 +42,20 @@ def _concurrent_worker(rank, world, port, q, size, loss, ghost_max, steps):
         moving = {k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'}
 
         def timeit(eng, fd, md, v):
-            for _ in range(5):
+            # (the velocity goes back to zero after every transition, in both modes: with a transport that moves nothing the ghost
+            # planes of the gradient hold garbage, the update carries it into the boundary planes of v, and a chain left to itself
+            # drifts until its ghost-width plans outgrow the held margin)
+            for i in range(5):
                 eng.transition(fd, md, v)
+                v.zero_()
             eng.flush()
+            v.zero_()
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
-            for _ in range(steps):
+            for i in range(steps):
                 eng.transition(fd, md, v)
+                v.zero_()  # (a memset of the slab-local field, < 0.5 % of a transition, in both modes)
             eng.flush()
             torch.cuda.synchronize()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
@@ -150,10 +156,12 @@ def main():
     def timeit(eng, fd, md, v):
         for _ in range(5):
             eng.transition(fd, md, v)
+            v.zero_()  # (see the concurrent mode: ghost planes that hold garbage make a chain drift)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
             eng.transition(fd, md, v)
+            v.zero_()
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t0) / args.steps
 
