@@ -643,6 +643,10 @@ void irs_destroy(irs_ctx* c) {
         if (c->ev_bwd[i]) (void)hipEventDestroy(c->ev_bwd[i]);
     for (int i = 0; i < 4; ++i)
         if (c->ra_ev[i]) (void)hipEventDestroy(c->ra_ev[i]);
+    for (int i = 0; i < 2; ++i)
+        if (c->sel_st[i]) (void)hipStreamDestroy(c->sel_st[i]);
+    for (int i = 0; i < 3; ++i)
+        if (c->sel_ev[i]) (void)hipEventDestroy(c->sel_ev[i]);
     if (c->lin.dev) (void)hipFree(c->lin.dev);
     if (c->hint) (void)hipHostFree(c->hint);
     if (c->slab) (void)hipFree(c->slab);
@@ -812,7 +816,26 @@ int irs_gmm_init(irs_ctx* c, const irs_io* io, const float* v_sample, int warm_u
 
 // One transition, enqueued.  `no_assumptions`: launch every kernel variant (nothing about max|d_k| is assumed, the transition
 // cannot end as a no-op) -- the mode of the re-runs after a failed prediction.
+// side streams / events of the tile-level variant selection, created on first use (0 on success)
+static int sel_streams(irs_ctx* c) {
+    if (c->sel_st[0]) return 0;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->sel_st[i], hipStreamNonBlocking);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->sel_ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        c->sel_st[0] = nullptr;
+        return 1;
+    }
+    return 0;
+}
+
 static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int timed, bool no_assumptions) {
+    bool capturing = false;
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        capturing = cap != hipStreamCaptureStatusNone;
+    }
     const irs_config& cfg = c->cfg;
     const int C = c->C;
     const Vol vol = c->vol, volv = c->volv;
@@ -910,14 +933,39 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
             // A step that may need more than the radius-1 gather somewhere: the variants take the TILES of their class, not whole
             // chains (a converged registration has its large displacements in a fraction of the volume).  Two small kernels first:
             // bounds of d_k per 8^3 cell, class per gather tile.
+            // (only where the step is EXPECTED to leave the radius-1 regime -- the bound the host last saw is near a voxel: a step that
+            // merely has its idle radius-2 launch pays 60 us for the bounds pass otherwise --, and not under stream capture)
             const unsigned char* cls = nullptr;
-            if (c->kn.tile_select && k >= 1 && gr == 2 && (max_radius >= 2 || !sa) && tile_select_possible(vol)) {
+            if (c->kn.tile_select && !capturing && k >= 1 && gr == 2 && (max_radius >= 2 || !sa) && !predicted_below(c, k, 0.9f) &&
+                tile_select_possible(vol) && sel_streams(c) == 0) {
                 launch_tile_select(dk, lay, cfg.no_steps, C, vol, dm, c->tile_bound, c->tile_class, st);
                 cls = c->tile_class;
             }
+            // The three variants write disjoint tiles of `out`: with the selection on they run SIDE BY SIDE (a partial launch does not
+            // fill the chip: the radius-2 tiles alone leave three quarters of it idle for their whole duration)
+            hipStream_t st2 = st, st3 = st;
+            if (cls) {
+                HIP_TRY(hipEventRecord(c->sel_ev[0], st));
+                if (max_radius >= 2) {
+                    st2 = c->sel_st[0];
+                    HIP_TRY(hipStreamWaitEvent(st2, c->sel_ev[0], 0));
+                }
+                if (!sa) {
+                    st3 = c->sel_st[1];
+                    HIP_TRY(hipStreamWaitEvent(st3, c->sel_ev[0], 0));
+                }
+            }
             launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, max_radius, sa, gscale, lay,
-                                      timed ? c->ev_bwd[2 * k + 1] : nullptr, st, cls);
-            if (!sa) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, gr, gscale, lay, c->cmm, st, cls);
+                                      timed ? c->ev_bwd[2 * k + 1] : nullptr, st, cls, st2);
+            if (!sa) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, gr, gscale, lay, c->cmm, st3, cls);
+            if (st2 != st) {
+                HIP_TRY(hipEventRecord(c->sel_ev[1], st2));
+                HIP_TRY(hipStreamWaitEvent(st, c->sel_ev[1], 0));
+            }
+            if (st3 != st) {
+                HIP_TRY(hipEventRecord(c->sel_ev[2], st3));
+                HIP_TRY(hipStreamWaitEvent(st, c->sel_ev[2], 0));
+            }
             G = out;
             cur ^= 1;
         }

@@ -1274,7 +1274,8 @@ size_t tile_select_tiles(Vol vol, int C) {  // (segments of at least 8 planes)
 
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
-                               hipEvent_t after_primary, hipStream_t st, const unsigned char* cls) {
+                               hipEvent_t after_primary, hipStream_t st, const unsigned char* cls, hipStream_t st_r2) {
+    if (!st_r2) st_r2 = st;  // (tile-level selection: the radius-2 tiles run beside the radius-1 ones on a stream of their own)
     dim3 tiles;
     int nseg;
     const bool sel = cls != nullptr && !prescale_in;
@@ -1284,7 +1285,7 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
     const int swz_env = global_knobs().swz_run;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;  // 0/1: no remap; default: one x-row of tiles per XCD run
 #define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale, lay)
-#define IRS_BWS(RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_sel_kernel<RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale, lay, cls)
+#define IRS_BWS(RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_sel_kernel<RR>), dim3(GRID), dim3(kMarchBlock), 0, (RR) == 2 ? st_r2 : st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale, lay, cls)
     const int rare = total < kRareGrid ? total : kRareGrid;
     // the radius-1 kernel first (the one the roofline is quoted on: `after_primary` brackets exactly its launch), then the
     // rarely selected radius-2 variant on the small persistent grid
