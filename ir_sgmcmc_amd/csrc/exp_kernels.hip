@@ -669,6 +669,9 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #ifndef IRS_MARCH_WAVES
 #define IRS_MARCH_WAVES 4
 #endif
+#ifndef IRS_MARCH_WAVES_R2
+#define IRS_MARCH_WAVES_R2 3  // radius-2 gather: 36 KB of LDS since round 4 -- three workgroups per CU (<= 168 VGPRs)
+#endif
 // Two round-3 experiments on the radius-1 adjoint, both measured SLOWER and not kept:
 //  * its own-term global-memory branch is dead code for max|d_k| < 1; compiled out (125 instead of 128 VGPRs) the kernel took
 //    217.5 instead of 202.0 us per launch -- the smaller kernel schedules worse;
@@ -811,7 +814,11 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     // where r = clipped sampling position - the source's own coordinate (|r| <= max|d|): every hat weight of the
     // gather is then a function of r plus a compile-time offset.  (Forming the three z weights of a source once, at commit
     // time, instead of in each of its nine gatherers was built and measured slower -- wider LDS records: DESIGN.md section 4.)
-    __shared__ float2 q_xy[NP * PN], q_zg[NP * PN], q_g[NP * PN], q_d[NP * PN];
+    // Radius 2: only d is needed across the NP planes of the ring (the corner taps of the own term); the (position, G) records
+    // are read by the gather of the CURRENT plane alone -- and R steps later by the voxel's own term, which keeps its column's
+    // record in registers meanwhile.  One slot of them instead of five: 36 instead of 78 KB, three workgroups per CU instead of two.
+    constexpr int NPQ = R == 2 ? 1 : NP;
+    __shared__ float2 q_xy[NPQ * PN], q_zg[NPQ * PN], q_g[NPQ * PN], q_d[NP * PN];
     __shared__ float q_dz[NP * PN];
     // XCD-aware tile assignment: consecutive tiles (x fastest, then y, then z-segment, then chain) stay on one L2
     const int tile_ = xcd_swizzle_runs(tile_id, (int)(tiles.x * tiles.y * tiles.z), swz_run);
@@ -913,10 +920,11 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
             const int i = slot * PN + threadIdx.x + it * kMarchBlock;
+            const int iq = R == 2 ? (int)threadIdx.x + it * kMarchBlock : i;  // (radius 2: the single slot of the (position, G) records)
             if (!zin) {  // plane outside the volume: no source there (G = 0 removes it from every gather)
-                q_xy[i] = make_float2(0.0f, 0.0f);
-                q_zg[i] = make_float2(0.0f, 0.0f);
-                q_g[i] = make_float2(0.0f, 0.0f);
+                q_xy[iq] = make_float2(0.0f, 0.0f);
+                q_zg[iq] = make_float2(0.0f, 0.0f);
+                q_g[iq] = make_float2(0.0f, 0.0f);
                 q_d[i] = make_float2(0.0f, 0.0f);
                 q_dz[i] = 0.0f;
                 continue;
@@ -934,9 +942,9 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
             const float gm_ = gs_ ? pgs[it] : 1.0f;
             const float g0 = sin_[it] ? pre[it][3] * gm_ : 0.0f, g1 = sin_[it] ? pre[it][4] * gm_ : 0.0f,
                         g2 = sin_[it] ? pre[it][5] * gm_ : 0.0f;
-            q_xy[i] = make_float2(p0 - sfx[it], p1 - sfy[it]);
-            q_zg[i] = make_float2(p2 - fs_, g2);
-            q_g[i] = make_float2(g0, g1);
+            q_xy[iq] = make_float2(p0 - sfx[it], p1 - sfy[it]);
+            q_zg[iq] = make_float2(p2 - fs_, g2);
+            q_g[iq] = make_float2(g0, g1);
             q_d[i] = make_float2(d0, d1);
             q_dz[i] = d2;
         }
@@ -948,6 +956,13 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     for (int a = 0; a < NP; ++a) {
         acc01[a] = make_float2(0.0f, 0.0f);
         acc2[a] = 0.0f;
+    }
+
+    // radius 2: this column's own (position, G) record of the planes s, s - 1, s - 2 (shifted along once per plane step)
+    float2 own_xy[R == 2 ? R + 1 : 1], own_zg[R == 2 ? R + 1 : 1], own_g[R == 2 ? R + 1 : 1];
+    if (R == 2) {
+#pragma unroll
+        for (int q = 0; q <= R; ++q) own_xy[q] = own_zg[q] = own_g[q] = make_float2(0.0f, 0.0f);
     }
 
     const int sbase = z0 - R;            // ring slot of plane s is (s - sbase) % NP
@@ -973,13 +988,25 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
             IRS_BT(3);
             __syncthreads();
             IRS_BT(4);
+            if (R == 2) {  // the record of plane s enters the column's register queue (its own term is due R steps from now)
+#pragma unroll
+                for (int q = R; q > 0; --q) {
+                    own_xy[q] = own_xy[q - 1];
+                    own_zg[q] = own_zg[q - 1];
+                    own_g[q] = own_g[q - 1];
+                }
+                const int co = (ly + R) * PX + (lx + R);
+                own_xy[0] = q_xy[co];
+                own_zg[0] = q_zg[co];
+                own_g[0] = q_g[co];
+            }
             // ---- contributions of source plane s to output planes s-R .. s+R
             if (s >= 0 && s < vol.D && col_in) {
 #pragma unroll IRS_GATHER_UNROLL_Y
                 for (int dy = 0; dy <= 2 * R; ++dy)
 #pragma unroll
                     for (int dx = 0; dx <= 2 * R; ++dx) {
-                        const int ri = PH * PN + (ly + dy) * PX + (lx + dx);
+                        const int ri = (R == 2 ? 0 : PH * PN) + (ly + dy) * PX + (lx + dx);
                         const float2 rxy = q_xy[ri];
                         // weight of source (x + dx - R, y + dy - R, s) on output (x, y, s + oo): hat(r + offset) per axis.
                         // R == 1 guarantees |r| < 1 (variant selection by the displacement bound), where
@@ -1008,8 +1035,10 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                 const int a = (PH - R + NP) % NP;
                 if (zo >= z0 && zo < z1 && col_in) {
                     const int ci = a * PN + (ly + R) * PX + (lx + R);  // plane zo sits in slot (zo - sbase) % NP == a
-                    // the sample this voxel took in the forward step: its clipped position is already in the ring
-                    const float2 pc = q_xy[ci], zg = q_zg[ci], Gc01 = q_g[ci];
+                    // the sample this voxel took in the forward step: its clipped position is already in the ring (radius 2: in
+                    // the register queue, R steps old)
+                    const float2 pc = R == 2 ? own_xy[R] : q_xy[R == 2 ? 0 : ci], zg = R == 2 ? own_zg[R] : q_zg[R == 2 ? 0 : ci],
+                                 Gc01 = R == 2 ? own_g[R] : q_g[R == 2 ? 0 : ci];
                     const float G0 = Gc01.x, G1 = Gc01.y, G2 = zg.y;
                     const float fx0 = floorf(pc.x), fy0 = floorf(pc.y), fz0 = floorf(zg.x);  // of the RELATIVE position
                     const float wx1 = __fsub_rn(pc.x, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), pc.x);
@@ -1117,7 +1146,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
 // small persistent grid that strides over the tiles, so that a launch whose variant is not selected costs ~2 us instead of
 // the dispatch of thousands of workgroups that exit at once.
 template <bool PRESCALE, int R>
-__global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp_bwd_march_kernel(
+__global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : IRS_MARCH_WAVES_R2) void exp_bwd_march_kernel(
     const float* __restrict__ G, const float* __restrict__ dk, float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
     const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int own_rest, int swz_run, dim3 tiles,
     const float* __restrict__ gscale, int lay) {
@@ -1217,7 +1246,7 @@ __global__ __launch_bounds__(kWave) void tile_class_kernel(const float* __restri
 
 // the gather variants on the tiles of their class (non-prescaled steps: k >= 1)
 template <int R>
-__global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp_bwd_march_sel_kernel(
+__global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : IRS_MARCH_WAVES_R2) void exp_bwd_march_sel_kernel(
     const float* __restrict__ G, const float* __restrict__ dk, float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
     const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int own_rest, int swz_run, dim3 tiles,
     const float* __restrict__ gscale, int lay, const unsigned char* __restrict__ cls) {
@@ -1229,7 +1258,7 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : 2) void exp
     }
 }
 
-constexpr int kRareGrid = 512;  // persistent grid of the rarely selected variants (two workgroups per CU)
+constexpr int kRareGrid = 256 * IRS_MARCH_WAVES_R2;  // persistent grid of the rarely selected radius-2 variant (what the chip holds at once)
 
 
 // launch geometry of the gather kernels; `sel`: z-segments in whole 8-plane cells, so that a 32 x 8 x 8 tile of the any-radius kernel
