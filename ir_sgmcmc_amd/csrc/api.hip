@@ -60,6 +60,7 @@ static Knobs knobs_from_env() {
     k.stats_seg = env_or("IRS_STATS_SEG", k.stats_seg);
     k.update_seg = env_or("IRS_UPDATE_SEG", k.update_seg);
     k.slab_split = env_or("IRS_SLAB_SPLIT", k.slab_split);
+    k.slab_buffers = env_or("IRS_SLAB_BUFFERS", k.slab_buffers);
     k.slab_exact = env_or("IRS_SLAB_EXACT", k.slab_exact);
     k.slab_force_h = env_or("IRS_SLAB_FORCE_H", k.slab_force_h);
     return k;
@@ -90,7 +91,7 @@ int knob_set(Knobs& k, const char* name, int value, bool on_context) {
     static const Entry table[] = {
         {"predict_variants", &Knobs::predict_variants, KN_CTX}, {"run_ahead", &Knobs::run_ahead, KN_CTX}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd, KN_CTX},
         {"energy_in_update", &Knobs::energy_in_update, KN_CTX}, {"fuse_noise", &Knobs::fuse_noise, KN_CTX}, {"recover", &Knobs::recover, KN_CTX},
-        {"slab_split", &Knobs::slab_split, KN_CTX}, {"slab_exact", &Knobs::slab_exact, KN_CTX}, {"slab_force_h", &Knobs::slab_force_h, KN_CTX}, {"tile_select", &Knobs::tile_select, KN_CTX},
+        {"slab_split", &Knobs::slab_split, KN_CTX}, {"slab_buffers", &Knobs::slab_buffers, KN_CTX}, {"slab_exact", &Knobs::slab_exact, KN_CTX}, {"slab_force_h", &Knobs::slab_force_h, KN_CTX}, {"tile_select", &Knobs::tile_select, KN_CTX},
         {"fwd_rows1", &Knobs::fwd_rows1, KN_GLOBAL}, {"coarse_box", &Knobs::coarse_box, KN_GLOBAL}, {"lds_from", &Knobs::lds_from, KN_GLOBAL},
         {"fwd_pf", &Knobs::fwd_pf, KN_GLOBAL}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1, KN_GLOBAL}, {"sobolev_tile", &Knobs::sobolev_tile, KN_GLOBAL},
         {"march_seg", &Knobs::march_seg, KN_GLOBAL}, {"march_seg_fwd", &Knobs::march_seg_fwd, KN_GLOBAL}, {"swz_run", &Knobs::swz_run, KN_GLOBAL},

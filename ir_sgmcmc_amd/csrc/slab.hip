@@ -88,8 +88,11 @@ int plan_rounds(Plan& p, int gmax, int min_slab, int nbuf = 2) {
             //  (2) the boundary strips of step i run after all interiors and read B_{i-1} up to a + r_i + h_i (r_i = h_1 + .. + h_i);
             //      step j = i - 1 + nbuf writes the interior of that same buffer from a + r_j on: r_i + h_i <= r_j.  For two buffers
             //      that is h_1 <= h_2; for three h_1 <= h_2 + h_3 (tests/test_slab_schedule.py replays exactly this).
+            //  (3) planes are only disjoint within ONE layout: adjoint step 0 writes the planar field the update reads, every other
+            //      step an interleaved one (ctx.h: bwd_lay) -- in the buffer the round's exchange carries and its first strips still
+            //      read, step 0's interior would land on other bytes than "its" planes.  It never closes a full rotation.
             const int m = k1 - c0 + 1;
-            bool hazard = m > nbuf;
+            bool hazard = m > nbuf || (c0 == 0 && m == nbuf);
             if (!hazard && m == nbuf) {  // (j = i - 1 + nbuf <= m only for i = 1)
                 int rj = 0;
                 for (int k = k1; k >= c0; --k) rj += p.h[k];
@@ -163,8 +166,9 @@ inline float* step_buf(const irs_ctx* c, const Views& v, int k) {  // output of 
 }
 inline bool step_is_aos(const irs_ctx* c, int k) { return (fwd_lay(c, k) & 4) != 0; }
 // dL/d(d_last) lands in A; adjoint step n-1 writes B, the next one C (or A again where there are only two buffers), ...
+inline int grad_buffers(const irs_ctx* c) { return c->gC && c->kn.slab_buffers >= 3 ? 3 : 2; }
 inline int grad_slot(const irs_ctx* c, int k, bool input) {
-    const int nbuf = c->gC ? 3 : 2;
+    const int nbuf = grad_buffers(c);
     return (c->cfg.no_steps - k - (input ? 1 : 0)) % nbuf;
 }
 inline float* grad_raw(const irs_ctx* c, int k, bool input) {
@@ -934,7 +938,7 @@ int slab_transition_once(irs_ctx* c, const irs_io* io_in, hipStream_t st) {
     const irs_io io = shifted_io(c, io_in);
     Plan plan;
     const bool planned = c->n_enqueued >= c->exact_until && plan_widths(c, plan);
-    if (planned && plan_rounds(plan, s.gmax, s.world > 1 ? s.min_slab : 1 << 30, c->gC ? 3 : 2)) return 1;
+    if (planned && plan_rounds(plan, s.gmax, s.world > 1 ? s.min_slab : 1 << 30, grad_buffers(c))) return 1;
 
     Exec ex{c, st, c->cs, io, io.v, io.curr_state ? io.curr_state : (c->ffd ? c->vs : planar(c->vs, v)), io.im_moving_warped ? io.im_moving_warped : planar(c->warped, v),
             io.residuals ? io.residuals : planar(c->z, v), planned ? &plan : nullptr, cfg.uniform_alpha > 0.0f, C};
@@ -944,7 +948,7 @@ int slab_transition_once(irs_ctx* c, const irs_io* io_in, hipStream_t st) {
     ex.in_transition = true;
     ex.planned_ = planned;
     Sched sch(s, cfg, C);
-    sch.nbuf_ = c->gC ? 3 : 2;
+    sch.nbuf_ = grad_buffers(c);
     sch.want_split_ = c->kn.slab_split != 0;
     sch.fuse_noise_ = c->kn.fuse_noise != 0 && !(io.sigma && io.eps);  // (sigma field AND injected noise, tests only: the two-kernel form, as in the fused engine)
     if (!c->dmax_clean) HIP_TRY(hipMemsetAsync(c->dmax, 0, sizeof(unsigned) * 4 * c->C * (n + 1), st));

@@ -41,7 +41,7 @@ def test_round_plans():
             ks = [k for k in range(n) if br[k] == r]
             assert w == sum(h[k] for k in ks) and len(ks) <= nbuf
             if len(ks) == nbuf:  # the round's last interior writes the buffer its first step's strips still read: beyond their reach
-                assert 2 * h[max(ks)] <= w
+                assert 2 * h[max(ks)] <= w and 0 not in ks   # (and never in another layout: step 0 writes a planar field)
             for k in ks:  # the ghost planes of d_k the forward pass left behind cover what the adjoint round reads
                 assert sum(h[j] for j in range(min(ks), k + 1)) <= E[k]
     with pytest.raises(L.IrsError):
@@ -75,6 +75,7 @@ class Replay:
         self.a, self.b, self.lo, self.hi = (self.lay[k] for k in ('a', 'b', 'lo', 'hi'))
         self.h = h
         self.ops = trace(cfg, rank, world, h, ghost_max=ghost_max)
+        self.layout = {}                                                        # gradient buffer -> layout of what it holds
         self.valid = {L.IRS_SB_V: {z: (-1, 0) for z in range(self.a, self.b)}}   # tag (-1, 0): the chain state as the caller handed it over   # buffer -> {plane: tensor it holds}
         self.flight = {}                                                        # exchange id -> (buf, sent planes, ghost planes, reqs, bufs)
         self.written = {}                                                       # (stage, k) -> planes written so far
@@ -109,6 +110,9 @@ class Replay:
             if buf < 0:
                 continue
             planes = self.valid.get(buf, {})
+            all_reads = reads
+            if o['stage'] == L.IRS_SG_UPDATE and which == 0:
+                reads = set(wins)  # the update reads the gradient voxel by voxel; its stencil (reach 1) is on the smoothed velocity
             assert reads <= set(planes), f'rank {self.rank}: {o} reads planes {sorted(reads - set(planes))} of buffer {buf} that were never written'
             want = self.expect_tag(o, which)
             if want is not None:
@@ -116,6 +120,7 @@ class Replay:
                 assert not wrong, f'rank {self.rank}: {o} expects tensor {want} in buffer {buf}, finds {wrong}'
             for f in self.flight.values():
                 assert not (f[0] == buf and reads & f[2]), f'rank {self.rank}: {o} reads ghost planes of buffer {buf} that are still in flight'
+            reads = all_reads
         if o['out'] >= 0 and o['stage'] < 32:
             tag = (o['stage'], o['k']) if o['stage'] != L.IRS_SG_COPY_V else (L.IRS_SG_PERTURB, 0)
             if o['stage'] == L.IRS_SG_PERTURB and o['out'] == L.IRS_SB_VS:
@@ -124,6 +129,15 @@ class Replay:
                 tag = (L.IRS_SG_SMOOTH, 0)  # (k = 1 marks the form that generates the Langevin noise while staging: same tensor)
             for f in self.flight.values():
                 assert not (f[0] == o['out'] and wins & (f[1] | f[2])), f'rank {self.rank}: {o} overwrites strips of buffer {o["out"]} in flight'
+            if o['stage'] in (L.IRS_SG_EXP_BWD, L.IRS_SG_WARP_BWD):
+                # the adjoint's fields change LAYOUT: step 0 and the backward warp write planar fields, every other step an
+                # interleaved one (csrc/ctx.h: bwd_lay).  "Plane z" of one layout is not plane z of the other: a write in the
+                # other layout clobbers whatever the buffer still held
+                lay = 'planar' if (o['stage'] == L.IRS_SG_WARP_BWD or o['k'] == 0) else 'interleaved'
+                if self.layout.get(o['out'], lay) != lay:
+                    assert not any(f[0] == o['out'] for f in self.flight.values()), f'rank {self.rank}: {o} changes the layout of a buffer in flight'
+                    self.valid[o['out']] = {}
+                self.layout[o['out']] = lay
             self.valid.setdefault(o['out'], {}).update({z: tag for z in wins})
             done = self.written.setdefault(tag, set())
             assert not (done & wins), f'rank {self.rank}: {o} writes planes {sorted(done & wins)} twice'

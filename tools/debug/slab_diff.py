@@ -1,0 +1,71 @@
+"""Where does a slab chain leave the fused engine's?  Per-plane deviation of v after T transitions (ranks sharing cuda:0 over the
+ipc transport), for a test configuration of tests/test_gpu_slab.py.
+
+    python tools/debug/slab_diff.py [--world 3] [--N 30] [--ghost-max 6] [--amp 12] [--exact 0|1] [--T 3]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def worker(rank, world, port, q, a):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ir_sgmcmc_amd.slab import SlabComm, SlabEngine
+    from tests.test_gpu_slab import _run_fused, _setup
+    torch.cuda.set_device(0)
+    comm = SlabComm.ipc()
+    cfg, fixed, moving, v0, noise = _setup(a.N, 1, 'GMM', amp=a.amp, transitions=a.T)
+    eng = SlabEngine(cfg, 'cuda:0', comm, ghost_max=a.ghost_max)
+    if a.exact:
+        eng.option('slab_exact', 1)
+    fd, md = eng.prepare(fixed, moving)
+    eng.gmm_init(fd, md)
+    v = eng.local_v(v0)
+    disp = eng.new_local(3)
+    for eps, unif in noise:
+        eng.transition(fd, md, v, None, eng.local_v(eps), eng.local(unif), {'displacement': disp})
+        st = eng.status()
+        if rank == 0:
+            print('transition done: rounds fwd', st['last_fwd_rounds'], 'bwd', st['last_bwd_rounds'], 'exact so far', st['exact_transitions'], flush=True)
+    v_full = eng.gather(v)
+    if rank == 0:
+        v_ref, d_ref, s_ref, _ = _run_fused(cfg, fixed, moving, v0, noise)
+        dev = (v_full - v_ref).abs().amax(dim=(0, 1, 3, 4)) / float(v_ref.abs().max())
+        print('per-plane max deviation of v (rel to max):')
+        for z, d in enumerate(dev.tolist()):
+            print(f'  z {z:3d}  {d:.2e}' + ('  <- slab edge' if z % (a.N // world) in (0, a.N // world - 1) else ''))
+    dist.barrier()
+    del eng
+    comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    import socket
+
+    import torch.multiprocessing as mp
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--world', type=int, default=3)
+    ap.add_argument('--N', type=int, default=30)
+    ap.add_argument('--ghost-max', type=int, default=6)
+    ap.add_argument('--amp', type=float, default=12.0)
+    ap.add_argument('--exact', type=int, default=0)
+    ap.add_argument('--T', type=int, default=3)
+    a = ap.parse_args()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=worker, args=(r, a.world, port, q, a)) for r in range(a.world)]
+    [p.start() for p in ps]
+    [p.join(200) for p in ps]
+    [p.kill() for p in ps if p.is_alive()]
