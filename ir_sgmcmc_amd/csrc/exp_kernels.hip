@@ -361,8 +361,12 @@ __global__ __launch_bounds__(kExpBlock, H == 0 ? 4 : 2) void exp_bwd_lds_kernel(
     for (int i = threadIdx.x; i < 3 * ETN; i += kExpBlock) acc[i] = 0ull;
 
     // ---- source box and the largest |G| inside it
+    // (z: the tile may stick out of the launch WINDOW -- a slab's boundary strip of a few planes.  Only sources within hz of the
+    // window's last plane can reach an output inside it; the planes beyond are not part of this exchange round and hold whatever
+    // an earlier transition left there -- a stale source with a stale, larger displacement would otherwise scatter into the strip)
+    const int zend = min(oz + ETZ, vol.z0 + vol.nz) - 1;
     int lo[3] = {max(ox - hx, 0), max(oy - hy, 0), max(oz - hz, 0)};
-    int hi[3] = {min(ox + ETX - 1 + hx, vol.W - 1), min(oy + ETY - 1 + hy, vol.H - 1), min(oz + ETZ - 1 + hz, vol.D - 1)};
+    int hi[3] = {min(ox + ETX - 1 + hx, vol.W - 1), min(oy + ETY - 1 + hy, vol.H - 1), min(zend + hz, vol.D - 1)};
     float gmax = 0.0f;
     auto block_reduce7 = [&](float (&m7)[kCmm]) {  // min over even slots < 6, max over the others; result in every thread
 #pragma unroll
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(kExpBlock, H == 0 ? 4 : 2) void exp_bwd_lds_kernel(
     if (cmm) {
         const int nax[3] = {vol.W, vol.H, vol.D};
         const int tlo[3] = {ox, oy, oz};
-        const int thi[3] = {min(ox + ETX, vol.W) - 1, min(oy + ETY, vol.H) - 1, min(oz + ETZ, vol.D) - 1};
+        const int thi[3] = {min(ox + ETX, vol.W) - 1, min(oy + ETY, vol.H) - 1, min(zend, vol.D - 1)};
         const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.D + kCell - 1) / kCell;
         const float* __restrict__ cm = cmm + (int64_t)chain * ncx * ncy * ncz * kCmm;
         // two rounds; max |G| is the one of the second round's cells, a superset of the final box: the scale may come out a power

@@ -15,6 +15,7 @@
 // floor(max|d_k|) + 1 planes; the plan of a transition comes from bounds the host has already seen (all-reduced, published
 // to pinned memory by the finalize kernel of an earlier transition) with a safety factor, and is validated on the device.
 #include <math.h>
+#include <stdio.h>
 #include <new>
 #include <vector>
 
@@ -976,6 +977,11 @@ int slab_transition_once(irs_ctx* c, const irs_io* io_in, hipStream_t st) {
     if (ex.run(sch.ops.data() + done, (int)(sch.ops.size() - done))) return 1;
     c->last_nf = plan.nf;
     c->last_nb = plan.nb;
+    if (getenv("IRS_SLAB_DEBUG") && s.rank == 0) {  // (debugging aid: the ghost widths this transition ran with)
+        fprintf(stderr, "[slab] transition %llu %s: h =", (unsigned long long)c->n_enqueued, planned ? "planned" : "exact");
+        for (int k = 0; k < n; ++k) fprintf(stderr, " %d", plan.h[k]);
+        fprintf(stderr, "\n");
+    }
     HIP_TRY(hipEventRecord(c->ra_ev[c->n_enqueued % 4], st));
     ++c->n_enqueued;
     return 0;

@@ -19,7 +19,7 @@ def worker(rank, world, port, q, a):
     from ir_sgmcmc_amd.slab import SlabComm, SlabEngine
     from tests.test_gpu_slab import _run_fused, _setup
     torch.cuda.set_device(0)
-    comm = SlabComm.ipc()
+    comm = SlabComm.create(a.transport, 'cuda:0')
     cfg, fixed, moving, v0, noise = _setup(a.N, 1, 'GMM', amp=a.amp, transitions=a.T)
     eng = SlabEngine(cfg, 'cuda:0', comm, ghost_max=a.ghost_max)
     if a.exact:
@@ -27,19 +27,33 @@ def worker(rank, world, port, q, a):
     fd, md = eng.prepare(fixed, moving)
     eng.gmm_init(fd, md)
     v = eng.local_v(v0)
-    disp = eng.new_local(3)
+    disp, gv = eng.new_local(3), eng.new_local(3)
+    hist = []
     for eps, unif in noise:
-        eng.transition(fd, md, v, None, eng.local_v(eps), eng.local(unif), {'displacement': disp})
+        eng.transition(fd, md, v, None, eng.local_v(eps), eng.local(unif), {'displacement': disp, 'grad_v': gv})
         st = eng.status()
+        hist.append((eng.gather(v), eng.gather(disp), eng.gather(gv)))
         if rank == 0:
             print('transition done: rounds fwd', st['last_fwd_rounds'], 'bwd', st['last_bwd_rounds'], 'exact so far', st['exact_transitions'], flush=True)
-    v_full = eng.gather(v)
     if rank == 0:
-        v_ref, d_ref, s_ref, _ = _run_fused(cfg, fixed, moving, v0, noise)
-        dev = (v_full - v_ref).abs().amax(dim=(0, 1, 3, 4)) / float(v_ref.abs().max())
-        print('per-plane max deviation of v (rel to max):')
-        for z, d in enumerate(dev.tolist()):
-            print(f'  z {z:3d}  {d:.2e}' + ('  <- slab edge' if z % (a.N // world) in (0, a.N // world - 1) else ''))
+        # the fused engine, transition by transition
+        from ir_sgmcmc_amd.engine import TransitionEngine
+        ref = TransitionEngine(cfg, 'cuda:0')
+        f2, m2 = ref.prepare({k: t.to('cuda:0') for k, t in fixed.items()}, {k: t.to('cuda:0') for k, t in moving.items()})
+        ref.gmm_init(f2, m2)
+        vr = v0.to('cuda:0').contiguous()
+        dr, gr = torch.zeros_like(vr), torch.zeros_like(vr)
+        edge = lambda z: '  <- slab edge' if z % (a.N // world) in (0, a.N // world - 1) else ''
+        for t, (eps, unif) in enumerate(noise):
+            ref.transition(f2, m2, vr, None, eps.to('cuda:0'), unif.to('cuda:0'), {'displacement': dr, 'grad_v': gr})
+            ref.flush()
+            print(f'--- after transition {t}: per-plane max deviation (v rel. to max | displacement [voxels] | grad_v rel. to max)')
+            dv = (hist[t][0] - vr.cpu()).abs().amax(dim=(0, 1, 3, 4)) / float(vr.abs().max())
+            dd = (hist[t][1] - dr.cpu()).abs().amax(dim=(0, 1, 3, 4))
+            dg = (hist[t][2] - gr.cpu()).abs().amax(dim=(0, 1, 3, 4)) / float(gr.abs().max())
+            for z in range(a.N):
+                if max(dv[z], dd[z], dg[z]) > 1e-5 or edge(z):
+                    print(f'  z {z:3d}  {float(dv[z]):.2e} | {float(dd[z]):.2e} | {float(dg[z]):.2e}' + edge(z))
     dist.barrier()
     del eng
     comm.close()
@@ -58,6 +72,7 @@ if __name__ == '__main__':
     ap.add_argument('--amp', type=float, default=12.0)
     ap.add_argument('--exact', type=int, default=0)
     ap.add_argument('--T', type=int, default=3)
+    ap.add_argument('--transport', default='ipc')
     a = ap.parse_args()
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
