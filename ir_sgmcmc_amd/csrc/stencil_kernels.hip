@@ -991,13 +991,6 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
         float xprev[QNOUT];
 #pragma unroll
         for (int o = 0; o < QNOUT; ++o) xprev[o] = 0.0f;
-        // The sums of ONE segment (at most a few dozen terms per thread) run in fp32 and enter the fp64 accumulators once per tile:
-        // thirteen f32 -> f64 conversions + f64 additions per voxel (half / quarter rate) were more of this kernel than the mixture
-        // it evaluates.  Fixed order, so still bitwise reproducible; the partial sums carry ~1e-7 relative rounding each, which
-        // averages out over the 10^5 .. 10^6 of them that make a total (loss terms and alpha stay within 1e-6 of the oracle).
-        float facc[NACC];
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) facc[j] = 0.0f;
         for (int zc = z0; zc < zend; ++zc) {
             const bool inseg = zc < z1;
 #pragma unroll
@@ -1009,14 +1002,14 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
                         float resp[KMAX], q[KMAX];
                         const MixEval e = mix_eval<true, KMAX>(pz[it], state, resp, q);
                         xv = e.x;
-                        facc[0] += 1.0f;
-                        facc[1] = fmaf(e.x, e.x, facc[1]);
+                        acc[0] += 1.0;
+                        acc[1] += (double)(e.x * e.x);
                         if (gmm) {
 #pragma unroll
                             for (int k = 0; k < KMAX; ++k)
                                 if (k < K) {
-                                    facc[5 + k] = fmaf(resp[k], 1.0f - q[k], facc[5 + k]);
-                                    facc[5 + KMAX + k] += resp[k];
+                                    acc[5 + k] += (double)(resp[k] * (1.0f - q[k]));
+                                    acc[5 + KMAX + k] += (double)resp[k];
                                 }
                         }
                     } else {
@@ -1034,17 +1027,15 @@ __global__ __launch_bounds__(kStBlock) void stats_march_kernel(const float* __re
                     const int yy = ly + o * QROWS;
                     const float own = X[yy * QPX + lx];
                     if (inseg) {
-                        facc[3] = fmaf(own, X[(yy + 1) * QPX + lx], facc[3]);
-                        facc[4] = fmaf(own, X[yy * QPX + lx + 1], facc[4]);
+                        acc[3] += (double)(own * X[(yy + 1) * QPX + lx]);
+                        acc[4] += (double)(own * X[yy * QPX + lx + 1]);
                     }
-                    if (zc > z0) facc[2] = fmaf(xprev[o], own, facc[2]);
+                    if (zc > z0) acc[2] += (double)(xprev[o] * own);
                     xprev[o] = own;
                 }
             }
             __syncthreads();
         }
-#pragma unroll
-        for (int j = 0; j < NACC; ++j) acc[j] += (double)facc[j];
     }
     block_sum<NACC>(acc, smem);
     if (threadIdx.x == 0) {
