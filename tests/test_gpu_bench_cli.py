@@ -48,6 +48,23 @@ def test_bench_two_ranks_ipc():
     assert '2 z-slabs' in d['config']['parallelism'] and 'peer-mapped' in d['config']['parallelism']
 
 
+def test_bench_auto_transport_survives_a_transport_that_fails():
+    """`--transport auto` is what `bench.py --gpus N` runs on a node: bring up BOTH product transports, verify and time each, keep
+    the faster.  With the ranks on one device RCCL cannot come up (it refuses two ranks per device): the run must go on with ipc,
+    say which transport carried it and what failed -- strong scaling, exit 0."""
+    d = _run(['--gpus', '2', '--size', '48', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--transport', 'auto'], {'IRS_BENCH_DEVICE': '0'})
+    assert d['scaling'] == 'strong' and d['slab']['transport'] == 'ipc'
+    assert list(d['slab']['transport_trials_ms']) == ['ipc'] and 'rccl' in d['slab_transport_failure']
+    assert 'ipc:' in d['slab']['transport_info'] and d['slab']['mispredictions'] == 0
+
+
+def test_bench_four_ranks_ipc():
+    """middle ranks with two neighbours, through the script"""
+    d = _run(['--gpus', '4', '--size', '64', '--steps', '4', '--warmup', '2', '--no-cpu-baseline'], {'IRS_BENCH_DEVICE': '0'})
+    assert d['n_gpus'] == 4 and d['scaling'] == 'strong' and d['slab']['transport'] == 'ipc'
+    assert d['slab']['planes_owned'] == 16 and d['slab']['mispredictions'] == 0 and d['value'] > 0
+
+
 def test_bench_exits_non_zero_without_a_slab_transport():
     """RCCL refuses two ranks on one device: with that the only transport asked for, the run must FAIL (a weak-scaling number must
     not pass for a point of the strong-scaling curve); --allow-chain-fallback turns it into the chain decomposition, which says
