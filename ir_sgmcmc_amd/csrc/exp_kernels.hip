@@ -1041,8 +1041,9 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                     const int ci = a * PN + (ly + R) * PX + (lx + R);  // plane zo sits in slot (zo - sbase) % NP == a
                     // the sample this voxel took in the forward step: its clipped position is already in the ring (radius 2: in
                     // the register queue, R steps old)
-                    const float2 pc = R == 2 ? own_xy[R] : q_xy[R == 2 ? 0 : ci], zg = R == 2 ? own_zg[R] : q_zg[R == 2 ? 0 : ci],
-                                 Gc01 = R == 2 ? own_g[R] : q_g[R == 2 ? 0 : ci];
+                    constexpr int OQ = R == 2 ? R : 0;  // (oldest entry of the register queue; the arrays have one entry for R = 1)
+                    const float2 pc = R == 2 ? own_xy[OQ] : q_xy[R == 2 ? 0 : ci], zg = R == 2 ? own_zg[OQ] : q_zg[R == 2 ? 0 : ci],
+                                 Gc01 = R == 2 ? own_g[OQ] : q_g[R == 2 ? 0 : ci];
                     const float G0 = Gc01.x, G1 = Gc01.y, G2 = zg.y;
                     const float fx0 = floorf(pc.x), fy0 = floorf(pc.y), fz0 = floorf(zg.x);  // of the RELATIVE position
                     const float wx1 = __fsub_rn(pc.x, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), pc.x);
