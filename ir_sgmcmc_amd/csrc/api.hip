@@ -47,7 +47,6 @@ static Knobs knobs_from_env() {
     k.fwd_pf = env_or("IRS_FWD_PF", k.fwd_pf);
     k.fwd_r2_rows1 = env_or("IRS_FWD_R2_ROWS1", k.fwd_r2_rows1);
     k.ps_rows = env_or("IRS_PS_ROWS", k.ps_rows);
-    k.tile_select = env_or("IRS_TILE_SELECT", k.tile_select);
     const char* tile = getenv("IRS_SOBOLEV_TILE");
     if (tile && *tile) k.sobolev_tile = tile[0] == 'b' ? 2 : (tile[0] == 's' ? 1 : atoi(tile));
     k.march_seg = env_or("IRS_MARCH_SEG", k.march_seg);
@@ -91,7 +90,7 @@ int knob_set(Knobs& k, const char* name, int value, bool on_context) {
     static const Entry table[] = {
         {"predict_variants", &Knobs::predict_variants, KN_CTX}, {"run_ahead", &Knobs::run_ahead, KN_CTX}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd, KN_CTX},
         {"energy_in_update", &Knobs::energy_in_update, KN_CTX}, {"fuse_noise", &Knobs::fuse_noise, KN_CTX}, {"recover", &Knobs::recover, KN_CTX},
-        {"slab_split", &Knobs::slab_split, KN_CTX}, {"slab_buffers", &Knobs::slab_buffers, KN_CTX}, {"slab_exact", &Knobs::slab_exact, KN_CTX}, {"slab_force_h", &Knobs::slab_force_h, KN_CTX}, {"tile_select", &Knobs::tile_select, KN_CTX},
+        {"slab_split", &Knobs::slab_split, KN_CTX}, {"slab_buffers", &Knobs::slab_buffers, KN_CTX}, {"slab_exact", &Knobs::slab_exact, KN_CTX}, {"slab_force_h", &Knobs::slab_force_h, KN_CTX},
         {"fwd_rows1", &Knobs::fwd_rows1, KN_GLOBAL}, {"coarse_box", &Knobs::coarse_box, KN_GLOBAL}, {"lds_from", &Knobs::lds_from, KN_GLOBAL},
         {"fwd_pf", &Knobs::fwd_pf, KN_GLOBAL}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1, KN_GLOBAL}, {"sobolev_tile", &Knobs::sobolev_tile, KN_GLOBAL},
         {"march_seg", &Knobs::march_seg, KN_GLOBAL}, {"march_seg_fwd", &Knobs::march_seg_fwd, KN_GLOBAL}, {"swz_run", &Knobs::swz_run, KN_GLOBAL},
@@ -559,8 +558,6 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     const size_t o_sums = take(sizeof(double) * (kStatVals + 2 * IRS_MAX_CHAINS));
     const size_t o_dmax = take(sizeof(unsigned) * 4 * IRS_MAX_CHAINS * 32);
     const size_t o_cmm = take(coarse_minmax_bytes(c->vol, C));
-    const size_t o_tb = take(sizeof(float) * tile_select_cells(c->vol, C));   // tile-level variant selection (exp_kernels.hip)
-    const size_t o_cls = take(tile_select_tiles(c->vol, C));
     const size_t o_state = take(sizeof(DevState));
     c->slab_bytes = off;
     if (hipMalloc((void**)&c->slab, off) != hipSuccess) {
@@ -590,8 +587,6 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     c->nll_sum = c->energy_sum + IRS_MAX_CHAINS;
     c->dmax = (unsigned*)(c->slab + o_dmax);
     c->cmm = (float*)(c->slab + o_cmm);
-    c->tile_bound = (float*)(c->slab + o_tb);
-    c->tile_class = (unsigned char*)(c->slab + o_cls);
     c->state = (DevState*)(c->slab + o_state);
 
     if (ensure_lin_tables(c->lin, D, H, W, nullptr)) {
@@ -644,10 +639,6 @@ void irs_destroy(irs_ctx* c) {
         if (c->ev_bwd[i]) (void)hipEventDestroy(c->ev_bwd[i]);
     for (int i = 0; i < 4; ++i)
         if (c->ra_ev[i]) (void)hipEventDestroy(c->ra_ev[i]);
-    for (int i = 0; i < 2; ++i)
-        if (c->sel_st[i]) (void)hipStreamDestroy(c->sel_st[i]);
-    for (int i = 0; i < 3; ++i)
-        if (c->sel_ev[i]) (void)hipEventDestroy(c->sel_ev[i]);
     if (c->lin.dev) (void)hipFree(c->lin.dev);
     if (c->hint) (void)hipHostFree(c->hint);
     if (c->slab) (void)hipFree(c->slab);
@@ -817,26 +808,8 @@ int irs_gmm_init(irs_ctx* c, const irs_io* io, const float* v_sample, int warm_u
 
 // One transition, enqueued.  `no_assumptions`: launch every kernel variant (nothing about max|d_k| is assumed, the transition
 // cannot end as a no-op) -- the mode of the re-runs after a failed prediction.
-// side streams / events of the tile-level variant selection, created on first use (0 on success)
-static int sel_streams(irs_ctx* c) {
-    if (c->sel_st[0]) return 0;
-    hipError_t e = hipSuccess;
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->sel_st[i], hipStreamNonBlocking);
-    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->sel_ev[i], hipEventDisableTiming);
-    if (e != hipSuccess) {
-        c->sel_st[0] = nullptr;
-        return 1;
-    }
-    return 0;
-}
-
 static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int timed, bool no_assumptions) {
-    bool capturing = false;
-    {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(st, &cap);
-        capturing = cap != hipStreamCaptureStatusNone;
-    }
+
     const irs_config& cfg = c->cfg;
     const int C = c->C;
     const Vol vol = c->vol, volv = c->volv;
@@ -930,43 +903,9 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
             // of the dominant kernel alone (as rocprofv3 reports it), not of the idle variants after it
             // lds_from 2: the any-radius kernel, when launched, takes every step beyond the radius-1 gather (no radius-2 gather then)
             const int gr = global_knobs().lds_from <= 2 ? 1 : 2;
-            const int max_radius = (s2 || (gr == 1 && !sa)) ? 1 : 2;
-            // A step that may need more than the radius-1 gather somewhere: the variants take the TILES of their class, not whole
-            // chains (a converged registration has its large displacements in a fraction of the volume).  Two small kernels first:
-            // bounds of d_k per 8^3 cell, class per gather tile.
-            // (only where the step is EXPECTED to leave the radius-1 regime -- the bound the host last saw is near a voxel: a step that
-            // merely has its idle radius-2 launch pays 60 us for the bounds pass otherwise --, and not under stream capture)
-            const unsigned char* cls = nullptr;
-            if (c->kn.tile_select && !capturing && k >= 1 && gr == 2 && (max_radius >= 2 || !sa) && !predicted_below(c, k, 0.9f) &&
-                tile_select_possible(vol) && sel_streams(c) == 0) {
-                launch_tile_select(dk, lay, cfg.no_steps, C, vol, dm, c->tile_bound, c->tile_class, st);
-                cls = c->tile_class;
-            }
-            // The three variants write disjoint tiles of `out`: with the selection on they run SIDE BY SIDE (a partial launch does not
-            // fill the chip: the radius-2 tiles alone leave three quarters of it idle for their whole duration)
-            hipStream_t st2 = st, st3 = st;
-            if (cls) {
-                HIP_TRY(hipEventRecord(c->sel_ev[0], st));
-                if (max_radius >= 2) {
-                    st2 = c->sel_st[0];
-                    HIP_TRY(hipStreamWaitEvent(st2, c->sel_ev[0], 0));
-                }
-                if (!sa) {
-                    st3 = c->sel_st[1];
-                    HIP_TRY(hipStreamWaitEvent(st3, c->sel_ev[0], 0));
-                }
-            }
-            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, max_radius, sa, gscale, lay,
-                                      timed ? c->ev_bwd[2 * k + 1] : nullptr, st, cls, st2);
-            if (!sa) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, gr, gscale, lay, c->cmm, st3, cls);
-            if (st2 != st) {
-                HIP_TRY(hipEventRecord(c->sel_ev[1], st2));
-                HIP_TRY(hipStreamWaitEvent(st, c->sel_ev[1], 0));
-            }
-            if (st3 != st) {
-                HIP_TRY(hipEventRecord(c->sel_ev[2], st3));
-                HIP_TRY(hipStreamWaitEvent(st, c->sel_ev[2], 0));
-            }
+            launch_exp_step_bwd_march(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, (s2 || (gr == 1 && !sa)) ? 1 : 2, sa, gscale, lay,
+                                      timed ? c->ev_bwd[2 * k + 1] : nullptr, st);
+            if (!sa) launch_exp_step_bwd_lds(G, dk, out, k == 0, cfg.no_steps, C, vol, lin, dm, 2, gr, gscale, lay, c->cmm, st);
             G = out;
             cur ^= 1;
         }

@@ -97,7 +97,6 @@ struct Knobs {
     int ps_rows = 0;           // IRS_PS_ROWS           fused perturbation + smoothing: rows per tile, 0: 16 with a sigma field, 32 without; 16 / 32
     int march_seg = 0, march_seg_fwd = 0, swz_run = -1, seg_min_blocks = 0, seg_min_len = 0;  // IRS_MARCH_SEG, _FWD, IRS_SWZ_RUN, IRS_SEG_MIN_*
     int sobolev_seg = 0, lcc_seg = 0, stats_seg = 0, update_seg = 0;                          // IRS_*_SEG
-    int tile_select = 0;       // IRS_TILE_SELECT       adjoint variants chosen per gather tile, not per chain, where max|d_k| is expected to reach a voxel (measured slower, twice: DESIGN.md section 4)
     int slab_buffers = 3;      // IRS_SLAB_BUFFERS      gradient fields the adjoint of a multi-rank slab rotates through (2: rounds of at most two steps)
     int slab_split = 1;        // IRS_SLAB_SPLIT        interior / boundary split around an exchange
     int slab_exact = 0;        // IRS_SLAB_EXACT        every transition in measuring mode

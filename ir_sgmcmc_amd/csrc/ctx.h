@@ -56,10 +56,6 @@ struct irs_ctx {
     double *stat_partials, *energy_partials, *nll_partials;
     double *stat_sum, *energy_sum, *nll_sum;  // reduced partial sums (staged / slab path)
     unsigned* dmax;  // [no_steps + 1][C][4] max |d_k| in voxels per axis (float bits), by-product of the forward steps
-    float* tile_bound;          // per 8^3 cell: max over axes of |d_k| in voxels  } tile-level variant selection of the
-    unsigned char* tile_class;  // per gather tile: floor(local bound) + 1           } adjoint (exp_kernels.hip)
-    hipStream_t sel_st[2];      // ... whose radius-2 and any-radius tiles run beside the radius-1 ones: two side streams,
-    hipEvent_t sel_ev[3];       // forked from / joined into the caller's stream by events (created on first use)
     float* cmm;      // coarse (8^3 cells) min / max of d_k for the source boxes of the any-radius adjoint (kernels.h)
     unsigned* hint = nullptr;  // pinned host copy of dmax as of the last finished transition (written by finalize_kernel, read
                      // by the host WITHOUT synchronisation: a hint that only decides which variants are launched)

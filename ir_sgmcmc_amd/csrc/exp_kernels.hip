@@ -71,12 +71,7 @@ __device__ __forceinline__ void atomic_max_nonneg(unsigned* addr, float v) {
 struct TileGrid {
     int ntx, nty, ntz, total;  // tiles per axis, total over all chains
 };
-// tile-level variant selection (further down: tile_class_kernel): class of every gather tile (32 x 8 columns x one z-segment of
-// seg_len planes -- a multiple of the any-radius kernel's 8-plane tiles), x fastest, then y, then segment, then chain; cls == nullptr: off
-struct TileSel {
-    const unsigned char* cls;
-    int seg_len, nseg, ntx, nty;
-};
+
 constexpr int kExpGridCap = 1024;  // also bounds the cost of a variant that is launched but not selected
 
 template <int H>
@@ -315,7 +310,7 @@ __global__ __launch_bounds__(kExpBlock, H == 0 ? 4 : 2) void exp_bwd_lds_kernel(
                                                                 float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
                                                                 const unsigned* __restrict__ dmax, TileGrid tg,
                                                                 int gather_radius, const float* __restrict__ gscale, int lay,
-                                                                const float* __restrict__ cmm, TileSel sel) {
+                                                                const float* __restrict__ cmm) {
     using B = ExpBox<H>;
     const Lay3 LD = lay3(lay & 1, vol.V), LG = lay3(lay & 2, vol.V), LO = lay3(lay & 4, vol.V);
     constexpr bool STAGED = H > 0;  // H = 0: no staged copy of d at all (sources and taps are far from the tile anyway)
@@ -349,8 +344,6 @@ __global__ __launch_bounds__(kExpBlock, H == 0 ? 4 : 2) void exp_bwd_lds_kernel(
     const int hy = (int)floorf(__uint_as_float(dmax[chain * 4 + 1])) + 1;
     const int hz = (int)floorf(__uint_as_float(dmax[chain * 4 + 2])) + 1;
     if (hx <= gather_radius && hy <= gather_radius && hz <= gather_radius) continue;  // a gather kernel owns this chain
-    // ... or this tile: every source that reaches the gather tile around these outputs stays within `gather_radius` voxels
-    if (sel.cls && sel.cls[ox / ETX + sel.ntx * (oy / ETY + sel.nty * (chain * sel.nseg + (oz - vol.z0) / sel.seg_len))] <= gather_radius) continue;
     const int64_t V = vol.V;
     const int64_t cb = (int64_t)chain * 3 * V;
     const float* c0 = dk + cb;
@@ -594,27 +587,19 @@ size_t coarse_minmax_bytes(Vol vol, int C) {
     return sizeof(float) * kCmm * (size_t)C * ((vol.W + kCell - 1) / kCell) * ((vol.H + kCell - 1) / kCell) * ((vol.D + kCell - 1) / kCell);
 }
 
-static int bwd_march_geometry(Vol vol, int C, bool sel, dim3* tiles, int* nseg_out);  // (with the gather kernels, below)
-
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
                              Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, int lay,
-                             float* cmm, hipStream_t st, const unsigned char* cls) {
+                             float* cmm, hipStream_t st) {
     if (vol.nzb > 0) {  // two windows (slab boundary strips): this rarely selected kernel takes them one launch each
         launch_exp_step_bwd_lds(G, dk, gout, prescale_in, no_steps, C, window(vol, vol.z0, vol.z0 + vol.nz), lin, dmax, halo,
-                                gather_radius, gscale, lay, cmm, st, nullptr);
+                                gather_radius, gscale, lay, cmm, st);
         launch_exp_step_bwd_lds(G, dk, gout, prescale_in, no_steps, C, window(vol, vol.z0b, vol.z0b + vol.nzb), lin, dmax, halo,
-                                gather_radius, gscale, lay, cmm, st, nullptr);
+                                gather_radius, gscale, lay, cmm, st);
         return;
     }
     TileGrid tz;
     (void)exp_grid(vol, C, &tz);
-    TileSel sel{nullptr, 1, 1, 1, 1};
-    if (cls && !prescale_in) {  // the same geometry the gather kernels of this step were launched with
-        dim3 mt;
-        int mnseg;
-        const int mseg = bwd_march_geometry(vol, C, true, &mt, &mnseg);
-        sel = TileSel{cls, mseg, mnseg, (int)mt.x, (int)mt.y};
-    }
+
     const Scale3L sc = make_scale_l(vol, no_steps);
     if (!global_knobs().coarse_box) cmm = nullptr;  // parity test of the two source boxes
     if (cmm) {  // coarse displacement extrema / gradient maxima (coarse_minmax_bytes(vol, C) of scratch)
@@ -637,7 +622,7 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
                 resident = kExpGridCap;                                                                                          \
         }                                                                                                                        \
         const dim3 g_((unsigned)(tz.total < resident ? tz.total : resident));                                                    \
-        hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), g_, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay, cmm, sel); \
+        hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), g_, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay, cmm); \
     } while (0)
     // With the gather variants in front (gather_radius >= 2) the staged box of d around the tile is of little use (sources
     // and taps are far away): H = 0 stages nothing (49 KB of accumulators instead of 111 KB of LDS -> three workgroups per CU)
@@ -809,8 +794,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                                                    float* __restrict__ gout, const Vol vol, const Lin lin, const Scale3L sc,
                                                    const unsigned* __restrict__ dmax, const int seg_len, const int nseg,
                                                    const int r_lo, const int own_rest, const int swz_run, const int tile_id,
-                                                   const dim3 tiles, const float* __restrict__ gscale, const int lay,
-                                                   const int hs_tile = 0) {
+                                                   const dim3 tiles, const float* __restrict__ gscale, const int lay) {
     using M = March<PRESCALE, R>;
     constexpr int NP = M::NP, PX = M::PX, PN = M::PN, NIT = M::NIT;
     // ring slot layout (9 floats per source, 8-byte fields so that the gather needs three ds_read_b64 per candidate):
@@ -828,10 +812,8 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
     const int tile_ = xcd_swizzle_runs(tile_id, (int)(tiles.x * tiles.y * tiles.z), swz_run);
     const int tbx = tile_ % tiles.x, tby = (tile_ / tiles.x) % tiles.y, tbz = tile_ / (tiles.x * tiles.y);
     const int chain = tbz / nseg, seg = tbz % nseg;
-    // hs_tile > 0 (exp_bwd_march_sel_kernel): the bound of THIS tile's sources instead of the chain's (a literal 0 everywhere else)
-    const int hs = hs_tile > 0 ? hs_tile
-                               : max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
-                                     (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
+    const int hs = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
+                       (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
     if (hs <= r_lo || (hs > R && !(R == 2 && own_rest))) return;  // another variant of this step owns the chain
     const int ox = tbx * MTX, oy = tby * MTY;
     int z0, z1;
@@ -1161,114 +1143,12 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : IRS_MARCH_W
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Variant selection PER TILE.  Which adjoint variant a squaring step needs follows max|d_k|: radius-1 gather below one voxel,
-// radius-2 gather below two, the any-radius scatter above.  Decided per CHAIN (the bound the forward step publishes), one region
-// of large displacement sends the whole volume to the slow variants -- and a registered image pair is exactly that: a smooth
-// field whose largest displacements sit in a fraction of the volume (a chain started 6 voxels away ran 21 % behind the
-// identity start).  So, for a step whose chain bound is >= 1 voxel:
-//   tile_bound_kernel   max over axes of |d_k| [voxels] per 8^3 cell (one pass over d_k: 201 MB at 256^3);
-//   tile_class_kernel   per gather tile (32 x 8 columns x one z-segment): hs = floor(max over the cells meeting tile +- H) + 1, H the
-//                       chain's hs.  Every source that reaches the tile lies within H of it; if all of THOSE stay below R voxels
-//                       they lie within R of it -- the radius-R gather is exact for that tile (and its own-voxel term, whose taps
-//                       stay within its own |d|);
-//   the three variants then take the tiles of their class instead of whole chains (exp_bwd_march_sel_kernel<R>; the any-radius
-//   kernel looks its 32 x 8 x 8 tiles up in the same map).  A deterministic function of d_k: results stay bitwise reproducible.
-// Single-window launches only (the fused engine); the z-slab schedule keeps the per-chain decision.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tile_bound_kernel(const float* __restrict__ dk, int aos, Vol vol, Scale3L sc, float* __restrict__ tb,
-                                                         int ncx, int ncy, int ncz) {
-    __shared__ float part[4][256];
-    const int cy = blockIdx.x, cz = blockIdx.y, chain = blockIdx.z;
-    const Lay3 LD = lay3(aos, vol.V);
-    const float* __restrict__ c0 = dk + (int64_t)chain * 3 * vol.V;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const float s0 = 0.5f * sc.nm1[0], s1 = 0.5f * sc.nm1[1], s2 = 0.5f * sc.nm1[2];
-    for (int xc = 0; xc < vol.W; xc += kWave) {
-        const int x = xc + lane;
-        float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
-        if (x < vol.W)
-            for (int r = wave; r < kCell * kCell; r += 4) {
-                const int y = cy * kCell + (r & (kCell - 1)), z = vol.z0 + cz * kCell + r / kCell;
-                if (y >= vol.H || z >= vol.z0 + vol.nz) continue;
-                const int64_t g = ((int64_t)z * vol.H + y) * vol.W + x;
-                float a, b, c;
-                if (LD.em == 3) {
-                    const F3 v = ld3g(c0 + g * 3);
-                    a = v.x;
-                    b = v.y;
-                    c = v.z;
-                } else {
-                    a = c0[g];
-                    b = c0[LD.cs + g];
-                    c = c0[2 * LD.cs + g];
-                }
-                m0 = fmaxf(m0, fabsf(a));
-                m1 = fmaxf(m1, fabsf(b));
-                m2 = fmaxf(m2, fabsf(c));
-            }
-        // the forward step's own arithmetic for its bound: max |d_a| first, then * (0.5 (n_a - 1))
-        float m = fmaxf(fmaxf(m0 * s0, m1 * s1), m2 * s2);
-        m = fmaxf(m, __shfl_xor(m, 1, kWave));
-        m = fmaxf(m, __shfl_xor(m, 2, kWave));
-        m = fmaxf(m, __shfl_xor(m, 4, kWave));
-        if ((lane & 7) == 0) part[wave][(xc >> 3) + (lane >> 3)] = m;
-    }
-    __syncthreads();
-    for (int cx = threadIdx.x; cx < ncx; cx += blockDim.x)
-        tb[(((int64_t)chain * ncz + cz) * ncy + cy) * ncx + cx] = fmaxf(fmaxf(part[0][cx], part[1][cx]), fmaxf(part[2][cx], part[3][cx]));
-}
-
-// one wavefront per gather tile (logical tile index: x fastest, then y, then z-segment, then chain)
-__global__ __launch_bounds__(kWave) void tile_class_kernel(const float* __restrict__ tb, const unsigned* __restrict__ dmax, Vol vol, int ncx,
-                                                           int ncy, int ncz, int seg_len, int nseg, dim3 tiles,
-                                                           unsigned char* __restrict__ cls) {
-    const int t = blockIdx.x;
-    const int tbx = t % tiles.x, tby = (t / tiles.x) % tiles.y, tbz = t / (tiles.x * tiles.y);
-    const int chain = tbz / nseg, seg = tbz % nseg;
-    const int H = max(max((int)floorf(__uint_as_float(dmax[chain * 4 + 0])), (int)floorf(__uint_as_float(dmax[chain * 4 + 1]))),
-                      (int)floorf(__uint_as_float(dmax[chain * 4 + 2]))) + 1;
-    if (H <= 1) {  // the whole chain stays below one voxel
-        if (threadIdx.x == 0) cls[t] = 1;
-        return;
-    }
-    int z0, z1;
-    seg_range(vol, seg, seg_len, z0, z1);
-    const int ox = tbx * MTX, oy = tby * MTY;
-    const int x0 = max(ox - H, 0) / kCell, x1 = min(ox + MTX - 1 + H, vol.W - 1) / kCell;
-    const int y0 = max(oy - H, 0) / kCell, y1 = min(oy + MTY - 1 + H, vol.H - 1) / kCell;
-    const int c0 = max(z0 - H - vol.z0, 0) / kCell, c1 = min(z1 - 1 + H - vol.z0, vol.nz - 1) / kCell;
-    const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, n = nx * ny * (c1 - c0 + 1);
-    float m = 0.0f;
-    for (int i = threadIdx.x; i < n; i += kWave) {
-        const int ix = i % nx, iy = (i / nx) % ny, iz = i / (nx * ny);
-        m = fmaxf(m, tb[(((int64_t)chain * ncz + c0 + iz) * ncy + y0 + iy) * ncx + x0 + ix]);
-    }
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
-    if (threadIdx.x == 0) cls[t] = (unsigned char)min((int)floorf(m) + 1, 255);
-}
-
-// the gather variants on the tiles of their class (non-prescaled steps: k >= 1)
-template <int R>
-__global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : IRS_MARCH_WAVES_R2) void exp_bwd_march_sel_kernel(
-    const float* __restrict__ G, const float* __restrict__ dk, float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
-    const unsigned* __restrict__ dmax, int seg_len, int nseg, int r_lo, int own_rest, int swz_run, dim3 tiles,
-    const float* __restrict__ gscale, int lay, const unsigned char* __restrict__ cls) {
-    const int total = (int)(tiles.x * tiles.y * tiles.z);
-    for (int id = blockIdx.x; id < total; id += gridDim.x) {
-        const int c = cls[xcd_swizzle_runs(id, total, swz_run)];  // (the tile function applies the same remap to `id`)
-        const bool mine = R == 1 ? c <= 1 : (own_rest ? c >= 2 : c == 2);
-        if (mine) exp_bwd_march_tile<false, R>(G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, r_lo, own_rest, swz_run, id, tiles, gscale, lay, c);
-    }
-}
-
 constexpr int kRareGrid = 256 * IRS_MARCH_WAVES_R2;  // persistent grid of the rarely selected radius-2 variant (what the chip holds at once)
 
 
-// launch geometry of the gather kernels; `sel`: z-segments in whole 8-plane cells, so that a 32 x 8 x 8 tile of the any-radius kernel
-// lies inside ONE gather tile (tile-level variant selection)
-static int bwd_march_geometry(Vol vol, int C, bool sel, dim3* tiles, int* nseg_out) {
+void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
+                               Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
+                               hipEvent_t after_primary, hipStream_t st) {
     const int seg_env = global_knobs().march_seg;
     const int64_t per_layer = (int64_t)((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * C;
     int seg_len = pick_seg_len(vol.nz + vol.nzb, per_layer, 8, seg_env);
@@ -1277,62 +1157,22 @@ static int bwd_march_geometry(Vol vol, int C, bool sel, dim3* tiles, int* nseg_o
         const int64_t res = resident_blocks((const void*)exp_bwd_march_kernel<false, 1>, kMarchBlock, &cache);
         if (res > 0) seg_len = pick_seg_len_fit(vol.nz, vol.nzb, per_layer, 8, 2, res, 0);
     }
-    if (sel && seg_len % kCell) seg_len = seg_len > kCell ? seg_len / kCell * kCell : kCell;
     const int nseg = vol_nseg(vol, seg_len);  // segments of both windows
-    *tiles = dim3((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
-    *nseg_out = nseg;
-    return seg_len;
-}
-
-bool tile_select_possible(Vol vol) { return vol.nzb == 0 && vol.W <= 2048; }
-
-// bounds per 8^3 cell of d_k (a non-prescaled step: k >= 1) and the class of every gather tile (see above); tb: C * cells floats,
-// cls: C * tiles bytes
-void launch_tile_select(const float* dk, int lay, int no_steps, int C, Vol vol, const unsigned* dmax, float* tb, unsigned char* cls,
-                        hipStream_t st) {
-    dim3 tiles;
-    int nseg;
-    const int seg_len = bwd_march_geometry(vol, C, true, &tiles, &nseg);
-    const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.nz + kCell - 1) / kCell;
-    const Scale3L sc = make_scale_l(vol, no_steps);
-    hipLaunchKernelGGL(tile_bound_kernel, dim3(ncy, ncz, C), dim3(256), 0, st, dk, lay & 1, vol, sc, tb, ncx, ncy, ncz);
-    hipLaunchKernelGGL(tile_class_kernel, dim3(tiles.x * tiles.y * tiles.z), dim3(kWave), 0, st, (const float*)tb, dmax, vol, ncx, ncy, ncz, seg_len,
-                       nseg, tiles, cls);
-}
-size_t tile_select_cells(Vol vol, int C) {
-    return (size_t)C * ((vol.W + kCell - 1) / kCell) * ((vol.H + kCell - 1) / kCell) * ((vol.D + kCell - 1) / kCell);
-}
-size_t tile_select_tiles(Vol vol, int C) {  // (segments of at least 8 planes)
-    return (size_t)C * ((vol.W + MTX - 1) / MTX) * ((vol.H + MTY - 1) / MTY) * ((vol.D + kCell - 1) / kCell + 1);
-}
-
-void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
-                               Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
-                               hipEvent_t after_primary, hipStream_t st, const unsigned char* cls, hipStream_t st_r2) {
-    if (!st_r2) st_r2 = st;  // (tile-level selection: the radius-2 tiles run beside the radius-1 ones on a stream of their own)
-    dim3 tiles;
-    int nseg;
-    const bool sel = cls != nullptr && !prescale_in;
-    const int seg_len = bwd_march_geometry(vol, C, sel, &tiles, &nseg);
+    const dim3 tiles((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     const Scale3L sc = make_scale_l(vol, no_steps);
     const int swz_env = global_knobs().swz_run;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;  // 0/1: no remap; default: one x-row of tiles per XCD run
 #define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale, lay)
-#define IRS_BWS(RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_sel_kernel<RR>), dim3(GRID), dim3(kMarchBlock), 0, (RR) == 2 ? st_r2 : st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale, lay, cls)
     const int rare = total < kRareGrid ? total : kRareGrid;
     // the radius-1 kernel first (the one the roofline is quoted on: `after_primary` brackets exactly its launch), then the
     // rarely selected radius-2 variant on the small persistent grid
-    if (sel) IRS_BWS(1, 0, total);
-    else if (prescale_in) IRS_BWM(true, 1, 0, total); else IRS_BWM(false, 1, 0, total);
+    if (prescale_in) IRS_BWM(true, 1, 0, total); else IRS_BWM(false, 1, 0, total);
     if (after_primary) (void)hipEventRecord(after_primary, st);
     if (max_radius >= 2) {
-        // (tile-level selection: the radius-2 tiles are a fraction of the volume wherever they are -- a grid that fills the chip)
-        if (sel) IRS_BWS(2, 1, total < 4 * kRareGrid ? total : 4 * kRareGrid);
-        else if (prescale_in) IRS_BWM(true, 2, 1, rare); else IRS_BWM(false, 2, 1, rare);
+        if (prescale_in) IRS_BWM(true, 2, 1, rare); else IRS_BWM(false, 2, 1, rare);
     }
 #undef IRS_BWM
-#undef IRS_BWS
 }
 
 // ------------------------------------------------------------------------------------------------

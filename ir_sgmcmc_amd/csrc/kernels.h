@@ -55,21 +55,13 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale, int
 // the work, chosen on the device from the bound max|d_k|
 void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
                                Lin lin, const unsigned* dmax, int max_radius, bool r2_owns_rest, const float* gscale, int lay,
-                               hipEvent_t after_primary, hipStream_t st, const unsigned char* cls = nullptr, hipStream_t st_r2 = nullptr);
-// Tile-level variant selection (exp_kernels.hip): for a step whose chain bound max|d_k| reaches one voxel the three adjoint variants
-// take the TILES of their class instead of whole chains.  launch_tile_select fills tb (tile_select_cells floats) and cls
-// (tile_select_tiles bytes) from d_k; cls is then handed to the two launchers of the step.  Single-window launches, k >= 1.
-bool tile_select_possible(Vol vol);
-size_t tile_select_cells(Vol vol, int C);
-size_t tile_select_tiles(Vol vol, int C);
-void launch_tile_select(const float* dk, int lay, int no_steps, int C, Vol vol, const unsigned* dmax, float* tb, unsigned char* cls,
-                        hipStream_t st);
+                               hipEvent_t after_primary, hipStream_t st);
 // cmm: scratch of coarse_minmax_bytes(vol, C) for the per-cell displacement extrema (nullptr: sources are bounded by the
 // global bound around the tile only -- correct, slow for large displacements)
 size_t coarse_minmax_bytes(Vol vol, int C);
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale, int no_steps, int C, Vol vol,
                              Lin lin, const unsigned* dmax, int halo, int gather_radius, const float* gscale, int lay,
-                             float* cmm, hipStream_t st, const unsigned char* cls = nullptr);
+                             float* cmm, hipStream_t st);
 void launch_field_absmax(const float* d, bool prescale, int no_steps, unsigned* dmax, int C, Vol vol, hipStream_t st);
 
 // ---- data_kernels.hip
