@@ -12,8 +12,12 @@ sys.path.insert(0, ROOT)
 
 
 def worker(rank, world, port, q, a):
+    import faulthandler
+    import time
     import torch
     import torch.distributed as dist
+    faulthandler.dump_traceback_later(a.watchdog, exit=True)  # a rank that stops making progress says where
+    t_start = time.perf_counter()
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from ir_sgmcmc_amd.slab import SlabComm, SlabEngine
@@ -31,10 +35,14 @@ def worker(rank, world, port, q, a):
     hist = []
     for eps, unif in noise:
         eng.transition(fd, md, v, None, eng.local_v(eps), eng.local(unif), {'displacement': disp, 'grad_v': gv})
+        if a.final_only and len(hist) + 1 < len(noise):
+            hist.append(None)   # (soak runs: thousands of exchanges back to back, nothing synchronises in between)
+            continue
         st = eng.status()
         hist.append((eng.gather(v), eng.gather(disp), eng.gather(gv)))
         if rank == 0:
-            print('transition done: rounds fwd', st['last_fwd_rounds'], 'bwd', st['last_bwd_rounds'], 'exact so far', st['exact_transitions'], flush=True)
+            print(f'[{time.perf_counter() - t_start:7.2f} s] transition done: rounds fwd', st['last_fwd_rounds'], 'bwd', st['last_bwd_rounds'], 'exact so far', st['exact_transitions'],
+                  'mispredictions', st['mispredictions'], flush=True)
     if rank == 0:
         # the fused engine, transition by transition
         from ir_sgmcmc_amd.engine import TransitionEngine
@@ -47,6 +55,8 @@ def worker(rank, world, port, q, a):
         for t, (eps, unif) in enumerate(noise):
             ref.transition(f2, m2, vr, None, eps.to('cuda:0'), unif.to('cuda:0'), {'displacement': dr, 'grad_v': gr})
             ref.flush()
+            if hist[t] is None:
+                continue
             print(f'--- after transition {t}: per-plane max deviation (v rel. to max | displacement [voxels] | grad_v rel. to max)')
             dv = (hist[t][0] - vr.cpu()).abs().amax(dim=(0, 1, 3, 4)) / float(vr.abs().max())
             dd = (hist[t][1] - dr.cpu()).abs().amax(dim=(0, 1, 3, 4))
@@ -73,6 +83,8 @@ if __name__ == '__main__':
     ap.add_argument('--exact', type=int, default=0)
     ap.add_argument('--T', type=int, default=3)
     ap.add_argument('--transport', default='ipc')
+    ap.add_argument('--watchdog', type=int, default=150)
+    ap.add_argument('--final-only', type=int, default=0, help='compare after the last transition only (soak run)')
     a = ap.parse_args()
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
