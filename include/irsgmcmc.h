@@ -303,6 +303,9 @@ typedef int (*irs_exchange_fn)(void* user, const irs_xfer* xfers, int n, void* s
 typedef int (*irs_allreduce_fn)(void* user, void* buf, size_t count, int kind, void* stream); /* 0 SUM f64 | 1 MAX u32 | 2 SUM f32 */
 int irs_comm_create_callbacks(irs_exchange_fn ex, irs_allreduce_fn ar, void* user, int rank, int world, irs_comm** out);
 void irs_comm_destroy(irs_comm* comm);
+/* timing hook: `iters` neighbour exchanges of `bytes` (a multiple of 16) per direction and link, then `iters` all-reduces of
+ * `ar_doubles` doubles, back to back; usec[0] / usec[1] = host-timed microseconds per exchange / per all-reduce. collective, blocking. */
+int irs_comm_probe(irs_comm* comm, size_t bytes, size_t ar_doubles, int iters, void* stream, double usec[2]);
 /* one line about the transport (kind, ranks; ipc: size and kind of the landing area, traffic so far) for logs */
 int irs_comm_describe(const irs_comm* comm, char* out, size_t n);
 int irs_comm_rank(const irs_comm* comm);

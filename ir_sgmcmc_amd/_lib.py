@@ -140,6 +140,7 @@ SIGNATURES = {
     'irs_comm_create_ipc': [C.c_char_p, _I, _I, C.POINTER(_P)],
     'irs_comm_create_callbacks': [EXCHANGE_FN, ALLREDUCE_FN, _P, _I, _I, C.POINTER(_P)],
     'irs_comm_destroy': [_P],
+    'irs_comm_probe': [_P, C.c_size_t, C.c_size_t, _I, _P, C.POINTER(C.c_double * 2)],
     'irs_comm_describe': [_P, C.c_char_p, C.c_size_t],
     'irs_comm_rank': [_P],
     'irs_comm_world': [_P],

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <stdio.h>
+#include <time.h>
 
 #include "comm.h"
 #include "ctx.h"
@@ -265,6 +266,54 @@ int irs_comm_selftest(irs_comm* c, void* stream) {
             if (has_hi && rh[i] != (double)(c->rank + 2 + pass) * (i + 1)) return done(fail("selftest pass %d: exchange with rank %d wrong at %d", pass, c->rank + 1, i));
         }
     }
+    return done(0);
+}
+
+// Timing hook (tools/comm_probe.py): `iters` grouped neighbour exchanges of `bytes` per direction and link, then `iters` all-reduces of
+// `ar_doubles` doubles, back to back on `stream`, host-timed around a stream synchronisation: what ONE hand-over of the transport costs
+// when nothing else runs (the software part of an exchange; on a node the wire time comes on top).  usec[0]: per exchange, usec[1]:
+// per all-reduce.  Collective, blocking.
+int irs_comm_probe(irs_comm* c, size_t bytes, size_t ar_doubles, int iters, void* stream, double usec[2]) {
+    if (!c || !usec || iters < 1 || (bytes & 15u)) return fail("irs_comm_probe: bad arguments (bytes a multiple of 16)");
+    hipStream_t st = (hipStream_t)stream;
+    if (comm_reserve(c, bytes, ar_doubles * sizeof(double))) return 1;
+    char* dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&dev, 4 * bytes + (ar_doubles + 1) * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(dev, 0, 4 * bytes + (ar_doubles + 1) * sizeof(double), st));
+    auto done = [&](int code) {
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(dev);
+        return code;
+    };
+    const bool has_hi = c->rank + 1 < c->world, has_lo = c->rank > 0;
+    irs_xfer x[4];
+    int m = 0;
+    if (has_hi) {
+        x[m++] = irs_xfer{dev, bytes, c->rank + 1, 0};
+        x[m++] = irs_xfer{dev + bytes, bytes, c->rank + 1, 1};
+    }
+    if (has_lo) {
+        x[m++] = irs_xfer{dev + 2 * bytes, bytes, c->rank - 1, 0};
+        x[m++] = irs_xfer{dev + 3 * bytes, bytes, c->rank - 1, 1};
+    }
+    double* ar = (double*)(dev + 4 * bytes);
+    auto now = []() {
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        return 1e6 * (double)t.tv_sec + 1e-3 * (double)t.tv_nsec;
+    };
+    for (int phase = 0; phase < 2; ++phase) {
+        for (int warm = 0; warm < 2; ++warm) {  // one untimed round first
+            if (hipStreamSynchronize(st) != hipSuccess) return done(fail("irs_comm_probe: stream failed"));
+            const double t0 = now();
+            const int n = warm ? iters : 3;
+            for (int i = 0; i < n; ++i)
+                if (phase == 0 ? (c->world > 1 && bytes ? comm_exchange(c, x, m, st) : 0) : comm_allreduce(c, ar, ar_doubles, 0, st)) return done(1);
+            if (hipStreamSynchronize(st) != hipSuccess) return done(fail("irs_comm_probe: stream failed"));
+            if (warm) usec[phase] = (now() - t0) / n;
+        }
+    }
+    if (comm_check(c)) return done(1);
     return done(0);
 }
 

@@ -149,6 +149,12 @@ class SlabComm:
         L.check(self.lib.irs_comm_describe(self.handle, buf, 256))
         return buf.value.decode()
 
+    def probe(self, nbytes, ar_doubles=21, iters=200):
+        """microseconds per neighbour exchange of `nbytes` per direction and per all-reduce of `ar_doubles` doubles (back to back)"""
+        us = (C.c_double * 2)()
+        L.check(self.lib.irs_comm_probe(self.handle, nbytes, ar_doubles, iters, L.stream_ptr(), C.byref(us)))
+        return us[0], us[1]
+
     def selftest(self):
         L.check(self.lib.irs_comm_selftest(self.handle, L.stream_ptr()))
 
