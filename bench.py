@@ -304,8 +304,22 @@ def main():
 
         # Every transport that comes up is verified and timed on a few transitions; the fastest carries the measurement.  One
         # that cannot be brought up (on ANY rank) does not take the run down with it as long as another one works.
-        best, failures = None, []
+        best, failures, preflight_info = None, [], None
+        preflight = transport == 'auto' and (not shared_device or os.environ.get('IRS_BENCH_PREFLIGHT') == '1')
         for name in (['ipc', 'rccl'] if transport == 'auto' else [transport]):
+            if name == 'ipc' and preflight:
+                # one rank per device: the peer-mapped transport's first cross-device stores happen in a CHILD of every rank
+                # (ir_sgmcmc_amd/ipc_preflight.py) -- a mapping this node cannot reach costs the children, not the run
+                from ir_sgmcmc_amd import ipc_preflight
+                box = [f'irs_pre_{os.getpid()}_{int.from_bytes(os.urandom(4), "little"):08x}'] if rank == 0 else [None]
+                dist.broadcast_object_list(box, src=0, **({'device': dev} if backend == 'nccl' else {}))
+                ok, pre = ipc_preflight.run(box[0], rank, world, dev_index)
+                if not agree(ok):
+                    err = f'ipc: {pre if not ok else "pre-flight failed on another rank"}'
+                    print(f'[bench] rank {rank}: {err}', file=sys.stderr, flush=True)
+                    failures.append(err)
+                    continue
+                preflight_info = pre
             got, err = bring_up(name)
             if got is None:
                 failures.append(err)
@@ -455,7 +469,7 @@ def main():
             out['slab_transport_failure'] = slab_failure
         if slab:
             st = slab_status
-            out['slab'] = {'transport': transport, 'transport_info': comm.describe(), 'transport_trials_ms': trials, 'planes_owned': eng.b - eng.a, 'planes_held': eng.hi - eng.lo, 'ghost_max': eng.ghost_max,
+            out['slab'] = {'transport': transport, 'transport_info': comm.describe(), 'transport_trials_ms': trials, 'ipc_preflight': preflight_info, 'planes_owned': eng.b - eng.a, 'planes_held': eng.hi - eng.lo, 'ghost_max': eng.ghost_max,
                            'exchange_rounds_per_transition': st['exchanges'] / max(st['transitions'], 1),
                            'MB_sent_per_transition_rank0': st['exchanged_bytes'] / max(st['transitions'], 1) / 1e6,
                            'exact_transitions': st['exact_transitions'], 'mispredictions': st['mispredictions']}

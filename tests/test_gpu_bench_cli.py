@@ -52,10 +52,25 @@ def test_bench_auto_transport_survives_a_transport_that_fails():
     """`--transport auto` is what `bench.py --gpus N` runs on a node: bring up BOTH product transports, verify and time each, keep
     the faster.  With the ranks on one device RCCL cannot come up (it refuses two ranks per device): the run must go on with ipc,
     say which transport carried it and what failed -- strong scaling, exit 0."""
-    d = _run(['--gpus', '2', '--size', '48', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--transport', 'auto'], {'IRS_BENCH_DEVICE': '0'})
+    d = _run(['--gpus', '2', '--size', '48', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--transport', 'auto'],
+             {'IRS_BENCH_DEVICE': '0', 'IRS_BENCH_PREFLIGHT': '1'})
     assert d['scaling'] == 'strong' and d['slab']['transport'] == 'ipc'
     assert list(d['slab']['transport_trials_ms']) == ['ipc'] and 'rccl' in d['slab_transport_failure']
     assert 'ipc:' in d['slab']['transport_info'] and d['slab']['mispredictions'] == 0
+    # (one rank per device, a node: the transport is first brought up, self-tested and timed by a child of every rank)
+    assert d['slab']['ipc_preflight']['exchange_us'] > 0 and 'ipc:' in d['slab']['ipc_preflight']['info']
+
+
+def test_bench_auto_transport_survives_a_preflight_child_that_dies():
+    """the peer-mapped transport's first stores into another rank's memory happen in a child of every rank: a child that dies there
+    (a mapping the node cannot reach is a memory fault, not an error code) costs the run the ipc transport, not the run -- here
+    RCCL cannot come up either (one device), so the run ends with the no-transport exit code and says what happened"""
+    p = _run(['--gpus', '2', '--size', '32', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--transport', 'auto'],
+             {'IRS_BENCH_DEVICE': '0', 'IRS_BENCH_PREFLIGHT': '1', 'IRS_IPC_PREFLIGHT_SIMULATE_FAULT': '1'}, expect_rc=1)
+    assert 'pre-flight child of rank 1 ended with code' in p.stderr and 'no slab transport came up' in p.stderr
+    d = _run(['--gpus', '2', '--size', '32', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--transport', 'auto', '--allow-chain-fallback'],
+             {'IRS_BENCH_DEVICE': '0', 'IRS_BENCH_PREFLIGHT': '1', 'IRS_IPC_PREFLIGHT_SIMULATE_FAULT': '1'})
+    assert d['scaling'] == 'weak' and 'pre-flight' in d['slab_transport_failure']
 
 
 def test_bench_four_ranks_ipc():
