@@ -305,8 +305,18 @@ extern "C" int irs_debug_lds_trace(unsigned long long* out) {
 #else
 #define IRS_LT(slot, val)
 #endif
+// waves per SIMD the unstaged variant is COMPILED for.  Its 49 KB of accumulators allow three workgroups per CU whatever the
+// register count, so the cap of 128 registers that "4" implies (60 bytes of scratch) buys no occupancy -- and still wins: compiled
+// for 3 (153 registers, no scratch) a transition of the 6- / 12-voxel displaced runs took 5.79 / 6.80 instead of 5.41 / 6.09 ms on
+// one box (round 4; two sources in flight per wave or three made no difference)
+#ifndef IRS_LDS_WAVES
+#define IRS_LDS_WAVES 4
+#endif
+#ifndef IRS_LDS_PIPE
+#define IRS_LDS_PIPE 2  // wavefront steps of sources requested ahead of their scatter
+#endif
 template <bool PRESCALE, int H>
-__global__ __launch_bounds__(kExpBlock, H == 0 ? 4 : 2) void exp_bwd_lds_kernel(const float* __restrict__ G, const float* __restrict__ dk,
+__global__ __launch_bounds__(kExpBlock, H == 0 ? IRS_LDS_WAVES : 2) void exp_bwd_lds_kernel(const float* __restrict__ G, const float* __restrict__ dk,
                                                                 float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
                                                                 const unsigned* __restrict__ dmax, TileGrid tg,
                                                                 int gather_radius, const float* __restrict__ gscale, int lay,
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(kExpBlock, H == 0 ? 4 : 2) void exp_bwd_lds_kernel(
     const bool magic_ok = ex > 1 && exy > 1 && (unsigned long long)nsrc * exy < (1ull << 32);
     const unsigned m_xy = magic_ok ? 0xFFFFFFFFu / exy + 1u : 0u, m_x = magic_ok ? 0xFFFFFFFFu / (unsigned)ex + 1u : 0u;
     const int nitems = (int)((nsrc + kWave - 1) / kWave);
-    constexpr int kWaves = kExpBlock / kWave, kPipe = 2;
+    constexpr int kWaves = kExpBlock / kWave, kPipe = IRS_LDS_PIPE;
     struct Src {  // the identity-grid coordinates stay separate from d until the scatter: adding them here would wait for the loads
         float d0, d1, d2, l0, l1, l2, G0, G1, G2, gsc;
         bool ok;
