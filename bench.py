@@ -490,6 +490,9 @@ def main():
             if N != 128:  # the reference runs C = 2 chains of a pair (configs/*/config.json): batched in one engine they fill the GPU at 128^3
                 also['size_128_two_chains'] = dict(side_run(128, args.loss, 'identity', 0.0, 50, 10, dev, chains=2), workload=workload_name(128, args.loss),
                                                    note='C = 2 chains in one engine, as every reference config; ms per chain-transition')
+                # ... and with the sigma field of an MCMC_init 'VI' start on top: the regime 14 of the reference's 16 configs run in
+                also['size_128_two_chains_sigma_field'] = dict(side_run(128, args.loss, 'identity', 0.0, 50, 10, dev, chains=2, sigma=0.5), workload=workload_name(128, args.loss),
+                                                               sigma='field, 0.5 everywhere', note='C = 2 chains + pSGLD preconditioner: configs/experiment1 semantics at its own size')
             also['sustained'] = dict(side_run(N, args.loss, 'identity', 0.0, 500, 5, dev), note='500 consecutive transitions from the identity')
             out['also'] = also
         if not args.no_cpu_baseline and world == 1:
