@@ -118,7 +118,10 @@ inline bool predicted_below(const irs_ctx* c, int k, float bound) {
     }
     return m < bound;
 }
-inline bool predicted_small(const irs_ctx* c, int k) { return predicted_below(c, k, 0.75f); }
+// (0.9: the radius-2 FORWARD variant only has work at max|d_k| >= 1, and the radius-1 kernel that remains reads a tap that leaves its
+// ring from global memory -- a bound that crosses 1 between this guess and the launch costs that one step some speed, nothing else.
+// With 0.75 a chain whose d_11 sits between 0.75 and 1 voxel -- the bench's -- paid an idle launch (~5 us) per transition for nothing.)
+inline bool predicted_small(const irs_ctx* c, int k) { return predicted_below(c, k, 0.9f); }
 // "max |d_k| is nowhere near one voxel": the radius-2 ADJOINT variant is not even launched.  Unlike the guesses above this one
 // is not backed by a fallback inside the kernel that remains (the radius-1 gather only covers |d| < 1), so it is (a) taken
 // from the production heuristic only, with a 2.5x margin -- d_k moves by O(0.1) voxel per transition and the host is at most
