@@ -210,6 +210,8 @@ def main():
                     help='slab mode: when no slab transport comes up, measure independent chains per rank instead ("scaling": "weak") '
                          'and exit 0; without this flag that is an error (exit 3): a weak-scaling number must not pass for a point of the '
                          'strong-scaling curve')
+    ap.add_argument('--split', choices=['auto', '0', '1'], default='auto',
+                    help='slab mode: interior / boundary split around an exchange (overlap with more launches); auto = time both, keep the faster')
     ap.add_argument('--ghost-max', type=int, default=0, help='slab mode: widest ghost zone of one exchange (0 = library default)')
     ap.add_argument('--watchdog', type=int, default=420, help='N > 1: seconds after which a run that has not finished dumps its stacks and exits (0 = off)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -351,10 +353,39 @@ def main():
                       f'independent chains instead', file=sys.stderr, flush=True)
                 sys.exit(3)
             slab = False
+    split_trials = {}
     if slab:
         transport, (comm, eng, fixed, moving, _) = best
         cfg = eng.cfg
         v = eng.local(initial_velocity(args.init, args.init_amp, N, dev))
+        # The interior / boundary split around an exchange buys overlap with more, smaller launches (one rank of eight at 256^3:
+        # 1.23 against 1.18 ms of launch sequence, tools/slab_probe.py); whether the overlap repays them depends on what a hand-over
+        # costs on THIS node.  Measured, not guessed: eight transitions each way on a scratch field, the faster form carries the run
+        # (same exchanges, same arithmetic, same chain: tests/test_gpu_slab.py::test_slab_without_the_interior_boundary_split).
+        if args.split == 'auto' and transport != 'rehearsal':
+            scratch = v.clone()
+            for mode in (1, 0):
+                eng.option('slab_split', mode)
+                for _ in range(2):
+                    eng.transition(fixed, moving, scratch)
+                eng.flush()
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+                t0_ = time.perf_counter()
+                for _ in range(8):
+                    eng.transition(fixed, moving, scratch)
+                eng.flush()
+                torch.cuda.synchronize(dev)
+                split_trials['split' if mode else 'unsplit'] = par.max_over_ranks(time.perf_counter() - t0_) * 1e3 / 8
+            del scratch
+            # (max_over_ranks: every rank holds the same two numbers, so every rank takes the same decision)
+            split_on = split_trials['split'] <= split_trials['unsplit']
+            eng.option('slab_split', 1 if split_on else 0)
+        elif args.split in ('0', '1'):
+            split_on = args.split == '1'
+            eng.option('slab_split', int(args.split))
+        else:
+            split_on = True
     else:
         cfg = engine_config(N, args.loss, par.chain_seed(1234))
         eng = TransitionEngine(cfg, dev)
@@ -477,7 +508,7 @@ def main():
             out['slab_transport_failure'] = slab_failure
         if slab:
             st = slab_status
-            out['slab'] = {'transport': transport, 'transport_info': comm.describe(), 'transport_trials_ms': trials, 'ipc_preflight': preflight_info, 'planes_owned': eng.b - eng.a, 'planes_held': eng.hi - eng.lo, 'ghost_max': eng.ghost_max,
+            out['slab'] = {'transport': transport, 'transport_info': comm.describe(), 'transport_trials_ms': trials, 'ipc_preflight': preflight_info, 'interior_boundary_split': split_on, 'split_trials_ms': split_trials, 'planes_owned': eng.b - eng.a, 'planes_held': eng.hi - eng.lo, 'ghost_max': eng.ghost_max,
                            'exchange_rounds_per_transition': st['exchanges'] / max(st['transitions'], 1),
                            'MB_sent_per_transition_rank0': st['exchanged_bytes'] / max(st['transitions'], 1) / 1e6,
                            'exact_transitions': st['exact_transitions'], 'mispredictions': st['mispredictions']}

@@ -46,6 +46,9 @@ def test_bench_two_ranks_ipc():
     assert s['mispredictions'] == 0 and s['planes_owned'] == 32 and s['planes_held'] > 32
     assert s['exchange_rounds_per_transition'] > 0 and d['value'] > 0
     assert '2 z-slabs' in d['config']['parallelism'] and 'peer-mapped' in d['config']['parallelism']
+    # the overlapped (interior / boundary split) and the unsplit launch sequence were both timed, the faster one carried the run
+    assert set(s['split_trials_ms']) == {'split', 'unsplit'}
+    assert s['interior_boundary_split'] == (s['split_trials_ms']['split'] <= s['split_trials_ms']['unsplit'])
 
 
 def test_bench_auto_transport_survives_a_transport_that_fails():

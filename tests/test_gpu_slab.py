@@ -185,6 +185,19 @@ def test_slab_measuring_mode_transition_after_transition(monkeypatch):
     check('slab_ipc/exact_mode_GMM_C1_N30_ranks3_amp12', 'loss terms (rel)', ds, 0.0, 1e-6)
 
 
+@pytest.mark.parametrize('world,N,ghost_max,amp', [(2, 32, 4, 9.0), (3, 30, 6, 12.0)])
+def test_slab_without_the_interior_boundary_split(monkeypatch, world, N, ghost_max, amp):
+    """`slab_split` 0: every launch covers its whole window after the exchange it depends on (fewer, larger launches -- what
+    `bench.py --gpus N` picks when it measures faster than the overlapped form).  Same exchanges, same arithmetic, same result."""
+    monkeypatch.setenv('IRS_SLAB_SPLIT', '0')  # (inherited by the spawned ranks)
+    dv, dd, ds, st = _launch(world, 'GMM', 1, N, True, amp, 'RegLoss_LogNormal', ghost_max, transport='ipc')
+    from tests._report import check
+    name = f'slab_ipc/unsplit_GMM_C1_N{N}_ranks{world}_g{ghost_max}_amp{amp:g}'
+    check(name, 'v_new (rel to max)', dv, 0.0, 1e-5)
+    check(name, 'displacement [voxels]', dd, 0.0, 1e-5)
+    check(name, 'loss terms (rel)', ds, 0.0, 1e-6)
+
+
 @pytest.mark.parametrize('transport', TRANSPORTS)
 def test_slab_long_run_replans_every_transition(transport):
     """40 consecutive transitions on two ranks: after the first (measuring) transition every plan comes from the bounds of
