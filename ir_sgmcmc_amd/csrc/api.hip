@@ -157,7 +157,6 @@ int irs_perturb_smooth(const float* v, const float* sigma, const float* eps, flo
                        void* stream) {
     if (!v || !out || !dims_ok(C, D, H, W)) return fail("irs_perturb_smooth: bad arguments");
     if (s < 0 || s > IRS_MAX_HALF_WIDTH || (s > 0 && (!kernel || !tmp))) return fail("irs_perturb_smooth: bad kernel/s");
-    if (s > 0 && (2 * s >= D || 2 * s >= H || 2 * s >= W)) return fail("irs_perturb_smooth: volume smaller than the kernel");
     hipStream_t st = (hipStream_t)stream;
     const Vol vol = make_vol(D, H, W);
     const size_t bytes = (size_t)C * 3 * vol.V * sizeof(float);
@@ -491,11 +490,8 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     c->ffd = any_cps;
     c->volv = c->ffd ? make_vol(control_points(D, cfg->cps[0]), control_points(H, cfg->cps[1]), control_points(W, cfg->cps[2]))
                      : c->vol;
-    if (cfg->sobolev_s > 0 && (2 * cfg->sobolev_s >= c->volv.D || 2 * cfg->sobolev_s >= c->volv.H || 2 * cfg->sobolev_s >= c->volv.W)) {
-        delete c;
-        context_gone();
-        return fail("irs_create: velocity grid smaller than the Sobolev kernel");
-    }
+    // (a velocity grid narrower than the 2 s + 1 taps of the Sobolev kernel -- an SVFFD control grid of a small volume -- is fine: every
+    // smoothing kernel reads through clamped coordinates, which IS the reference's replicate padding, however often a tap folds back)
     c->sob.s = cfg->sobolev_s;
     for (int i = 0; i <= 2 * cfg->sobolev_s; ++i) c->sob.k[i] = cfg->sobolev_kernel[i];
     if (c->ffd)

@@ -181,7 +181,7 @@ def ffd_upsample(v_cp, dims, cps):
     """
     v = v_cp
     for i, c in enumerate(cps):
-        k = bspline_kernel_1d(c)
+        k = bspline_kernel_1d(c).to(v.dtype)  # (fp32 like the reference; the fp64 error-band runs carry their dtype through)
         p = (k.numel() - 1) // 2
         ax = i + 2
         x = v.transpose(ax, -1)

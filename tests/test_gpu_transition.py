@@ -113,14 +113,17 @@ def test_transition_matches_reference_fixture(name):
 
 
 @pytest.mark.parametrize('variant', ['ssd_l2', 'ssd_vd_lognormal', 'gmm_nosobolev_c3', 'steps1', 'steps2', 'steps5_c2',
-                                     'noncubic_gmm', 'noncubic_ssd_c2', 'tiny_gmm', 'gmm_k2', 'gmm_k6'])
+                                     'noncubic_gmm', 'noncubic_ssd_c2', 'tiny_gmm', 'gmm_k2', 'gmm_k6', 'narrow_sobolev', 'narrow_sobolev_svffd'])
 def test_transition_matches_oracle_builder_variants(variant):
     """Configurations without a reference counterpart (SSD is builder-defined) or not covered by a fixture; the non-cubic ones
     (D != H != W, none a multiple of a tile edge) put ragged tiles and segments under every kernel of the composition."""
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     N = 20
     # tiny_gmm: a volume smaller than any tile or marching segment
-    dims = {'noncubic_gmm': (18, 26, 34), 'noncubic_ssd_c2': (33, 20, 17), 'tiny_gmm': (8, 9, 10)}.get(variant, (N, N, N))
+    # narrow_sobolev*: a velocity grid NARROWER than the 2 s + 1 taps of the Sobolev kernel (replicate padding folds a tap back more
+    # than once; irs_create used to refuse these, the reference runs them -- found by tests/test_gpu_fuzz.py)
+    dims = {'noncubic_gmm': (18, 26, 34), 'noncubic_ssd_c2': (33, 20, 17), 'tiny_gmm': (8, 9, 10), 'narrow_sobolev': (5, 13, 7),
+            'narrow_sobolev_svffd': (12, 14, 9)}.get(variant, (N, N, N))
     kw = dict(ssd_l2=dict(data_loss='SSD', virtual_decimation=False, ssd_sigma=0.05),
               ssd_vd_lognormal=dict(data_loss='SSD', virtual_decimation=True, reg_loss='RegLoss_LogNormal',
                                     reg_learnable=True, no_chains=2),
@@ -129,6 +132,7 @@ def test_transition_matches_oracle_builder_variants(variant):
               steps1=dict(no_steps=1, lr=0.05), steps2=dict(no_steps=2, lr=0.05), steps5_c2=dict(no_steps=5, no_chains=2, lr=0.05),
               noncubic_gmm=dict(), noncubic_ssd_c2=dict(data_loss='SSD', virtual_decimation=True, no_chains=2),
               tiny_gmm=dict(lr=0.05),
+              narrow_sobolev=dict(lr=0.05, sobolev_s=4), narrow_sobolev_svffd=dict(lr=0.05, sobolev_s=4, transformation='SVFFD_3D', cps=(4, 4, 4), data_loss='SSD'),
               # other numbers of mixture components: K <= 4 and K > 4 run different builds of the statistics kernel
               gmm_k2=dict(gmm_components=2), gmm_k6=dict(gmm_components=6, no_chains=2))[variant]
     oc = OracleConfig(dims=dims, **kw)
@@ -138,8 +142,9 @@ def test_transition_matches_oracle_builder_variants(variant):
     moving = {k: v.unsqueeze(0).expand(C, *v.shape).contiguous() for k, v in m1.items() if k != 'seg'}
     gen = torch.Generator().manual_seed(11)
     from oracle import ops as O
-    amp = 1.5 if variant == 'tiny_gmm' else 6.0  # (6 voxels would fold an 8-voxel volume several times over)
-    v0 = O.separable_conv3d_replicate(amp * torch.randn(C, 3, *dims, generator=gen), O.sobolev_kernel_1d(2, 0.5)).contiguous()
+    amp = 1.5 if variant in ('tiny_gmm', 'narrow_sobolev', 'narrow_sobolev_svffd') else 6.0  # (6 voxels would fold an 8-voxel volume several times over)
+    dv = oc.dims_v  # (the control grid of an SVFFD)
+    v0 = O.separable_conv3d_replicate(amp * torch.randn(C, 3, *dv, generator=gen), O.sobolev_kernel_1d(2, 0.5)).contiguous()
     orc = OracleChain(oc, v0=v0)
     orc.init_gmm(fixed, moving)
 
@@ -153,7 +158,7 @@ def test_transition_matches_oracle_builder_variants(variant):
     v = v0.to(DEV).contiguous()
     out = outputs_for(cfg)
     for it in range(3):
-        eps = torch.randn(C, 3, *dims, generator=gen)
+        eps = torch.randn(C, 3, *dv, generator=gen)
         unif = torch.rand(C, 3, *dims, generator=gen) if oc.uniform_noise is not None else None
         o = orc.transition(fixed, moving, eps, unif)
         eng.transition(fixed_d, moving_d, v, None, eps.to(DEV), unif.to(DEV) if unif is not None else None, out)
