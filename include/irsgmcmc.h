@@ -314,7 +314,8 @@ int irs_comm_world(const irs_comm* comm);
 int irs_comm_selftest(irs_comm* comm, void* stream);
 
 typedef struct irs_slab_config {
-    int32_t ghost_max;  /* widest ghost zone of one exchange, planes (0 -> 8) */
+    int32_t ghost_max;  /* widest ghost zone of one exchange, planes (0 -> 8); lowered to what the thinnest slab can send a
+                         * neighbour (slab planes - sobolev_s): irs_slab_layout.ghost_max says what is in force */
     int32_t margin;     /* ghost planes held beyond a neighbour-facing edge (0 -> derived from the stencil widths) */
 } irs_slab_config;
 typedef struct irs_slab_layout {

@@ -136,17 +136,22 @@ int plan_layout(const irs_config* cfg, const irs_slab_config* scfg, int rank, in
     sl->world = world;
     sl->a = (int)(((int64_t)rank * D) / world);
     sl->b = (int)(((int64_t)(rank + 1) * D) / world);
-    sl->gmax = scfg && scfg->ghost_max > 0 ? scfg->ghost_max : kDefaultGhostMax;
-    sl->margin = scfg && scfg->margin > 0 ? scfg->margin : default_margin(cfg, sl->gmax);
-    sl->has_lo = rank > 0;
-    sl->has_hi = rank + 1 < world;
-    sl->lo = sl->has_lo ? (sl->a - sl->margin > 0 ? sl->a - sl->margin : 0) : 0;
-    sl->hi = sl->has_hi ? (sl->b + sl->margin < D ? sl->b + sl->margin : D) : D;
     sl->min_slab = D;
     for (int r = 0; r < world; ++r) {
         const int n = (int)(((int64_t)(r + 1) * D) / world) - (int)(((int64_t)r * D) / world);
         if (n < sl->min_slab) sl->min_slab = n;
     }
+    // The widest exchange a round limit of g planes leads to is the velocity's: sobolev_s + e0 planes with e0 <= g.  An exchange
+    // reaches the NEIGHBOUR only, so it must fit the thinnest slab: the limit is lowered to what fits (same on every rank).  It
+    // used to be taken as given, and the default of 8 -- or any generous request -- made thin slabs refuse their first exchange
+    // ("ghost zone of 14 planes exceeds the smallest slab (13 planes)": tests/test_gpu_slab_fuzz.py).
+    sl->gmax = scfg && scfg->ghost_max > 0 ? scfg->ghost_max : kDefaultGhostMax;
+    if (world > 1 && sl->gmax > sl->min_slab - cfg->sobolev_s) sl->gmax = sl->min_slab - cfg->sobolev_s > 1 ? sl->min_slab - cfg->sobolev_s : 1;
+    sl->margin = scfg && scfg->margin > 0 ? scfg->margin : default_margin(cfg, sl->gmax);
+    sl->has_lo = rank > 0;
+    sl->has_hi = rank + 1 < world;
+    sl->lo = sl->has_lo ? (sl->a - sl->margin > 0 ? sl->a - sl->margin : 0) : 0;
+    sl->hi = sl->has_hi ? (sl->b + sl->margin < D ? sl->b + sl->margin : D) : D;
     return 0;
 }
 

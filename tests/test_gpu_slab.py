@@ -159,6 +159,7 @@ TRANSPORTS = ['rehearsal', 'ipc']
     ('GMM', 1, 30, 3, 6, 12.0),   # thin slabs (10 planes) under a displacement of several voxels: late steps are all boundary, no interior
     ('GMM', 1, (38, 21, 45), 2, 4, 9.0),   # D != H != W, none a multiple of a tile edge: ragged tiles inside slab windows
     ('GMM', 2, 28, 2, 4, 9.0),             # two chains: the mixture's statistics are all-reduced and stepped per chain, serially
+    ('GMM', 1, (27, 20, 22), 3, 12, 3.0),  # 9-plane slabs and a round limit of 12: lowered to what a slab can send its neighbour (9 - sobolev_s)
 ])
 def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max, amp, transport):
     dv, dd, ds, st = _launch(world, data_loss, C, N, True, amp, 'RegLoss_LogNormal', ghost_max, transport=transport)
