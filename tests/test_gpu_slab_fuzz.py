@@ -29,7 +29,7 @@ def _draw(seed):
                 reg=r.choice(['RegLoss_LogNormal', 'RegLoss_L2']), ghost_max=ghost_max, split=r.choice([1, 1, 0]))
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('IRS_SLAB_FUZZ_SEEDS', '8')))))   # (IRS_SLAB_FUZZ_SEEDS=60: a longer hunt)
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('IRS_SLAB_FUZZ_SEEDS', '6')))))   # (IRS_SLAB_FUZZ_SEEDS=60: a longer hunt)
 def test_random_slab_configuration_equals_the_fused_engine(seed, monkeypatch):
     k = _draw(seed)
     monkeypatch.setenv('IRS_SLAB_SPLIT', str(k['split']))   # (inherited by the spawned ranks)
