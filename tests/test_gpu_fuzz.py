@@ -60,9 +60,22 @@ def _draw(seed):
 
 @pytest.mark.parametrize('seed', list(range(int(os.environ.get('IRS_FUZZ_SEEDS', '10')))))   # (IRS_FUZZ_SEEDS=200: a longer hunt)
 def test_random_configuration_against_the_oracle(seed):
+    oc, amp, sigma = _draw(1000 + seed)
+    _compare(oc, amp, sigma, seed)
+
+
+def test_limits_of_the_interface_against_the_oracle():
+    """everything at the limit include/irsgmcmc.h states at once: IRS_MAX_CHAINS chains, IRS_MAX_COMPONENTS mixture components, the
+    widest Sobolev kernel (IRS_MAX_HALF_WIDTH), the wider LCC window, more squaring steps than any reference config"""
+    from ir_sgmcmc_amd import _lib as L
+    oc = OracleConfig(dims=(13, 17, 15), no_chains=L.IRS_MAX_CHAINS, no_steps=14, sobolev_s=L.IRS_MAX_HALF_WIDTH, gmm_components=L.IRS_MAX_COMPONENTS,
+                      lcc_s=2, lr=0.05, reg_loss='RegLoss_LogNormal', reg_learnable=True)
+    _compare(oc, 2.0, 0.5, 4242)
+
+
+def _compare(oc, amp, sigma, seed):
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from oracle import ops as O
-    oc, amp, sigma = _draw(1000 + seed)
     C, dims, dv = oc.no_chains, oc.dims, oc.dims_v
     amp = min(amp, 0.2 * min(dims))   # (a field that folds the volume several times over is no registration)
     f1, m1 = synthetic_pair(dims, seed=seed)
