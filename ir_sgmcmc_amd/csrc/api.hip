@@ -837,6 +837,12 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
         skip_any[k] = predicted_below(c, k, global_knobs().lds_from <= 2 ? 0.75f : 1.5f);
         skip_r2[k] = skip_any[k] && predicted_tiny(c, k);
         if (skip_r2[k]) vd.need_lt1 |= 1u << k;
+        // ... and with the any-radius kernel left out a step must stay within the radius-2 gather's ring: its generic fallback beyond
+        // it is correct, but sums in another order than the kernel a chain that launches every variant uses there -- and WHICH of the
+        // two ran would depend on how old the bounds were that the host happened to see.  Part of the verdict instead: the chain is
+        // the same chain, bit for bit, whatever the host guessed (tests/test_gpu_recovery_fuzz.py found the difference).
+        // (lds_from 2: the any-radius kernel owns everything beyond ONE voxel when it is launched, so leaving it out assumes that)
+        else if (skip_any[k]) (global_knobs().lds_from > 2 ? vd.need_lt2 : vd.need_lt1) |= 1u << k;
     }
 
     if (timed) HIP_TRY(hipEventRecord(c->ev[0], st));

@@ -35,6 +35,8 @@ struct Verdict {
     const unsigned* bounds;    // [steps + 1][C][4] max|d_k| per chain and axis (float bits); nullptr: nothing assumed
     int n, C;                  // squaring steps, chains
     unsigned need_lt1;         // bit k: step k only ran in a form that needs max|d_k| < 1 voxel (radius-1 kernels without fallback)
+    unsigned need_lt2;         // bit k: the any-radius adjoint of step k was not launched -- beyond 2 voxels the radius-2 gather's generic
+                               // fallback would own the step: correct, but not the bits of the any-radius kernel's fixed-point sums
     unsigned char width[32];   // slab: planned ghost width of step k (0: not planned) -- needs floor(max|d_k|) + 1 <= width
 };
 inline Verdict no_verdict() {
@@ -52,6 +54,7 @@ __device__ __forceinline__ bool verdict_bad(const Verdict& v) {
             const int k = i / per;
             const float m = __uint_as_float(v.bounds[i]);
             if (k < 32 && ((v.need_lt1 >> k) & 1u) && !(m < 1.0f)) bad = 1;
+            if (k < 32 && ((v.need_lt2 >> k) & 1u) && !(m < 2.0f)) bad = 1;
             if (k < 32 && v.width[k] && (!(m >= 0.0f) || (int)floorf(m) + 1 > (int)v.width[k])) bad = 1;
         }
     }

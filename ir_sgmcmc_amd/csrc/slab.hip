@@ -677,7 +677,9 @@ struct Exec {
                 float* out = (lay & 4) ? aos(go, v) : planar(go, v);
                 const float* dk = k == 0 ? d0 : step_buf(c, v, k - 1);
                 const unsigned* dm = c->dmax + (int64_t)k * c->C * 4;
-                const bool skip_any = (hplan >= 1 && hplan <= 2) || predicted_below(c, k, 1.5f);
+                // (only from the PLAN, which the verdict checks -- a host guess here could hand a step beyond two voxels to the radius-2
+                // gather's generic fallback, whose sums are not the any-radius kernel's bit for bit)
+                const bool skip_any = hplan >= 1 && hplan <= 2;
                 launch_exp_step_bwd_march(G, dk, out, k == 0, n, c->C, w, lin, dm, hplan == 1 ? 1 : 2, skip_any, nullptr, lay, nullptr, st);
                 // the any-radius kernel bounds its sources by the global bound around the tile (no coarse grid: that one spans the volume)
                 if (!skip_any) launch_exp_step_bwd_lds(G, dk, out, k == 0, n, c->C, w, lin, dm, 2, 2, nullptr, lay, nullptr, st);
