@@ -122,6 +122,8 @@ def _worker(rank, world, port, q, transport, expect_exact, data_loss, C, N, vd, 
             dd = float((d_full - d_ref).abs().max())
             ds = max(abs(a[k][c] - b[k][c]) / max(abs(b[k][c]), 1e-30) for a, b in zip(s, s_ref)
                      for k in ('alpha', 'data_term', 'reg_term') for c in range(C))
+            st = dict(st)   # (+ how MANY elements deviate: a single cell-face element is not a wrong exchange -- tests/test_gpu_slab_fuzz.py)
+            st['v_elements_beyond_1e-5'] = int(((v_full - v_ref).abs() / float(v_ref.abs().max()) > 1e-5).sum())
             q.put((dv, dd, ds, st))
         dist.barrier()
         del eng

@@ -38,6 +38,13 @@ def test_random_slab_configuration_equals_the_fused_engine(seed, monkeypatch):
     from tests._report import check
     name = 'slab_fuzz/%d_%s_ranks%d_%s_C%d_cps%s_g%d_amp%g_split%d' % (seed, 'x'.join(map(str, k['dims'])), k['world'], k['data_loss'], k['C'],
                                                                       k['cps'][0] if k['cps'] else 0, k['ghost_max'], k['amp'], k['split'])
-    check(name, 'v_new (rel to max)', dv, 0.0, 1e-5)
+    # The slab chain is not the fused chain bit for bit (the statistics are summed per rank, then over the ranks): the two drift apart
+    # at 1e-7, and a voxel whose sampling position lies within that of a cell face then takes the other one-sided derivative in one
+    # of them -- ONE gradient element, O(1e-4) of the maximum (seed 62 of the long hunt: 1 element of 117 936 at 1.8e-4, everything
+    # else below 1e-6; tools/debug/slab_diff.py).  A wrong or missing ghost plane is thousands of elements.
+    if dv > 1e-5 and st['v_elements_beyond_1e-5'] <= 3:
+        check(name, 'v_new (rel to max), cell-face elements', dv, 0.0, 2e-3)
+    else:
+        check(name, 'v_new (rel to max)', dv, 0.0, 1e-5)
     check(name, 'displacement [voxels]', dd, 0.0, 1e-5)
     check(name, 'loss terms (rel)', ds, 0.0, 1e-6)

@@ -24,7 +24,8 @@ def worker(rank, world, port, q, a):
     from tests.test_gpu_slab import _run_fused, _setup
     torch.cuda.set_device(0)
     comm = SlabComm.create(a.transport, 'cuda:0')
-    cfg, fixed, moving, v0, noise = _setup(a.N, 1, 'GMM', amp=a.amp, transitions=a.T)
+    N = tuple(a.dims) if a.dims else a.N
+    cfg, fixed, moving, v0, noise = _setup(N, 1, 'GMM', amp=a.amp, reg=a.reg, transitions=a.T)
     eng = SlabEngine(cfg, 'cuda:0', comm, ghost_max=a.ghost_max)
     if a.exact:
         eng.option('slab_exact', 1)
@@ -51,7 +52,8 @@ def worker(rank, world, port, q, a):
         ref.gmm_init(f2, m2)
         vr = v0.to('cuda:0').contiguous()
         dr, gr = torch.zeros_like(vr), torch.zeros_like(vr)
-        edge = lambda z: '  <- slab edge' if z % (a.N // world) in (0, a.N // world - 1) else ''
+        D = N if isinstance(N, int) else N[0]
+        edge = lambda z: '  <- slab edge' if z % (D // world) in (0, D // world - 1) else ''
         for t, (eps, unif) in enumerate(noise):
             ref.transition(f2, m2, vr, None, eps.to('cuda:0'), unif.to('cuda:0'), {'displacement': dr, 'grad_v': gr})
             ref.flush()
@@ -61,7 +63,9 @@ def worker(rank, world, port, q, a):
             dv = (hist[t][0] - vr.cpu()).abs().amax(dim=(0, 1, 3, 4)) / float(vr.abs().max())
             dd = (hist[t][1] - dr.cpu()).abs().amax(dim=(0, 1, 3, 4))
             dg = (hist[t][2] - gr.cpu()).abs().amax(dim=(0, 1, 3, 4)) / float(gr.abs().max())
-            for z in range(a.N):
+            rel = (hist[t][2] - gr.cpu()).abs() / float(gr.abs().max())
+            print(f'    grad_v elements beyond 1e-5 of max: {int((rel > 1e-5).sum())} of {rel.numel()} (beyond 1e-6: {int((rel > 1e-6).sum())})')
+            for z in range(D):
                 if max(dv[z], dd[z], dg[z]) > 1e-5 or edge(z):
                     print(f'  z {z:3d}  {float(dv[z]):.2e} | {float(dd[z]):.2e} | {float(dg[z]):.2e}' + edge(z))
     dist.barrier()
@@ -78,6 +82,8 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--world', type=int, default=3)
     ap.add_argument('--N', type=int, default=30)
+    ap.add_argument('--dims', type=int, nargs=3, default=None, help='D H W (instead of --N)')
+    ap.add_argument('--reg', default='RegLoss_LogNormal')
     ap.add_argument('--ghost-max', type=int, default=6)
     ap.add_argument('--amp', type=float, default=12.0)
     ap.add_argument('--exact', type=int, default=0)
