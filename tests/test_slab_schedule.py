@@ -65,6 +65,20 @@ def _free_port():
     return p
 
 
+def test_round_limit_is_lowered_to_what_a_thin_slab_can_exchange():
+    """the widest exchange a round limit of g planes leads to is the velocity's: sobolev_s + e0 planes with e0 <= g, and an exchange
+    reaches the neighbour only -- so on thin slabs the limit in force is (thinnest slab - sobolev_s), the same on every rank, whatever
+    was asked for (the default of 8 on slabs of fewer than 11 planes used to make the first exchange refuse; tests/test_gpu_slab_fuzz.py)"""
+    from ir_sgmcmc_amd.engine import EngineConfig
+    cfg = EngineConfig(dims=(27, 16, 16))            # sobolev_s = 3 by default
+    for asked in (0, 4, 12):                          # 0: the library default (8)
+        lays = [plan_layout(cfg, r, 3, ghost_max=asked) for r in range(3)]   # 9-plane slabs
+        assert {l['ghost_max'] for l in lays} == {min(asked or 8, 9 - 3)}
+        assert all(l['margin'] >= l['ghost_max'] + 3 for l in lays)
+    roomy = [plan_layout(EngineConfig(dims=(96, 16, 16)), r, 3, ghost_max=12) for r in range(3)]   # 32-plane slabs: as asked
+    assert {l['ghost_max'] for l in roomy} == {12}
+
+
 class Replay:
     """one rank's view: which planes of which buffer hold which tensor"""
 
