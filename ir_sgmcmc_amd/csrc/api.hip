@@ -62,12 +62,33 @@ static Knobs knobs_from_env() {
     k.slab_buffers = env_or("IRS_SLAB_BUFFERS", k.slab_buffers);
     k.slab_exact = env_or("IRS_SLAB_EXACT", k.slab_exact);
     k.slab_force_h = env_or("IRS_SLAB_FORCE_H", k.slab_force_h);
+    k.launch_log = env_or("IRS_LAUNCH_LOG", k.launch_log);
     return k;
 }
 
 Knobs& global_knobs() {
     static Knobs k = knobs_from_env();  // the only place the library reads IRS_* tuning variables, once per process
     return k;
+}
+
+void log_launch(const char* kernel, int tile_x, int tile_y, int64_t blocks, int threads, int seg_len, int run_in, int planes_out,
+                int chains, int64_t resident) {
+    if (!global_knobs().launch_log) return;
+    static uint64_t seen[256];
+    static int n_seen = 0;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    for (const char* p = kernel; *p; ++p) mix((uint64_t)*p);
+    mix((uint64_t)blocks); mix((uint64_t)threads); mix((uint64_t)seg_len); mix((uint64_t)planes_out); mix((uint64_t)chains);
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i] == h) return;
+    if (n_seen < 256) seen[n_seen++] = h;
+    const int steps = (seg_len < planes_out ? seg_len : planes_out) + run_in;
+    const double rounds = resident > 0 ? (double)blocks / (double)resident : 0.0;
+    fprintf(stderr, "[irs launch] {\"kernel\": \"%s\", \"tile\": [%d, %d], \"workgroups\": %lld, \"threads\": %d, \"seg_len\": %d, \"run_in\": %d, "
+                    "\"planes_out\": %d, \"chains\": %d, \"plane_steps\": %d, \"resident\": %lld, \"rounds\": %.3f, \"run_in_overhead\": %.3f}\n",
+            kernel, tile_x, tile_y, (long long)blocks, threads, seg_len, run_in, planes_out, chains, steps, (long long)resident, rounds,
+            (double)steps / (double)(steps - run_in > 0 ? steps - run_in : 1));
 }
 
 static int g_live_contexts = 0;  // contexts alive in this process (a context is not thread-safe, and neither is this count)
@@ -94,7 +115,7 @@ int knob_set(Knobs& k, const char* name, int value, bool on_context) {
         {"fwd_rows1", &Knobs::fwd_rows1, KN_GLOBAL}, {"coarse_box", &Knobs::coarse_box, KN_GLOBAL}, {"lds_from", &Knobs::lds_from, KN_GLOBAL},
         {"fwd_pf", &Knobs::fwd_pf, KN_GLOBAL}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1, KN_GLOBAL}, {"sobolev_tile", &Knobs::sobolev_tile, KN_GLOBAL},
         {"march_seg", &Knobs::march_seg, KN_GLOBAL}, {"march_seg_fwd", &Knobs::march_seg_fwd, KN_GLOBAL}, {"swz_run", &Knobs::swz_run, KN_GLOBAL},
-        {"sobolev_seg", &Knobs::sobolev_seg, KN_GLOBAL}, {"ps_rows", &Knobs::ps_rows, KN_GLOBAL},
+        {"sobolev_seg", &Knobs::sobolev_seg, KN_GLOBAL}, {"ps_rows", &Knobs::ps_rows, KN_GLOBAL}, {"launch_log", &Knobs::launch_log, KN_GLOBAL},
         {"seg_fit", &Knobs::seg_fit, KN_LAYOUT}, {"seg_min_blocks", &Knobs::seg_min_blocks, KN_LAYOUT}, {"seg_min_len", &Knobs::seg_min_len, KN_LAYOUT},
         {"lcc_seg", &Knobs::lcc_seg, KN_LAYOUT}, {"stats_seg", &Knobs::stats_seg, KN_LAYOUT}, {"update_seg", &Knobs::update_seg, KN_LAYOUT},
     };

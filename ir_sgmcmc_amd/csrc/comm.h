@@ -29,6 +29,9 @@ int comm_allreduce(irs_comm* c, void* buf, size_t count, int max_u32, hipStream_
 int comm_reserve(irs_comm* c, size_t xbytes, size_t arbytes);
 // a timeout raised on the device by a waiting kernel of the peer-mapped transport (0: none)
 int comm_check(irs_comm* c);
+// the sticky DEVICE word such a timeout also sets (nullptr for the other transports): kernels that modify persistent state test
+// it, so a transition that ran on a timed-out exchange is a no-op (scalar_kernels.h: comm_bad)
+const unsigned* comm_error_flag(const irs_comm* c);
 
 // ipc.hip
 int ipc_create(const char* name, int rank, int world, irs_comm** out);
@@ -38,4 +41,5 @@ int ipc_exchange(irs_comm* c, const irs_xfer* x, int n, hipStream_t st);
 int ipc_allreduce(irs_comm* c, void* buf, size_t count, int kind, hipStream_t st);
 int ipc_check(irs_comm* c);
 void ipc_describe(const irs_comm* c, char* out, size_t n);
+const unsigned* ipc_error_flag(const irs_comm* c);
 }  // namespace irs

@@ -119,6 +119,7 @@ int comm_reserve(irs_comm* cm, size_t xbytes, size_t arbytes) {
 }
 
 int comm_check(irs_comm* cm) { return cm && cm->kind == 2 ? ipc_check(cm) : 0; }
+const unsigned* comm_error_flag(const irs_comm* cm) { return cm && cm->kind == 2 ? ipc_error_flag(cm) : nullptr; }
 
 }  // namespace irs
 

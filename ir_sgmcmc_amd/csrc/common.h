@@ -101,6 +101,7 @@ struct Knobs {
     int slab_split = 1;        // IRS_SLAB_SPLIT        interior / boundary split around an exchange
     int slab_exact = 0;        // IRS_SLAB_EXACT        every transition in measuring mode
     int slab_force_h = 0;      // IRS_SLAB_FORCE_H      test hook: a deliberately wrong ghost-width plan
+    int launch_log = 0;        // IRS_LAUNCH_LOG        print the shape of every distinct marching launch once (stderr; tools/launch_shapes.py)
 };
 Knobs& global_knobs();                                   // api.hip; initialised from the environment on first use
 int knob_set(Knobs& k, const char* name, int value, bool on_context);  // 0 on success (api.hip: scopes)
@@ -153,6 +154,12 @@ inline int64_t resident_blocks(const void* kernel, int block, int* cache) {
     }
     return *cache > 0 ? *cache : 0;
 }
+
+// IRS_LAUNCH_LOG=1: one stderr line per distinct (kernel, shape) -- workgroups, threads, segment length, run-in planes, plane steps a
+// workgroup marches, workgroups the chip holds at once -> rounds.  What a launch on a small volume or a thin slab looks like
+// ("where a small launch loses"); api.hip.
+void log_launch(const char* kernel, int tile_x, int tile_y, int64_t blocks, int threads, int seg_len, int run_in, int planes_out,
+                int chains, int64_t resident);
 
 inline dim3 vox_grid(const Vol& vol, int planes) {
     return dim3((unsigned)((vol.W + 63) / 64), (unsigned)((vol.H + 3) / 4), (unsigned)(vol.nz * planes));

@@ -689,6 +689,9 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #ifndef IRS_BWD_R1_FALLBACK
 #define IRS_BWD_R1_FALLBACK 1
 #endif
+#ifndef IRS_BWD_PEEL
+#define IRS_BWD_PEEL 1  // radius-1 adjoint: run-in plane steps update only the accumulators whose output plane is inside the segment
+#endif
 // hat of (r + c) for a relative position r and a compile-time integer offset c.
 template <int R>
 __device__ __forceinline__ float rel_hat(float r, int c);
@@ -997,7 +1000,12 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                 own_g[0] = q_g[co];
             }
             // ---- contributions of source plane s to output planes s-R .. s+R
-            if (s >= 0 && s < vol.D && col_in) {
+            // MK: which of those output planes lie inside the segment (bit oo + R).  The run-in steps of a segment reach one or
+            // two of them only, and on a small volume or a thin slab the run-in is a quarter of all plane steps (8-plane
+            // segments: 10 steps, 6 of their 30 accumulator updates land outside) -- those steps run an instantiation that leaves
+            // the other accumulators alone (IRS_BWD_PEEL; same operations in the same order for every plane that is stored)
+            auto gather = [&](auto MK) {
+                constexpr int MASK = decltype(MK)::value;
 #pragma unroll IRS_GATHER_UNROLL_Y
                 for (int dy = 0; dy <= 2 * R; ++dy)
 #pragma unroll
@@ -1016,6 +1024,7 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                         const float2 rzg = q_zg[ri], g01 = q_g[ri];
 #pragma unroll
                         for (int oo = -R; oo <= R; ++oo) {
+                            if (!((MASK >> (oo + R)) & 1)) continue;
                             const int a = (PH + oo + NP) % NP;  // accumulator of output plane s + oo (static index)
                             const float w = hxy * rel_hat<R>(rzg.x, -oo);
                             acc01[a].x = fmaf(w, g01.x, acc01[a].x);
@@ -1023,6 +1032,20 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                             acc2[a] = fmaf(w, rzg.y, acc2[a]);
                         }
                     }
+            };
+            if (s >= 0 && s < vol.D && col_in) {
+                constexpr int ALL = (1 << NP) - 1;
+                if (R == 1 && IRS_BWD_PEEL) {
+                    const int m = (s - 1 >= z0 && s - 1 < z1 ? 1 : 0) | (s >= z0 && s < z1 ? 2 : 0) | (s + 1 >= z0 && s + 1 < z1 ? 4 : 0);  // wave-uniform
+                    if (m == ALL) gather(LayC<ALL>{});
+                    else if (m == 4) gather(LayC<4>{});
+                    else if (m == 6) gather(LayC<6>{});
+                    else if (m == 3) gather(LayC<3>{});
+                    else if (m == 1) gather(LayC<1>{});
+                    else gather(LayC<ALL>{});  // (segments of one or two planes: 2, 5 never occur, a lone 2 is rare)
+                } else {
+                    gather(LayC<ALL>{});
+                }
             }
             IRS_BT(5);
             // ---- output plane zo = s - R is complete
@@ -1173,6 +1196,11 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
     const Scale3L sc = make_scale_l(vol, no_steps);
     const int swz_env = global_knobs().swz_run;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;  // 0/1: no remap; default: one x-row of tiles per XCD run
+    if (global_knobs().launch_log) {
+        static int cache_l = 0;
+        log_launch("exp_bwd_march_kernel<R=1>", MTX, MTY, total, kMarchBlock, seg_len, 2, vol.nz + vol.nzb, C,
+                   resident_blocks((const void*)exp_bwd_march_kernel<false, 1>, kMarchBlock, &cache_l));
+    }
 #define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale, lay)
     const int rare = total < kRareGrid ? total : kRareGrid;
     // the radius-1 kernel first (the one the roofline is quoted on: `after_primary` brackets exactly its launch), then the
@@ -1517,6 +1545,13 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     const Scale3L sc = make_scale_l(vol, no_steps);
     const int swz_env = global_knobs().swz_run;
     const int swz_run = swz_env >= 0 ? swz_env : (int)tiles.x;
+    if (global_knobs().launch_log) {
+        static int cache_ls = 0, cache_lb = 0;
+        log_launch(small ? "exp_fwd_march_kernel<R=1,rows=1>" : "exp_fwd_march_kernel<R=1,rows=2>", FTX, FTY, total, small ? FTX * FTY : FTX * FTY / FROWS_BIG,
+                   seg_len, 2, vol.nz + vol.nzb, C,
+                   small ? resident_blocks((const void*)exp_fwd_march_kernel<false, 1, 1, 2>, FTX * FTY, &cache_ls)
+                         : resident_blocks((const void*)exp_fwd_march_kernel<false, 1, FROWS_BIG, 1>, FTX * FTY / FROWS_BIG, &cache_lb));
+    }
 #define IRS_FWM(P, RR, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), dim3(GRID), dim3(FTX * FTY / FROWS_BIG), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
 #define IRS_FW2(P, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 2, 1>), dim3(GRID), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
 #define IRS_FWS(P, LO, HI)                                                                                                      \

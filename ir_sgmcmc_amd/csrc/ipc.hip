@@ -14,8 +14,12 @@
 //               hipMalloc memory never saw the other process's store, even with both ranks on one device.)
 //   exchange    push kernel: packs this rank's strips into slot (seq & 1) of each neighbour's landing area; when its last
 //               workgroup has drained its stores (system-scope release) it stores `seq` into the neighbours' flags.
-//               wait kernel (ONE wavefront): polls this rank's flags until `seq` has arrived (bounded: a timeout raises an error
-//               word); drain kernel behind it: unpacks the landing slot into the ghost planes.  Two slots suffice without credits because every
+//               wait kernel (ONE wavefront): polls this rank's flags until `seq` has arrived -- bounded: a timeout raises a STICKY
+//               error word (pinned host memory for ipc_check, a device word for the kernels), after which every drain / reduce
+//               kernel of this communicator does nothing and the slab transition in flight ends as a no-op on this rank
+//               (scalar_kernels.h: comm_bad -- no parameter, moment, counter or velocity changes), so no stale landing slot is
+//               ever consumed; the host gets the error from its next call.  drain kernel behind it: unpacks the landing slot
+//               into the ghost planes.  Two slots suffice without credits because every
 //               exchange is symmetric on a link: a rank's push of seq + 2 follows its own drain of seq + 1, which waited for the
 //               neighbour's push of seq + 1, which that neighbour enqueued behind ITS drain of seq (checked: comm_exchange
 //               refuses an asymmetric list for this transport).
@@ -95,6 +99,8 @@ struct IpcState {
     uint32_t xseq = 0, arseq = 0;
     unsigned* err = nullptr;       // pinned, device-visible: first timeout (code) raised by a waiting kernel
     unsigned* err_dev = nullptr;
+    unsigned* err_flag = nullptr;  // the same fact in DEVICE memory: what the consumer kernels test (no PCIe round trip per launch)
+    bool bailing = false;          // this rank failed during the bootstrap: it takes no further part in the arrival counter
     unsigned long long timeout_ticks = 0;
     uint64_t exchanges = 0, allreduces = 0;
 };
@@ -115,6 +121,8 @@ int host_barrier(IpcState* s, double timeout_s = 120.0) {
         }
         usleep(200);
     }
+    // (a rank that fails AFTER its arrival has completed this barrier is seen here, not a barrier later)
+    if (__atomic_load_n(&m->failed, __ATOMIC_ACQUIRE)) return fail("ipc transport: another rank failed during the bootstrap");
     return 0;
 }
 
@@ -145,16 +153,8 @@ struct Signals {
 
 __device__ __forceinline__ unsigned load_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-// one lane waits until `*flag` has reached `seq` (wrap-safe), bounded by `timeout` ticks of the 100 MHz wall clock
-__device__ void wait_flag(const unsigned* flag, unsigned seq, unsigned long long timeout, unsigned* err, unsigned code) {
-    const unsigned long long t0 = wall_clock64();
-    while ((int)(load_flag(flag) - seq) < 0) {
-        __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > timeout) {
-            __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-        }
-    }
+__device__ __forceinline__ bool comm_failed(const unsigned* err_flag) {
+    return __hip_atomic_load(err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 }
 
 __device__ __forceinline__ void copy_bytes(const char* __restrict__ src, char* __restrict__ dst, uint64_t bytes, unsigned part, unsigned parts) {
@@ -184,7 +184,9 @@ __device__ __forceinline__ void copy_bytes(const char* __restrict__ src, char* _
 // every workgroup: stores drained, system-scope release; the LAST one to arrive stores `seq` into the flags.
 // (MI355X_MICROARCH.md, inter-workgroup visibility: every storing wave's vmcnt(0), the barrier, lane-0 release, an explicit
 // vmcnt(0) the compiler cannot drop, then the counter / flag.)
-__device__ void publish(unsigned* done, unsigned total, const Signals& sig, unsigned seq) {
+// A rank whose communicator has FAILED (a wait of its own timed out) keeps its flags to itself: what it would push derives from
+// stale ghost planes, and a peer that never sees the flag times out in turn instead of consuming it.
+__device__ void publish(unsigned* done, unsigned total, const Signals& sig, unsigned seq, const unsigned* err_flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ unsigned last;
@@ -196,15 +198,15 @@ __device__ void publish(unsigned* done, unsigned total, const Signals& sig, unsi
         if (last) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
     }
     __syncthreads();
-    if (last && threadIdx.x == 0)
+    if (last && threadIdx.x == 0 && !comm_failed(err_flag))
         for (int i = 0; i < sig.n; ++i) __hip_atomic_store(sig.flag[i], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // grid (parts, runs)
-__global__ void __launch_bounds__(256) ipc_push_kernel(Runs runs, Signals sig, unsigned seq, unsigned* done) {
+__global__ void __launch_bounds__(256) ipc_push_kernel(Runs runs, Signals sig, unsigned seq, unsigned* done, const unsigned* err_flag) {
     const Run r = runs.r[blockIdx.y];
     copy_bytes(r.src, r.dst, r.bytes, blockIdx.x, gridDim.x);
-    publish(done, gridDim.x * gridDim.y, sig, seq);
+    publish(done, gridDim.x * gridDim.y, sig, seq, err_flag);
 }
 
 // Waiting is ONE wavefront's business: a kernel of its own in front of the consumer, so that what spins while a peer is late is
@@ -215,14 +217,34 @@ struct Waits {
     int n;
     const unsigned* flag[kMaxWorld];
 };
-__global__ void __launch_bounds__(64) ipc_wait_kernel(Waits w, unsigned seq, unsigned long long timeout, unsigned* err, unsigned code) {
-    for (int i = 0; i < w.n; ++i)  // one lane per flag, all polling at once (uniform index: the pointers stay scalar)
-        if ((int)threadIdx.x == i) wait_flag(w.flag[i], seq, timeout, err, code | (unsigned)i);
+__global__ void __launch_bounds__(64) ipc_wait_kernel(Waits w, unsigned seq, unsigned long long timeout, unsigned* err, unsigned* err_flag, unsigned code) {
+    // one lane per flag, ALL polling in the same loop: the bound is one timeout whatever the number of peers (wrap-safe
+    // sequence comparison; 100 MHz wall clock).  The flag pointers are picked per lane by selects (kernel arguments stay scalar).
+    const int lane = (int)threadIdx.x;
+    const unsigned* p = w.flag[0];
+#pragma unroll
+    for (int i = 1; i < kMaxWorld; ++i) p = lane == i ? w.flag[i] : p;
+    bool pending = lane < w.n;
+    if (comm_failed(err_flag)) return;  // an earlier wait of this communicator timed out: nothing behind it consumes anything
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        if (pending && (int)(load_flag(p) - seq) >= 0) pending = false;
+        if (!__any(pending)) break;
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > timeout) {
+            if (pending) {
+                __hip_atomic_store(err, code | (unsigned)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ void __launch_bounds__(256) ipc_drain_kernel(Runs runs) {
+__global__ void __launch_bounds__(256) ipc_drain_kernel(Runs runs, const unsigned* err_flag) {
+    if (comm_failed(err_flag)) return;  // the wait in front timed out: the landing slot is stale
     const Run r = runs.r[blockIdx.y];
     copy_bytes(r.src, r.dst, r.bytes, blockIdx.x, gridDim.x);
 }
@@ -231,13 +253,16 @@ struct ArDst {
     char* dst[kMaxWorld];  // slot [seq & 1][me] of every rank's landing area
 };
 // grid (parts, world): this rank's contribution to every rank
-__global__ void __launch_bounds__(256) ipc_ar_push_kernel(const char* buf, uint64_t bytes, ArDst to, Signals sig, unsigned seq, unsigned* done) {
+__global__ void __launch_bounds__(256) ipc_ar_push_kernel(const char* buf, uint64_t bytes, ArDst to, Signals sig, unsigned seq, unsigned* done,
+                                                          const unsigned* err_flag) {
     copy_bytes(buf, to.dst[blockIdx.y], bytes, blockIdx.x, gridDim.x);
-    publish(done, gridDim.x * gridDim.y, sig, seq);
+    publish(done, gridDim.x * gridDim.y, sig, seq, err_flag);
 }
 
 // kind 0: SUM of doubles, 1: MAX of uint32, 2: SUM of floats; contributions combined in rank order (launched behind ipc_wait_kernel)
-__global__ void __launch_bounds__(256) ipc_ar_reduce_kernel(void* buf, uint64_t count, int kind, const char* slot, uint64_t stride, int world) {
+__global__ void __launch_bounds__(256) ipc_ar_reduce_kernel(void* buf, uint64_t count, int kind, const char* slot, uint64_t stride, int world,
+                                                            const unsigned* err_flag) {
+    if (comm_failed(err_flag)) return;  // the wait in front timed out: contributions are missing
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
         if (kind == 0) {
             double a = ((const double*)slot)[i];
@@ -297,6 +322,8 @@ int ipc_check(irs_comm* cm) {
                 (e >> 28) == 1 ? "exchange" : "all-reduce", (e >> 4) & 0xffffffu, e & 15u);
 }
 
+const unsigned* ipc_error_flag(const irs_comm* cm) { return cm && cm->ipc ? cm->ipc->err_flag : nullptr; }
+
 // (Re)allocate the landing area for exchanges of up to `xbytes` per side and all-reduces of up to `arbytes`; collective, blocking.
 int ipc_reserve(irs_comm* cm, size_t xbytes, size_t arbytes) {
     IpcState* s = cm->ipc;
@@ -316,7 +343,7 @@ int ipc_reserve(irs_comm* cm, size_t xbytes, size_t arbytes) {
     // enough still takes part in the barriers of one that does not -- so all of them re-publish whenever ANY call grows
     const bool grow = xbytes > s->x_slot || arbytes > s->ar_slot || !s->land;
     if (!grow) return 0;
-    HIP_TRY(hipDeviceSynchronize());
+    if (hipDeviceSynchronize() != hipSuccess) return give_up(s, fail("ipc_reserve: hipDeviceSynchronize failed"));
     if (give_up(s, host_barrier(s))) return 1;  // nobody is still writing into an old area
     close_peers(s);
     if (give_up(s, host_barrier(s))) return 1;  // nobody still maps an old area
@@ -351,8 +378,8 @@ int ipc_reserve(irs_comm* cm, size_t xbytes, size_t arbytes) {
         if (e != hipSuccess) return give_up(s, fail("ipc_reserve: hipMalloc of %zu bytes failed: %s", s->land_bytes, hipGetErrorString(e)));
         e = hipIpcGetMemHandle(&me.handle, s->land);
     }
-    HIP_TRY(hipMemset(s->land, 0, kLandHeader));
-    HIP_TRY(hipDeviceSynchronize());
+    if (hipMemset(s->land, 0, kLandHeader) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+        return give_up(s, fail("ipc_reserve: clearing the landing header failed"));  // (the peers stop waiting at once)
     if (e != hipSuccess) return give_up(s, fail("hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed where the driver only has dmabuf IPC)", hipGetErrorString(e)));
     me.land_bytes = s->land_bytes;
     me.x_slot = s->x_slot;
@@ -390,6 +417,7 @@ int ipc_exchange(irs_comm* cm, const irs_xfer* x, int n, hipStream_t st) {
     sig.n = 0;
     Waits wt;
     wt.n = 0;
+    for (int i = 0; i < kMaxWorld; ++i) wt.flag[i] = nullptr;
     // my neighbours: side 0 = the lower one (rank - 1), side 1 = the upper one.  At the UPPER neighbour I am its lower side (0).
     for (int side = 0; side < 2; ++side) {
         const int peer = side == 0 ? s->rank - 1 : s->rank + 1;
@@ -426,9 +454,9 @@ int ipc_exchange(irs_comm* cm, const irs_xfer* x, int n, hipStream_t st) {
     uint64_t most = 0;
     for (int i = 0; i < push.n; ++i) most = push.r[i].bytes > most ? push.r[i].bytes : most;
     const unsigned parts = parts_for(most);
-    hipLaunchKernelGGL(ipc_push_kernel, dim3(parts, push.n), dim3(256), 0, st, push, sig, seq, done_ptr(s, 0));
-    hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, st, wt, seq, s->timeout_ticks, s->err_dev, (1u << 28) | ((seq & 0xffffffu) << 4));
-    hipLaunchKernelGGL(ipc_drain_kernel, dim3(parts, drain.n), dim3(256), 0, st, drain);
+    hipLaunchKernelGGL(ipc_push_kernel, dim3(parts, push.n), dim3(256), 0, st, push, sig, seq, done_ptr(s, 0), (const unsigned*)s->err_flag);
+    hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, st, wt, seq, s->timeout_ticks, s->err_dev, s->err_flag, (1u << 28) | ((seq & 0xffffffu) << 4));
+    hipLaunchKernelGGL(ipc_drain_kernel, dim3(parts, drain.n), dim3(256), 0, st, drain, (const unsigned*)s->err_flag);
     LAUNCH_CHECK();
     ++s->exchanges;
     return 0;
@@ -447,7 +475,7 @@ int ipc_allreduce(irs_comm* cm, void* buf, size_t count, int kind, hipStream_t s
     Waits wt;
     Signals sig;
     sig.n = wt.n = 0;
-    for (int r = 0; r < kMaxWorld; ++r) to.dst[r] = nullptr;
+    for (int r = 0; r < kMaxWorld; ++r) to.dst[r] = nullptr, wt.flag[r] = nullptr;
     for (int r = 0; r < s->world; ++r) {
         to.dst[r] = s->peer[r] + ar_off(s->peer_x_slot[r], s->peer_ar_slot[r], s->world, slot, s->rank);
         if (r == s->rank) continue;
@@ -455,13 +483,14 @@ int ipc_allreduce(irs_comm* cm, void* buf, size_t count, int kind, hipStream_t s
         wt.flag[wt.n++] = flag_ptr(s, s->rank, arflag_off(r));
     }
     const unsigned parts = parts_for(bytes);
-    hipLaunchKernelGGL(ipc_ar_push_kernel, dim3(parts, s->world), dim3(256), 0, st, (const char*)buf, (uint64_t)bytes, to, sig, seq, done_ptr(s, 1));
+    hipLaunchKernelGGL(ipc_ar_push_kernel, dim3(parts, s->world), dim3(256), 0, st, (const char*)buf, (uint64_t)bytes, to, sig, seq, done_ptr(s, 1), (const unsigned*)s->err_flag);
     const uint64_t per_block = 256 * 8;
     unsigned blocks = (unsigned)((count + per_block - 1) / per_block);
     blocks = blocks < 1 ? 1 : (blocks > 128 ? 128 : blocks);
-    hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, st, wt, seq, s->timeout_ticks, s->err_dev, (2u << 28) | ((seq & 0xffffffu) << 4));
+    hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, st, wt, seq, s->timeout_ticks, s->err_dev, s->err_flag, (2u << 28) | ((seq & 0xffffffu) << 4));
     hipLaunchKernelGGL(ipc_ar_reduce_kernel, dim3(blocks), dim3(256), 0, st, buf, (uint64_t)count, kind,
-                       (const char*)(s->land + ar_off(s->x_slot, s->ar_slot, s->world, slot, 0)), (uint64_t)s->ar_slot, s->world);
+                       (const char*)(s->land + ar_off(s->x_slot, s->ar_slot, s->world, slot, 0)), (uint64_t)s->ar_slot, s->world,
+                       (const unsigned*)s->err_flag);
     LAUNCH_CHECK();
     ++s->allreduces;
     return 0;
@@ -474,13 +503,17 @@ void ipc_destroy(irs_comm* cm) {
     close_peers(s);
     if (s->shm) {
         // the owner of a landing area frees it only when nobody maps it any more; a peer that has already died is not waited for long
-        (void)host_barrier(s, 10.0);
+        // (a rank that failed during the bootstrap only raises `failed`: an extra arrival could complete the barrier the healthy
+        // ranks are in and let them return success next to a dead peer)
+        if (s->bailing) __atomic_store_n(&s->shm->failed, 1u, __ATOMIC_RELEASE);
+        else (void)host_barrier(s, 10.0);
         if (s->registered) (void)hipHostUnregister(s->shm);
         (void)munmap(s->shm, kShmBytes);
     }
     if (s->land) (void)hipFree(s->land);
     for (int i = 0; i < s->n_retired; ++i) (void)hipFree(s->retired[i]);
     if (s->err) (void)hipHostFree(s->err);
+    if (s->err_flag) (void)hipFree(s->err_flag);
     delete s;
     cm->ipc = nullptr;
 }
@@ -502,6 +535,7 @@ int ipc_create(const char* name, int rank, int world, irs_comm** out) {
     c->ipc = s;
     snprintf(s->name, sizeof(s->name), "%s%s", name[0] == '/' ? "" : "/", name);
     auto bail = [&](int rc) {
+        s->bailing = true;
         ipc_destroy(c);
         delete c;
         return rc;
@@ -557,9 +591,14 @@ int ipc_create(const char* name, int rank, int world, irs_comm** out) {
         *s->err = 0;
         e = hipHostGetDevicePointer((void**)&s->err_dev, s->err, 0);
     }
-    if (e != hipSuccess) return bail(give_up(s, fail("ipc transport: pinned host memory failed: %s", hipGetErrorString(e))));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->err_flag, 64);
+    if (e == hipSuccess) e = hipMemset(s->err_flag, 0, 64);
+    if (e != hipSuccess) return bail(give_up(s, fail("ipc transport: pinned host memory / error word failed: %s", hipGetErrorString(e))));
+    // How long a kernel waits for a peer's flag.  It bounds the SKEW between ranks, host pauses included: a rank whose host stops
+    // enqueueing for longer than this between two transitions (checkpoint, metrics I/O) makes its neighbours give up -- raise
+    // IRS_IPC_TIMEOUT_S for such runs.  A timeout is fail-safe (header of this file), never a corrupted chain.
     const char* to = getenv("IRS_IPC_TIMEOUT_S");
-    const double secs = to && atof(to) > 0.0 ? atof(to) : 20.0;
+    const double secs = to && atof(to) > 0.0 ? atof(to) : 60.0;
     s->timeout_ticks = (unsigned long long)(secs * 100.0e6);  // wall_clock64: 100 MHz
     if (give_up(s, host_barrier(s))) return bail(1);
     *out = c;

@@ -24,7 +24,16 @@ struct DevState {
     double moments[3];            // scratch: n, sum z, sum z^2 (GMM initialisation)
     unsigned bad_now;             // verdict about the transition in flight (Verdict below), written by the first scalar stage
     unsigned fails;               // transitions that ended as no-ops because an assumption about max|d_k| did not hold
+    const unsigned* comm_err;     // slab over the peer-mapped transport: its sticky device error word (ipc.hip), else nullptr
 };
+
+// A wait of the peer-mapped transport timed out (a peer is gone or late beyond IRS_IPC_TIMEOUT_S): whatever the exchanges after it
+// delivered is stale, so every kernel that modifies persistent state treats the transition in flight as a no-op -- the same
+// mechanism as a failed verdict -- and the host gets the error from its next call (comm_check).
+__device__ __forceinline__ bool comm_bad(const DevState* s) {
+    const unsigned* e = s->comm_err;
+    return e != nullptr && __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
 
 // What the launch sequence of the transition in flight ASSUMED about the displacement bounds max|d_k| (decided on the host from
 // bounds of earlier transitions, never waited for).  Every kernel that modifies persistent state -- the mixture and regulariser

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
     } else {
         bad = vd.bounds != nullptr && s->bad_now != 0u;
     }
+    bad = bad || comm_bad(s);
     __shared__ double rs[kStatVals];
     __shared__ double alpha_s;
     // step-count part of the Adam update (two fp64 pow), one lane per parameter, BEFORE the reduction: it overlaps the memory
@@ -325,7 +326,7 @@ __device__ void reg_scalar_body(DevState* s, const double* __restrict__ partials
 
 __global__ __launch_bounds__(kBlock) void reg_scalar_kernel(DevState* s, const double* __restrict__ partials, int nblocks,
                                                             DevCfg cfg, Verdict vd) {
-    const bool bad = verdict_bad(vd);  // (this stage may run before the first chain's scalar stage)
+    const bool bad = verdict_bad(vd) || comm_bad(s);  // (this stage may run before the first chain's scalar stage)
     reg_scalar_body(s, partials, nblocks, cfg, bad);
 }
 
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(DevState* s, const dou
                                                           int nbounds, Verdict vd, int flag_word, int zero_bounds,
                                                           const double* __restrict__ reg_partials, int reg_blocks) {
     __shared__ double smem[kBlock / kWave];
-    const bool bad = verdict_bad(vd);
+    const bool bad = verdict_bad(vd) || comm_bad(s);
     if (reg_partials) {
         reg_scalar_body(s, reg_partials, reg_blocks, cfg, bad);
         __syncthreads();

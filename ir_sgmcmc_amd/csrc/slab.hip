@@ -866,6 +866,12 @@ int irs_slab_create(const irs_config* cfg, const irs_slab_config* scfg, irs_comm
             irs_destroy(c);
             return 1;
         }
+        // a timed-out wait of the peer-mapped transport freezes the transition in flight (scalar_kernels.h: comm_bad)
+        const unsigned* ef = comm_error_flag(comm);
+        if (ef && hipMemcpy((char*)c->state + offsetof(DevState, comm_err), &ef, sizeof(ef), hipMemcpyHostToDevice) != hipSuccess) {
+            irs_destroy(c);
+            return fail("irs_slab_create: publishing the transport's error word failed");
+        }
     }
     // the communication stream gets the HIGHEST priority: its send / recv kernels are enqueued while interior launches of a
     // thousand workgroups occupy every CU, and the overlap the schedule is built on needs them to be dispatched ahead of those

@@ -421,6 +421,13 @@ void launch_perturb_sobolev_march(const float* v, const float* sigma, const floa
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const float inv_pow = 1.0f / (float)(1 << no_steps);
     const dim3 grid(ntx, nty, (unsigned)(nseg * C));
+    if (global_knobs().launch_log) {
+        static int cache_l = 0, cache_lh = 0;
+        log_launch(half ? "perturb_sobolev_march_kernel<rows=16>" : "perturb_sobolev_march_kernel<rows=32>", PSX, psy, (int64_t)ntx * nty * nseg * C, kPsBlock,
+                   seg_len, 2 * taps.s, vol.nz, C,
+                   half ? resident_blocks((const void*)perturb_sobolev_march_kernel<3, false, false, 16>, kPsBlock, &cache_lh)
+                        : resident_blocks((const void*)perturb_sobolev_march_kernel<3, false, false, 32>, kPsBlock, &cache_l));
+    }
     const NoiseSrc ns{sigma, eps, amp, seed, iteration, dev_iteration};
 #define IRS_PS(SS, SG, EP, PY) hipLaunchKernelGGL((perturb_sobolev_march_kernel<SS, SG, EP, PY>), grid, dim3(kPsBlock), 0, st, v, ns, out, taps, vol, dmax0, inv_pow, seg_len, nseg)
 #define IRS_PS2(SS)                                   \
@@ -654,6 +661,11 @@ void launch_lcc_fwd_march(const float* fhat, int64_t fhat_stride, const float* i
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + LMX - 1) / LMX, (vol.H + LMY - 1) / LMY, (unsigned)(nseg * C));
     const bool map = fhat != nullptr;
+    if (global_knobs().launch_log) {
+        static int cache_l = 0;
+        log_launch("lcc_fwd_march_kernel", LMX, LMY, (int64_t)grid.x * grid.y * grid.z, kStBlock, seg_len, 4 * s, vol.nz, C,
+                   resident_blocks((const void*)lcc_fwd_march_kernel<1, true>, kStBlock, &cache_l));
+    }
 #define IRS_LCC_FWD(SS)                                                                                                    \
     if (map) hipLaunchKernelGGL((lcc_fwd_march_kernel<SS, true>), grid, dim3(kStBlock), 0, st, fhat, fhat_stride, im, z,  \
                                 sigma_out, vol, seg_len, nseg);                                                           \
@@ -913,6 +925,11 @@ void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* s
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const dim3 grid((vol.W + LMX - 1) / LMX, (vol.H + LMY - 1) / LMY, (unsigned)nseg);
     const DevState* state = (const DevState*)dev_state;
+    if (global_knobs().launch_log) {
+        static int cache_l = 0;
+        log_launch("lcc_data_bwd_march_kernel (per chain)", LMX, LMY, (int64_t)grid.x * grid.y * grid.z, kStBlock, seg_len, 4 * s, vol.nz, 1,
+                   resident_blocks((const void*)lcc_data_bwd_march_kernel<1, false>, kStBlock, &cache_l));
+    }
 #define IRS_LCC_BWD(SS)                                                                                                      \
     if (g_z_override) hipLaunchKernelGGL((lcc_data_bwd_march_kernel<SS, true>), grid, dim3(kStBlock), 0, st, fhat, z,       \
                                          sigma_m, mask, g_z_override, state, chain, g_warped, nll_partials, vol, seg_len,   \
@@ -1058,6 +1075,12 @@ void launch_stats_march(int want_vd, const float* z, const uint8_t* mask, const 
     const int seg_len = pick_seg_len(vol.nz, (int64_t)((vol.W + QTX - 1) / QTX) * ((vol.H + TTY - 1) / TTY), 4, seg_env, 2048);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + TTY - 1) / TTY;
+    if (global_knobs().launch_log) {
+        static int cache_l = 0;
+        const int64_t tiles = (int64_t)ntx * nty * nseg;
+        log_launch("stats_march_kernel<4> (tiles walked by a capped grid)", QTX, TTY, tiles < blocks ? tiles : blocks, kStBlock, seg_len, 1, vol.nz, 1,
+                   resident_blocks((const void*)stats_march_kernel<4>, kStBlock, &cache_l));
+    }
     if (K >= 1 && K <= 4)
         hipLaunchKernelGGL(stats_march_kernel<4>, dim3(blocks), dim3(kStBlock), 0, st, z, mask, (const DevState*)dev_state, want_vd,
                            partials, vol, seg_len, nseg, ntx, nty);
@@ -1189,7 +1212,7 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
     const int x = ox + lx, y = oy + ly;
     const bool col_in = x < vol.W && y < vol.H;
     const float coef2 = coef_from_w ? (float)exp(state->st.reg_param[0]) : 2.0f * (float)state->coef[chain];  // 2 coef; L2 family: coef = w / 2
-    const bool frozen = state->bad_now != 0u;  // the transition turned out to be a no-op (scalar_kernels.h: Verdict): v stays
+    const bool frozen = state->bad_now != 0u || comm_bad(state);  // the transition turned out to be a no-op (scalar_kernels.h: Verdict, comm_bad): v stays
     const float sc[3] = {s0, s1, s2};
     // weights of the two difference terms touching a position: w(q) = 2 for the last (replicated) difference q = n - 2
     auto wm = [](int pos, int n) { return pos >= 1 ? (pos - 1 == n - 2 ? 2.0f : 1.0f) : 0.0f; };
@@ -1322,6 +1345,11 @@ void launch_sgld_update_march(float* v, const float* sigma, const float* g_d0, c
     const int seg_len = update_seg_len(vol, C);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
     const int ntx = (vol.W + QTX - 1) / QTX, nty = (vol.H + QTY - 1) / QTY;
+    if (global_knobs().launch_log) {
+        static int cache_l = 0;
+        log_launch("sgld_update_march_kernel", QTX, QTY, (int64_t)ntx * nty * nseg * C, kStBlock, seg_len, 2, vol.nz, C,
+                   resident_blocks((const void*)sgld_update_march_kernel<false>, kStBlock, &cache_l));
+    }
     if (sigma)
         hipLaunchKernelGGL(sgld_update_march_kernel<true>, dim3((unsigned)(ntx * nty * nseg * C)), dim3(kStBlock), 0, st, v, sigma, g_d0,
                            v_s, (const DevState*)dev_state, lr, s0, s1, s2, grad_out, vol, seg_len, nseg, ntx, nty, energy_partials,

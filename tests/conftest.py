@@ -8,6 +8,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The default `-m gpu` run has to fit the driver's time limit with room to spare: the soak runs and the extra fuzz draws only run
+# with IRS_LONG=1 in the environment (an explicit skip with this reason otherwise -- never a marker `-m gpu` would deselect silently).
+LONG = os.environ.get('IRS_LONG') == '1'
+long_only = pytest.mark.skipif(not LONG, reason='long-running: set IRS_LONG=1 (soak runs, extra fuzz seeds)')
+
+
+def fuzz_seeds(env_name, default, long_default):
+    """seed list of a fuzz suite: `env_name` overrides; `default` draws normally -- the ones that exercise distinct code paths, picked
+    from the 10 .. 12 the suites ran in round 4 --, `long_default` with IRS_LONG=1"""
+    v = os.environ.get(env_name)
+    if v:
+        return list(range(int(v)))
+    return list(long_default) if LONG else list(default)
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

@@ -309,3 +309,72 @@ def test_misprediction_is_recovered(cps, amp):
     assert res[0][2] == 0 and res[1][2] >= 1
     assert res[0][3] == res[1][3]
     assert torch.equal(res[0][0], res[1][0])
+
+
+def _stall_worker(rank, world, port, q, stall_s):
+    """two ranks over ipc; rank 1 stops enqueueing for `stall_s` seconds before its second transition"""
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from ir_sgmcmc_amd._lib import IrsError
+        from ir_sgmcmc_amd.slab import SlabComm, SlabEngine
+        torch.cuda.set_device(0)
+        comm = SlabComm.create('ipc', DEV)
+        comm.selftest()
+        cfg, fixed, moving, v0, noise = _setup(24, 1, 'GMM', with_noise=False, amp=4.0)
+        eng = SlabEngine(cfg, DEV, comm, ghost_max=4)
+        fd, md = eng.prepare(fixed, moving)
+        eng.gmm_init(fd, md)
+        v = eng.local_v(v0)
+        eng.transition(fd, md, v)
+        eng.flush()
+        torch.cuda.synchronize()
+        v1, st1 = v.clone(), eng.state()
+        dist.barrier()
+        if rank == 1:
+            time.sleep(stall_s)
+        err = None
+        try:
+            eng.transition(fd, md, v)   # rank 0: its first wait times out on the device; rank 1 (later): rank 0 raised no flag any more
+            eng.flush()
+        except IrsError as e:
+            err = str(e)
+        torch.cuda.synchronize()
+        st2 = eng.state()
+        same = (list(st1.gmm_log_std), list(st1.gmm_logits), list(st1.gmm_adam_step), list(st1.reg_param)) == \
+               (list(st2.gmm_log_std), list(st2.gmm_logits), list(st2.gmm_adam_step), list(st2.reg_param))
+        q.put((rank, err, bool(torch.equal(v, v1)), int(st1.iteration), int(st2.iteration), same))
+        dist.barrier()
+        del eng
+        comm.close()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ipc_timeout_is_fail_safe(monkeypatch):
+    """A peer that is late beyond IRS_IPC_TIMEOUT_S: the waiting kernel gives up, and NOTHING of the transition that ran on the
+    stale landing slot is applied -- velocity, mixture / regulariser parameters, Adam moments and the iteration counter are those
+    of the last good transition (csrc/ipc.hip: sticky error word; scalar_kernels.h: comm_bad) -- the call returns the error, and
+    the rank that stalled finds no flag raised by the failed one and fails the same way instead of consuming what it pushed."""
+    monkeypatch.setenv('IRS_IPC_TIMEOUT_S', '1.5')  # (inherited by the spawned ranks)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stall_worker, args=(r, 2, port, q, 5.0)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    for rank, err, v_same, it1, it2, params_same in res:
+        assert err is not None and 'timed out' in err, (rank, err)
+        assert v_same and params_same and it1 == it2 == 1, (rank, v_same, params_same, it1, it2)
