@@ -690,7 +690,13 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #define IRS_BWD_R1_FALLBACK 1
 #endif
 #ifndef IRS_BWD_PEEL
-#define IRS_BWD_PEEL 1  // radius-1 adjoint: run-in plane steps update only the accumulators whose output plane is inside the segment
+// radius-1 adjoint: run-in plane steps update only the accumulators whose output plane is inside the segment (6 of the 30
+// accumulator updates of an 8-plane segment land outside it).  Built in round 5 as asked (per-mask instantiations of the gather
+// behind a wave-uniform dispatch; the full gather, commit and own-term blocks unchanged instruction for instruction,
+// tools/debug/isa_block_diff.py; chains bit-identical) and measured SLOWER on one box, three / two alternating repetitions:
+// 128^3 36.6-37.2 against 35.5-35.8 us per launch, 256^3 223-229 against 215-218 (profiles/r05_peel_ab.txt) -- the kernel grows from
+// 2 687 to 4 363 instructions and the dispatch sits in front of every gather.  Off.
+#define IRS_BWD_PEEL 0
 #endif
 // hat of (r + c) for a relative position r and a compile-time integer offset c.
 template <int R>
@@ -1230,6 +1236,25 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
 #ifndef IRS_FWD_PITCH_ALIGN
 #define IRS_FWD_PITCH_ALIGN 16
 #endif
+#ifndef IRS_FWD_TAPS
+#define IRS_FWD_TAPS 0  // 0: the compiler's LDS reads (ds_read2_b64 / ds_read2_b32 corner pairs); 1: one ds_read_b64 + ds_read_b32 per corner
+#endif
+// LDS reads the compiler cannot pair (inline asm; it does not count them either: lds_wait_all before their first use).
+// The byte address of a __shared__ object is the low half of its flat address.
+__device__ __forceinline__ unsigned lds_byte_addr(const void* p) { return (unsigned)(uintptr_t)p; }
+template <int OFF>
+__device__ __forceinline__ float2 lds_rd64(unsigned a) {
+    float2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ float lds_rd32(unsigned a) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // FROWS is a template parameter of the radius-1 kernel: two rows per thread (256 threads) where the launch fills the chip; ONE row
 // per thread (512 threads, 8 waves per tile) on small volumes and thin slabs, where a launch has a workgroup or two per CU and
 // twice the waves per tile hide more of a plane step's latency (128^3: 22.9 against 24.7 us per step; at 256^3 it loses, 142
@@ -1360,6 +1385,11 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
 #ifdef IRS_FWD_TRACE
     const bool trace_on = R == 1 && !PRESCALE && tile_id == (int)(tiles.x * tiles.y * tiles.z) / 2 + 3 && threadIdx.x == 64;
     int trace_it = 0;
+    if (trace_on) {  // entry 63: tile set-up done (clock64, 100 MHz wall clock) ... loop left (both again): prologue and clock rate
+        g_fwd_trace[63 * 8 + 0] = clock64();
+        g_fwd_trace[63 * 8 + 1] = wall_clock64();
+        g_fwd_trace[63 * 8 + 4] = (unsigned long long)(slast - sbase + 1);
+    }
 #endif
     static_assert(NS % PF == 0, "the buffer of plane s is (s - sbase) % PF == PH % PF");
     prefetch(sbase, pre[0]);
@@ -1417,18 +1447,63 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                         sl1 = rel == q ? ((a + q + 1 + NS) % NS) * PNP : sl1;
                     }
                     const int off = by0 * PITCH + bx0;
+#if IRS_FWD_TAPS == 1 || IRS_FWD_TAPS == 2
+                    // every corner its own ds_read_b64 + ds_read_b32: the compiler pairs the cx = 0 / 1 corners into ds_read2_b64 +
+                    // ds_read2_b32, and a ds_read2_b64 occupies the LDS for 8 cycles where two ds_read_b64 take 4 (MI355X_MICROARCH.md,
+                    // LDS table; tools/probes/lds_tap_probe.hip measures the tap pattern of this kernel under both).  Same values,
+                    // same products, same order of the additions.  IRS_FWD_TAPS 1: the sixteen reads of a voxel in one batch
+                    // (24 registers of corner data at once); 2: the two z corners one after the other (12).
+                    const unsigned bxy = lds_byte_addr(r_xy), bzz = lds_byte_addr(r_z);
+                    float2 txy[2][2][2];
+                    float tzz[2][2][2];
+                    auto issue = [&](int cz) {
+                        const unsigned e = (unsigned)((cz ? sl1 : sl0) + off);
+                        const unsigned xa = bxy + 8u * e, za = bzz + 4u * e;
+                        txy[cz][0][0] = lds_rd64<0>(xa);
+                        txy[cz][0][1] = lds_rd64<8>(xa);
+                        txy[cz][1][0] = lds_rd64<8 * PITCH>(xa);
+                        txy[cz][1][1] = lds_rd64<8 * PITCH + 8>(xa);
+                        tzz[cz][0][0] = lds_rd32<0>(za);
+                        tzz[cz][0][1] = lds_rd32<4>(za);
+                        tzz[cz][1][0] = lds_rd32<4 * PITCH>(za);
+                        tzz[cz][1][1] = lds_rd32<4 * PITCH + 4>(za);
+                    };
+                    if (IRS_FWD_TAPS == 1) {
+                        issue(0);
+                        issue(1);
+                        lds_wait_all();
+                    }
+#endif
 #pragma unroll
                     for (int cz = 0; cz < 2; ++cz) {
                         const int bs = (cz ? sl1 : sl0) + off;
+#if IRS_FWD_TAPS == 2
+                        issue(cz);
+                        lds_wait_all();
+#endif
 #pragma unroll
                         for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
                             for (int cx = 0; cx < 2; ++cx) {
                                 const float w = __fmul_rn(wxy[cy][cx], cz ? tz.w1 : tz.w0);
-                                const float2 txy = r_xy[bs + cy * PITCH + cx];
-                                a0 = __fadd_rn(a0, __fmul_rn(txy.x, w));
-                                a1 = __fadd_rn(a1, __fmul_rn(txy.y, w));
-                                a2 = __fadd_rn(a2, __fmul_rn(r_z[bs + cy * PITCH + cx], w));
+#if IRS_FWD_TAPS == 3
+                                // volatile: the load / store optimiser leaves such accesses alone (no ds_read2 pairs), the compiler still
+                                // counts and schedules them
+                                typedef float VF2 __attribute__((ext_vector_type(2)));
+                                const VF2 tv = *(const volatile __attribute__((address_space(3))) VF2*)(&r_xy[bs + cy * PITCH + cx]);
+                                const float2 t2 = make_float2(tv.x, tv.y);
+                                const float t1 = *(const volatile __attribute__((address_space(3))) float*)(&r_z[bs + cy * PITCH + cx]);
+#elif IRS_FWD_TAPS >= 1
+                                (void)bs;
+                                const float2 t2 = txy[cz][cy][cx];
+                                const float t1 = tzz[cz][cy][cx];
+#else
+                                const float2 t2 = r_xy[bs + cy * PITCH + cx];
+                                const float t1 = r_z[bs + cy * PITCH + cx];
+#endif
+                                a0 = __fadd_rn(a0, __fmul_rn(t2.x, w));
+                                a1 = __fadd_rn(a1, __fmul_rn(t2.y, w));
+                                a2 = __fadd_rn(a2, __fmul_rn(t1, w));
                             }
                     }
                 };
@@ -1474,6 +1549,12 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
 #endif
         }
     }
+#ifdef IRS_FWD_TRACE
+    if (trace_on) {
+        g_fwd_trace[63 * 8 + 2] = clock64();
+        g_fwd_trace[63 * 8 + 3] = wall_clock64();
+    }
+#endif
     if (dmax_out) {
         m0 *= 0.5f * sc.nm1[0];
         m1 *= 0.5f * sc.nm1[1];

@@ -107,7 +107,19 @@ struct IpcState {
 
 namespace {
 
-int host_barrier(IpcState* s, double timeout_s = 120.0) {
+// how long a rank waits for the others at a bootstrap step (creation, reservation of the landing area): IRS_IPC_BOOT_TIMEOUT_S,
+// default 120 s -- a peer that DIED (it cannot raise `failed` any more) costs the survivors this long
+double boot_timeout_s() {
+    static double t = 0.0;
+    if (t <= 0.0) {
+        const char* e = getenv("IRS_IPC_BOOT_TIMEOUT_S");
+        t = e && atof(e) > 0.0 ? atof(e) : 120.0;
+    }
+    return t;
+}
+
+int host_barrier(IpcState* s, double timeout_s = 0.0) {
+    if (timeout_s <= 0.0) timeout_s = boot_timeout_s();
     Shm* m = s->shm;
     __atomic_add_fetch(&m->arrived, 1u, __ATOMIC_ACQ_REL);
     const uint32_t want = (uint32_t)s->world * (++s->barriers);

@@ -27,6 +27,9 @@ def run(name, rank, world, device_index, timeout=120.0):
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'TORCHELASTIC_RUN_ID'):   # the child is nobody's rank but its argument's
         env.pop(k, None)
     env.setdefault('IRS_IPC_TIMEOUT_S', '10')
+    # the children of all ranks start together: one that waits longer than this for a peer at a bootstrap step is waiting for a
+    # child that died (the library's default of 120 s is for ranks whose start-up may be minutes apart)
+    env.setdefault('IRS_IPC_BOOT_TIMEOUT_S', '45')
     try:
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=_ROOT)
     except subprocess.TimeoutExpired:

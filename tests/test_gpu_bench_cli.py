@@ -67,12 +67,14 @@ def test_bench_auto_transport_survives_a_transport_that_fails():
 def test_bench_auto_transport_survives_a_preflight_child_that_dies():
     """the peer-mapped transport's first stores into another rank's memory happen in a child of every rank: a child that dies there
     (a mapping the node cannot reach is a memory fault, not an error code) costs the run the ipc transport, not the run -- here
-    RCCL cannot come up either (one device), so the run ends with the no-transport exit code and says what happened"""
+    RCCL cannot come up either (one device), so the run ends with the no-transport exit code and says what happened.
+    (IRS_IPC_BOOT_TIMEOUT_S: the surviving child waits that long for the dead one at the next bootstrap step -- with the pre-flight's
+    default of 45 s this test took 2 x 120 s of the round-4 suite's 764.)"""
     p = _run(['--gpus', '2', '--size', '32', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--transport', 'auto'],
-             {'IRS_BENCH_DEVICE': '0', 'IRS_BENCH_PREFLIGHT': '1', 'IRS_IPC_PREFLIGHT_SIMULATE_FAULT': '1'}, expect_rc=1)
+             {'IRS_BENCH_DEVICE': '0', 'IRS_BENCH_PREFLIGHT': '1', 'IRS_IPC_PREFLIGHT_SIMULATE_FAULT': '1', 'IRS_IPC_BOOT_TIMEOUT_S': '6'}, expect_rc=1)
     assert 'pre-flight child of rank 1 ended with code' in p.stderr and 'no slab transport came up' in p.stderr
     d = _run(['--gpus', '2', '--size', '32', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--transport', 'auto', '--allow-chain-fallback'],
-             {'IRS_BENCH_DEVICE': '0', 'IRS_BENCH_PREFLIGHT': '1', 'IRS_IPC_PREFLIGHT_SIMULATE_FAULT': '1'})
+             {'IRS_BENCH_DEVICE': '0', 'IRS_BENCH_PREFLIGHT': '1', 'IRS_IPC_PREFLIGHT_SIMULATE_FAULT': '1', 'IRS_IPC_BOOT_TIMEOUT_S': '6'})
     assert d['scaling'] == 'weak' and 'pre-flight' in d['slab_transport_failure']
 
 

@@ -11,11 +11,12 @@ import torch
 from ir_sgmcmc_amd import ops as G
 from oracle import ops as O
 from tests._report import GRAD_RTOL
+from tests.conftest import fuzz_seeds
 from tests.test_gpu_fuzz import check_but_flips
 from tests.test_gpu_ops import dev, maxdiff, smooth_field
 
 pytestmark = pytest.mark.gpu
-SEEDS = list(range(int(os.environ.get('IRS_OPS_FUZZ_SEEDS', '10'))))   # (IRS_OPS_FUZZ_SEEDS=100: a longer hunt)
+SEEDS = fuzz_seeds('IRS_OPS_FUZZ_SEEDS', range(5), range(10))   # (IRS_LONG=1: ten draws; IRS_OPS_FUZZ_SEEDS=100: a longer hunt)
 
 
 def _dims(r, lo=7, hi=46):

@@ -19,6 +19,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from tests.conftest import LONG, long_only
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 T = 3  # transitions: the first measures the ghost widths (exact mode), the second and third run from predicted widths
@@ -153,6 +155,13 @@ def _launch(world, *args, transport='rehearsal', expect_exact=1):
 
 
 TRANSPORTS = ['rehearsal', 'ipc']
+# The synchronous rehearsal transport (gloo + host staging) runs the same schedule and the same kernels as `ipc`, minus the asynchrony
+# that found the bugs of round 4: by default it runs two of the exchange configurations (a plain one and the three-rank one); the other
+# rehearsal cases, the 256^3 duplicates and the 40-transition runs need IRS_LONG=1 (tests/conftest.py) -- the suite had grown to
+# 764 s of the driver's 900.
+REHEARSAL_TOO = {('GMM', 1, 32, 2, 4, 9.0), ('GMM', 1, 48, 3, 4, 9.0)}
+_rehearsal_long = lambda: pytest.param('rehearsal', marks=long_only)
+TRANSPORTS_LONG = [_rehearsal_long(), 'ipc']   # rehearsal only with IRS_LONG=1
 
 
 @pytest.mark.parametrize('transport', TRANSPORTS)
@@ -164,6 +173,8 @@ TRANSPORTS = ['rehearsal', 'ipc']
     ('GMM', 1, (27, 20, 22), 3, 12, 3.0),  # 9-plane slabs and a round limit of 12: lowered to what a slab can send its neighbour (9 - sobolev_s)
 ])
 def test_slab_ranks_exchange_ghost_planes(data_loss, C, N, world, ghost_max, amp, transport):
+    if transport == 'rehearsal' and not LONG and (data_loss, C, N, world, ghost_max, amp) not in REHEARSAL_TOO:
+        pytest.skip('rehearsal duplicate of the ipc case: set IRS_LONG=1')
     dv, dd, ds, st = _launch(world, data_loss, C, N, True, amp, 'RegLoss_LogNormal', ghost_max, transport=transport)
     from tests._report import check
     name = f'slab_{transport}/{data_loss}_C{C}_N{N if isinstance(N, int) else "x".join(map(str, N))}_ranks{world}_g{ghost_max}_amp{amp:g}'
@@ -201,6 +212,7 @@ def test_slab_without_the_interior_boundary_split(monkeypatch, world, N, ghost_m
     check(name, 'loss terms (rel)', ds, 0.0, 1e-6)
 
 
+@long_only
 @pytest.mark.parametrize('transport', TRANSPORTS)
 def test_slab_long_run_replans_every_transition(transport):
     """40 consecutive transitions on two ranks: after the first (measuring) transition every plan comes from the bounds of
@@ -214,7 +226,7 @@ def test_slab_long_run_replans_every_transition(transport):
     check(name, 'loss terms (rel)', ds, 0.0, 1e-5)
 
 
-@pytest.mark.parametrize('transport', TRANSPORTS)
+@pytest.mark.parametrize('transport', TRANSPORTS_LONG)
 @pytest.mark.parametrize('data_loss,C,N,world,cps', [('GMM', 1, 32, 2, (4, 4, 4)), ('SSD', 2, 36, 3, (2, 2, 2))])
 def test_slab_svffd(data_loss, C, N, world, cps, transport):
     """SVFFD_3D (utils/transformation.py:126-164; the experiment5 configs): control grid whole on every rank, dense velocity
@@ -227,7 +239,7 @@ def test_slab_svffd(data_loss, C, N, world, cps, transport):
     check(name, 'loss terms (rel)', ds, 0.0, 1e-6)
 
 
-@pytest.mark.parametrize('transport', TRANSPORTS)
+@pytest.mark.parametrize('transport', TRANSPORTS_LONG)
 def test_config4_256_cubed_ssd_two_slabs(transport, monkeypatch):
     """BASELINE.json config 4 at its own size: 256^3, SSD + RegLoss_L2, one chain in two z-slabs vs the fused engine.
     (ipc: with a first landing area of 1 MiB per slot, so that the context outgrows it and the communicator re-exports a larger
@@ -240,7 +252,7 @@ def test_config4_256_cubed_ssd_two_slabs(transport, monkeypatch):
     check(f'slab_{transport}/config4_256_ssd_ranks2', 'loss terms (rel)', ds, 0.0, 1e-6)
 
 
-@pytest.mark.parametrize('transport', TRANSPORTS)
+@pytest.mark.parametrize('transport', TRANSPORTS_LONG)
 def test_bench_workload_256_cubed_gmm_four_slabs(transport):
     """The workload bench.py times (256^3, GMM / LCC with virtual decimation, RegLoss_L2, in-kernel noise) as one chain in FOUR
     z-slabs of 64 planes (middle ranks with two neighbours, ghost exchanges in both directions) vs the fused engine."""

@@ -7,6 +7,7 @@ import random
 
 import pytest
 
+from tests.conftest import fuzz_seeds
 from tests.test_gpu_slab import _launch
 
 pytestmark = pytest.mark.gpu
@@ -29,7 +30,10 @@ def _draw(seed):
                 reg=r.choice(['RegLoss_LogNormal', 'RegLoss_L2']), ghost_max=ghost_max, split=r.choice([1, 1, 0]))
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('IRS_SLAB_FUZZ_SEEDS', '6')))))   # (IRS_SLAB_FUZZ_SEEDS=60: a longer hunt)
+# default draws: 0 (three ranks, SVFFD_3D cps 2, three chains, round limit 1), 1 (two ranks, SSD, two chains, round limit 12, 9-voxel start),
+# 5 (four ranks -- middle ranks with two neighbours --, unsplit launches, 9-voxel start).  IRS_LONG=1: the six of round 4;
+# IRS_SLAB_FUZZ_SEEDS=60: a longer hunt
+@pytest.mark.parametrize('seed', fuzz_seeds('IRS_SLAB_FUZZ_SEEDS', (0, 1, 5), range(6)))
 def test_random_slab_configuration_equals_the_fused_engine(seed, monkeypatch):
     k = _draw(seed)
     monkeypatch.setenv('IRS_SLAB_SPLIT', str(k['split']))   # (inherited by the spawned ranks)
@@ -38,13 +42,12 @@ def test_random_slab_configuration_equals_the_fused_engine(seed, monkeypatch):
     from tests._report import check
     name = 'slab_fuzz/%d_%s_ranks%d_%s_C%d_cps%s_g%d_amp%g_split%d' % (seed, 'x'.join(map(str, k['dims'])), k['world'], k['data_loss'], k['C'],
                                                                       k['cps'][0] if k['cps'] else 0, k['ghost_max'], k['amp'], k['split'])
-    # The slab chain is not the fused chain bit for bit (the statistics are summed per rank, then over the ranks): the two drift apart
-    # at 1e-7, and a voxel whose sampling position lies within that of a cell face then takes the other one-sided derivative in one
-    # of them -- ONE gradient element, O(1e-4) of the maximum (seed 62 of the long hunt: 1 element of 117 936 at 1.8e-4, everything
-    # else below 1e-6; tools/debug/slab_diff.py).  A wrong or missing ghost plane is thousands of elements.
-    if dv > 1e-5 and st['v_elements_beyond_1e-5'] <= 3:
-        check(name, 'v_new (rel to max), cell-face elements', dv, 0.0, 2e-3)
-    else:
-        check(name, 'v_new (rel to max)', dv, 0.0, 1e-5)
+    # Strict: 1e-5 on every element.  (The slab chain is not the fused chain bit for bit -- the statistics are summed per rank, then
+    # over the ranks -- and in a long hunt ONE draw, seed 62, had one gradient element of 117 936 at 1.8e-4 where a sampling position
+    # sat within rounding of a cell face and took the other one-sided derivative.  Round 4 relaxed the criterion for <= 3 such elements
+    # without asserting the cell-face condition; a one- or two-voxel defect of a boundary strip would have passed the same way, so the
+    # relaxation is gone: a draw that fails here is diagnosed (tools/debug/slab_diff.py: per plane and per transition, with the
+    # count of deviating elements), not waved through.)
+    check(name, 'v_new (rel to max)', dv, 0.0, 1e-5)
     check(name, 'displacement [voxels]', dd, 0.0, 1e-5)
     check(name, 'loss terms (rel)', ds, 0.0, 1e-6)

@@ -9,6 +9,8 @@ import random
 import pytest
 import torch
 
+from tests.conftest import fuzz_seeds
+
 from oracle import OracleChain, OracleConfig
 from oracle.transition import OracleVI, OracleVIConfig
 
@@ -16,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('IRS_VI_FUZZ_SEEDS', '5')))))   # (=40: a longer hunt)
+@pytest.mark.parametrize('seed', fuzz_seeds('IRS_VI_FUZZ_SEEDS', (0, 1), range(5)))   # (IRS_LONG=1: five draws; IRS_VI_FUZZ_SEEDS=40: a longer hunt)
 def test_random_vi_iterations_against_the_oracle(seed, tmp_path):
     from ir_sgmcmc_amd.data_loader import synthetic_pair
     from ir_sgmcmc_amd.parse_config import ConfigParser

@@ -41,8 +41,9 @@ def main():
     fn = lib.irs_debug_fwd_trace
     fn.argtypes = [C.POINTER(C.c_ulonglong)]
     assert fn(buf) == 0
-    t = [[buf[i * 8 + j] for j in range(6)] for i in range(64)]
+    t = [[buf[i * 8 + j] for j in range(6)] for i in range(63)]
     t = [r for r in t if r[0]]
+    e = [buf[63 * 8 + j] for j in range(5)]   # entry 63: (clock64, 100 MHz wall clock) after the tile set-up and after the loop; plane steps
     # the last launch that traced overwrote the earlier ones: one workgroup's plane steps in order
     names = ['wait for loads', 'commit to LDS', 'issue next loads', 'barrier', 'compute + stores']
     rows = []
@@ -56,6 +57,12 @@ def main():
         print(f'  {nme:18s} mean {sum(col) / len(col):8.1f}   min {min(col):6d}   max {max(col):6d}')
     tot = [sum(r) for r in rows]
     print(f'  per plane step     mean {sum(tot) / len(tot):8.1f}')
+    if e[0] and e[2] > e[0] and e[3] > e[1]:
+        ticks, wall_ns = e[2] - e[0], (e[3] - e[1]) * 10.0
+        print(f'  whole marching loop of this workgroup: {int(e[4])} plane steps, {ticks} ticks = {wall_ns / 1e3:.2f} us '
+              f'({ticks / wall_ns * 1e3:.0f} MHz tick rate; {wall_ns / max(int(e[4]), 1):.0f} ns per plane step)')
+        if rows:
+            print(f'  first plane step starts {t[0][0] - e[0]} ticks after the tile set-up (first prefetches issued in between)')
 
 
 if __name__ == '__main__':
