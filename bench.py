@@ -330,6 +330,10 @@ def main():
                     failures.append(err)
                     continue
                 preflight_info = pre
+                # sequence flags in device memory (one xGMI store + local polls per hand-over instead of two PCIe round trips) where
+                # EVERY rank's child saw them work; host flags otherwise (csrc/ipc.hip; IRS_IPC_FLAGS set by hand is left alone)
+                if 'IRS_IPC_FLAGS' not in os.environ and agree(bool(pre.get('device_flags'))):
+                    os.environ['IRS_IPC_FLAGS'] = 'device'
             got, err = bring_up(name)
             if got is None:
                 failures.append(err)
@@ -409,10 +413,34 @@ def main():
     # when asked: inside the timed region, so that the K steps timed are K VALID transitions whatever happened (normally a no-op)
     eng.flush()
     sync()
-    elapsed = par.max_over_ranks(time.perf_counter() - t0)
+    elapsed_here = time.perf_counter() - t0
+    elapsed = par.max_over_ranks(elapsed_here)
     assert bool(torch.isfinite(v).all()), 'chain diverged'
+    slab_diag = None
     if slab:
         slab_status = eng.status()   # mispredictions are reported in the output line (`slab`), not fatal: the chain was repaired
+        # What makes a first run on a node diagnosable (outside the timed region): every rank's own time per transition, and the
+        # hand-over timeline of one more transition on a scratch copy of the field -- per exchange round and all-reduce, how long the
+        # communication stream took from "data ready" to "delivered" and how long the compute stream STALLED at the launch that
+        # needs it (irs_slab_timeline_*: HIP events on the two streams the executor already orders).  A slow transport shows as long
+        # hand-overs on every rank, load imbalance as stalls on the fast ranks only, a split that does not overlap as stall ~ hand-over.
+        mine = {'rank': rank, 'ms_per_transition': 1e3 * elapsed_here / args.steps}
+        try:
+            scratch = v.clone()
+            eng.timeline_arm(2)
+            for _ in range(2):
+                eng.transition(fixed, moving, scratch)
+            eng.flush()
+            entries, total_us = eng.timeline()
+            del scratch
+            mine.update(transition_us=round(total_us, 1), stall_us=round(sum(e['stall_us'] for e in entries), 1),
+                        handover_us=round(sum(e['handover_us'] for e in entries), 1),
+                        rounds=[[e['kind'][0] + str(e['stage']), e['k'], e['width'], e['handover_us'], e['stall_us']] for e in entries])
+        except Exception as e:  # noqa: BLE001  (a diagnostic must not cost the measurement)
+            mine['timeline_error'] = f'{type(e).__name__}: {e}'
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        slab_diag = gathered
 
     # ---- side measurements on rank 0 (outside the timed region) ------------------------------------------------------------
     extras = {}
@@ -511,7 +539,12 @@ def main():
             out['slab'] = {'transport': transport, 'transport_info': comm.describe(), 'transport_trials_ms': trials, 'ipc_preflight': preflight_info, 'interior_boundary_split': split_on, 'split_trials_ms': split_trials, 'planes_owned': eng.b - eng.a, 'planes_held': eng.hi - eng.lo, 'ghost_max': eng.ghost_max,
                            'exchange_rounds_per_transition': st['exchanges'] / max(st['transitions'], 1),
                            'MB_sent_per_transition_rank0': st['exchanged_bytes'] / max(st['transitions'], 1) / 1e6,
-                           'exact_transitions': st['exact_transitions'], 'mispredictions': st['mispredictions']}
+                           'exact_transitions': st['exact_transitions'], 'mispredictions': st['mispredictions'],
+                           'ms_per_transition_by_rank': {'min': min(d['ms_per_transition'] for d in slab_diag), 'max': max(d['ms_per_transition'] for d in slab_diag),
+                                                         'all': [round(d['ms_per_transition'], 4) for d in slab_diag]},
+                           # per rank, one sampled transition: [kind + stage ('e' exchange of buffer IRS_SB_*, 'a' all-reduce IRS_AR_*), adjoint step,
+                           # ghost planes, hand-over us on the communication stream, stall us of the compute stream]
+                           'round_wait_us': [{k: d.get(k) for k in ('rank', 'transition_us', 'handover_us', 'stall_us', 'rounds', 'timeline_error') if k in d} for d in slab_diag]}
         if world == 1 and not args.no_extras:
             also = {}
             print('[bench] extras: SSD, displaced start, 128^3, sustained run ...', file=sys.stderr, flush=True)

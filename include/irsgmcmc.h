@@ -257,8 +257,9 @@ int irs_transition_timed(irs_ctx* ctx, const irs_io* io, void* stream, irs_timin
  * whole (67 MB at 256^3): the warp may then sample it at any displacement without traffic.
  *
  * irs_slab_transition runs the same kernels as irs_transition on windows of the slab and moves ghost planes between
- * neighbouring ranks with the communicator (RCCL ncclSend / ncclRecv on a communication stream of its own; four small
- * ncclAllReduce for the partial sums) -- no host synchronisation, no Python between the stages:
+ * neighbouring ranks with the communicator (RCCL ncclSend / ncclRecv groups, or producer-side stores into peer-mapped landing areas, on a
+ * communication stream of its own; three small all-reduces per transition -- displacement bounds, statistics per chain, data-term
+ * sums together with the regulariser energies) -- no host synchronisation, no Python between the stages:
  *   - stencil halos of fixed width (Sobolev s, LCC 4 s, update 1);
  *   - gather halos of the squaring steps, whose width floor(max|d_k|) + 1 follows the displacement: planned on the host from
  *     the all-reduced bounds of an earlier transition (never waited for), validated on the device afterwards
@@ -343,6 +344,24 @@ typedef struct irs_slab_status {
 /* blocking (waits for the enqueued transitions). A non-zero `mispredictions` is also returned as an error by the next
  * irs_slab_transition. */
 int irs_slab_status_get(irs_ctx* ctx, irs_slab_status* out, void* stream);
+/* Hand-over TIMELINE of one slab transition: what a first run on a node needs in order to tell a slow transport from load imbalance
+ * from a serialised interior / boundary split (the reference has no counterpart: base/base_trainer.py:16 is single-device).
+ * irs_slab_timeline_arm(ctx, t): the next `t` transitions record timing events around every exchange and all-reduce (a few
+ * hipEventRecord per hand-over: off the timed path -- bench.py arms it on its trial transitions); the LAST armed one is kept.
+ * irs_slab_timeline_get: blocking; entries in schedule order, *n_entries = how many there were (also when max_entries is smaller),
+ * *total_us = first launch .. last launch of that transition on this rank. */
+typedef struct irs_slab_timeline_entry {
+    int32_t kind;       /* IRS_OP_EXCHANGE | IRS_OP_ALLREDUCE */
+    int32_t stage;      /* exchange: the buffer (IRS_SB_*); all-reduce: IRS_AR_* */
+    int32_t k, width;   /* exchange: adjoint step that consumes it (-1: none), ghost planes per side */
+    float ready_us;     /* since the transition's first launch: the data to hand over was ready on the compute stream (event P) */
+    float handover_us;  /* P .. the communication stream finished the hand-over (event R): push, waiting for the peer, drain / reduce */
+    float wait_at_us;   /* since the first launch: the compute stream reached the launch that needs R (-1: never waited for) */
+    float stall_us;     /* how long the compute stream stood still there (0: the hand-over was hidden behind interior work) */
+} irs_slab_timeline_entry;
+int irs_slab_timeline_arm(irs_ctx* ctx, int transitions);
+int irs_slab_timeline_get(irs_ctx* ctx, irs_slab_timeline_entry* out, int max_entries, int32_t* n_entries, float* total_us, void* stream);
+
 /* The schedule of the squaring steps as pure host arithmetic (tests, documentation): given the per-step ghost widths
  * h[0..n) (= floor(max|d_k|) + 1), the widest exchange and the smallest slab, fill fwd_round[k] / bwd_round[k] with the index
  * of the exchange round step k belongs to, and fwd_width[r] / bwd_width[r] with the planes that round exchanges (round 0 of

@@ -86,6 +86,11 @@ class IrsSlabStatus(C.Structure):
                 ('last_bwd_rounds', C.c_int32)]
 
 
+class IrsSlabTimelineEntry(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('stage', C.c_int32), ('k', C.c_int32), ('width', C.c_int32), ('ready_us', C.c_float),
+                ('handover_us', C.c_float), ('wait_at_us', C.c_float), ('stall_us', C.c_float)]
+
+
 class IrsSlabOp(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('kind', 'stage', 'k', 'lo0', 'hi0', 'lo1', 'hi1', 'in0', 'in1', 'reach', 'out', 'width', 'id')]
 
@@ -151,6 +156,8 @@ SIGNATURES = {
     'irs_slab_transition': [_P, C.POINTER(IrsIO), _P],
     'irs_slab_gmm_init': [_P, C.POINTER(IrsIO), _P, _I, _P],
     'irs_slab_status_get': [_P, C.POINTER(IrsSlabStatus), _P],
+    'irs_slab_timeline_arm': [_P, _I],
+    'irs_slab_timeline_get': [_P, C.POINTER(IrsSlabTimelineEntry), _I, _I32P, C.POINTER(C.c_float), _P],
     'irs_slab_trace': [C.POINTER(IrsConfig), C.POINTER(IrsSlabConfig), _I, _I, _I32P, C.POINTER(IrsSlabOp), _I, _I32P],
     'irs_slab_plan_rounds': [_I32P, _I, _I, _I, _I, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P],
     'irs_option_set': [_P, C.c_char_p, _I],

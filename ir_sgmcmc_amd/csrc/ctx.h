@@ -94,6 +94,17 @@ struct irs_ctx {
     uint64_t slab_exact = 0;           // transitions run in measuring mode
     uint64_t slab_mispredictions = 0;  // transitions found to have run with too narrow a plan (reported as errors)
     int last_nf = 0, last_nb = 0;      // exchange rounds of the last transition
+    // ---- hand-over timeline of one sampled slab transition (irs_slab_timeline_*): timing events around every exchange / all-reduce
+    struct TlRec {
+        int32_t kind, stage, k, width;
+        int eP, eR, eW0, eW1;  // indices into tl_ev (-1: not recorded)
+    };
+    int tl_arm = 0;                  // > 0: the next transition records
+    hipEvent_t* tl_ev = nullptr;     // pool of timing-enabled events, created when first armed
+    int tl_ev_n = 0, tl_ev_used = 0;
+    TlRec tl_rec[128];               // by comm id
+    int tl_n = 0, tl_t0 = -1, tl_t1 = -1;
+    bool tl_have = false;
 };
 
 namespace irs {

@@ -12,6 +12,12 @@
 //               of one process's kernel is what the next poll of another's reads.  (Flags inside the landing areas -- polled
 //               locally, written through the peer mapping -- were built and do NOT work: on this driver a system-scope poll of
 //               hipMalloc memory never saw the other process's store, even with both ranks on one device.)
+//               IRS_IPC_FLAGS=device (round 5) places them in the header of every rank's LANDING AREA instead -- polled locally,
+//               raised by the peer through its mapping: on a node a hand-over is then one xGMI store and local polls instead of
+//               two PCIe round trips.  Whether a poll of (uncached) device memory sees another DEVICE's store is exactly what a
+//               one-GPU box cannot tell: the pre-flight child (ir_sgmcmc_amd/ipc_preflight.py) probes it with a short timeout --
+//               a flag that never arrives is a clean error since round 5 -- and bench.py uses device flags only where every
+//               rank's child proved them.
 //   exchange    push kernel: packs this rank's strips into slot (seq & 1) of each neighbour's landing area; when its last
 //               workgroup has drained its stores (system-scope release) it stores `seq` into the neighbours' flags.
 //               wait kernel (ONE wavefront): polls this rank's flags until `seq` has arrived -- bounded: a timeout raises a STICKY
@@ -65,7 +71,8 @@ struct Shm {
     uint32_t magic, world;
     uint32_t arrived;  // host barrier (monotonic counter)
     uint32_t failed;   // a rank gave up during bootstrap: the others stop waiting
-    char pad[kLine - 16];
+    uint32_t flags_device_votes;  // ranks that asked for IRS_IPC_FLAGS=device (all or none)
+    char pad[kLine - 20];
     ShmRank rank[kMaxWorld];
     ShmFlags flags[kMaxWorld];
 };
@@ -101,6 +108,7 @@ struct IpcState {
     unsigned* err_dev = nullptr;
     unsigned* err_flag = nullptr;  // the same fact in DEVICE memory: what the consumer kernels test (no PCIe round trip per launch)
     bool bailing = false;          // this rank failed during the bootstrap: it takes no further part in the arrival counter
+    bool device_flags = false;     // IRS_IPC_FLAGS=device: sequence flags in the landing-area headers (else in the host segment)
     unsigned long long timeout_ticks = 0;
     uint64_t exchanges = 0, allreduces = 0;
 };
@@ -146,7 +154,11 @@ int give_up(IpcState* s, int rc) {  // tell the peers before returning an error 
 // flag words: where this rank POLLS (its own, written by `src`) and where it SIGNALS (the peer's, naming itself)
 inline size_t xflag_off(int side) { return offsetof(ShmFlags, x) + (size_t)side * kLine; }
 inline size_t arflag_off(int src) { return offsetof(ShmFlags, ar) + (size_t)src * kLine; }
-unsigned* flag_ptr(IpcState* s, int owner, size_t off) { return (unsigned*)((char*)&s->shm_dev->flags[owner] + off); }
+// (device flags: the first sizeof(ShmFlags) bytes of the owner's landing area, reached through this rank's mapping of it)
+unsigned* flag_ptr(IpcState* s, int owner, size_t off) {
+    if (s->device_flags) return (unsigned*)(s->peer[owner] + off);
+    return (unsigned*)((char*)&s->shm_dev->flags[owner] + off);
+}
 
 // ---- device side -----------------------------------------------------------------------------------------------------------
 struct Run {
@@ -320,8 +332,9 @@ void close_peers(IpcState* s) {
 
 void ipc_describe(const irs_comm* cm, char* out, size_t n) {
     const IpcState* s = cm->ipc;
-    snprintf(out, n, "ipc: %d ranks, landing area %.1f MiB %s, sequence flags in host shared memory, %llu exchanges / %llu all-reduces so far",
+    snprintf(out, n, "ipc: %d ranks, landing area %.1f MiB %s, sequence flags in %s, %llu exchanges / %llu all-reduces so far",
              s->world, (double)s->land_bytes / 1048576.0, s->land ? (s->land_uncached ? "uncached device memory" : "hipMalloc") : "(not reserved yet)",
+             s->device_flags ? "the landing areas (device memory)" : "host shared memory",
              (unsigned long long)s->exchanges, (unsigned long long)s->allreduces);
 }
 
@@ -392,6 +405,8 @@ int ipc_reserve(irs_comm* cm, size_t xbytes, size_t arbytes) {
     }
     if (hipMemset(s->land, 0, kLandHeader) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
         return give_up(s, fail("ipc_reserve: clearing the landing header failed"));  // (the peers stop waiting at once)
+    // (device flags live in that header: a fresh area starts at zero while the sequence numbers go on -- every later flag value is
+    // larger than anything waited for before, and nobody waits across a reservation: it is collective and drains the device first)
     if (e != hipSuccess) return give_up(s, fail("hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed where the driver only has dmabuf IPC)", hipGetErrorString(e)));
     me.land_bytes = s->land_bytes;
     me.x_slot = s->x_slot;
@@ -609,9 +624,17 @@ int ipc_create(const char* name, int rank, int world, irs_comm** out) {
     // How long a kernel waits for a peer's flag.  It bounds the SKEW between ranks, host pauses included: a rank whose host stops
     // enqueueing for longer than this between two transitions (checkpoint, metrics I/O) makes its neighbours give up -- raise
     // IRS_IPC_TIMEOUT_S for such runs.  A timeout is fail-safe (header of this file), never a corrupted chain.
+    const char* fl = getenv("IRS_IPC_FLAGS");
+    s->device_flags = fl && !strcmp(fl, "device");
     const char* to = getenv("IRS_IPC_TIMEOUT_S");
     const double secs = to && atof(to) > 0.0 ? atof(to) : 60.0;
     s->timeout_ticks = (unsigned long long)(secs * 100.0e6);  // wall_clock64: 100 MHz
+    // every rank must have chosen the same flag placement (an environment variable: easy to set on one rank only)
+    __atomic_fetch_add(&s->shm->flags_device_votes, s->device_flags ? 1u : 0u, __ATOMIC_ACQ_REL);
+    if (give_up(s, host_barrier(s))) return bail(1);
+    const uint32_t votes = __atomic_load_n(&s->shm->flags_device_votes, __ATOMIC_ACQUIRE);
+    if (votes != 0u && votes != (uint32_t)world)
+        return bail(give_up(s, fail("ipc transport: IRS_IPC_FLAGS=device on %u of %d ranks -- every rank must place the flags alike", votes, world)));
     if (give_up(s, host_barrier(s))) return bail(1);
     *out = c;
     return 0;

@@ -466,6 +466,18 @@ struct Exec {
     hipEvent_t pending[128];  // event to wait for, by comm id (ids of one transition are < 128)
 
     hipEvent_t take() { return c->sev[(next_ev++) % 16]; }
+    // timeline sampling (irs_slab_timeline_arm): a timing event on `s`, or -1 when this transition is not sampled / the pool is out
+    bool tl = false;
+    int stamp(hipStream_t s) {
+        if (!tl || c->tl_ev_used >= c->tl_ev_n) return -1;
+        const int i = c->tl_ev_used++;
+        return hipEventRecord(c->tl_ev[i], s) == hipSuccess ? i : -1;
+    }
+    void tl_open(int id, int kind, int stage, int k, int width, int eP) {
+        if (!tl || id < 0 || id >= 128) return;
+        c->tl_rec[id] = irs_ctx::TlRec{kind, stage, k, width, eP, -1, -1, -1};
+        if (id + 1 > c->tl_n) c->tl_n = id + 1;
+    }
     float* buffer(int id, const Views& v, int* kind) const {
         const int n = c->cfg.no_steps;
         switch (id) {
@@ -519,7 +531,12 @@ struct Exec {
                 if (allreduce(o)) return 1;
             } else if (o.kind == IRS_OP_WAIT) {
                 if (o.id < 0 || o.id >= 128) return fail("slab: bad wait id %d", o.id);
-                if (pending[o.id]) HIP_TRY(hipStreamWaitEvent(st, pending[o.id], 0));
+                if (pending[o.id]) {
+                    const bool first = tl && c->tl_rec[o.id].eW0 < 0 && c->tl_rec[o.id].eP >= 0;
+                    if (first) c->tl_rec[o.id].eW0 = stamp(st);
+                    HIP_TRY(hipStreamWaitEvent(st, pending[o.id], 0));
+                    if (first) c->tl_rec[o.id].eW1 = stamp(st);
+                }
             } else return fail("slab: unknown op kind %d", o.kind);
         }
         LAUNCH_CHECK();
@@ -533,9 +550,11 @@ struct Exec {
         if (!buf) return fail("slab: exchange of unknown buffer %d", o.stage);
         hipEvent_t prod = take(), recv = take();
         HIP_TRY(hipEventRecord(prod, st));
+        tl_open(o.id, IRS_OP_EXCHANGE, o.stage, o.k, o.width, stamp(st));
         HIP_TRY(hipStreamWaitEvent(cs, prod, 0));
         if (exchange_planes(c, buf, kind, chains, o.width, cs)) return 1;
         HIP_TRY(hipEventRecord(recv, cs));
+        if (tl) c->tl_rec[o.id].eR = stamp(cs);
         pending[o.id] = recv;
         return 0;
     }
@@ -561,9 +580,11 @@ struct Exec {
         const int slot = o.stage == IRS_AR_MOMENTS ? 5 : o.stage;  // kinds 0 .. 4 and 7
         hipEvent_t prod = c->sev[16 + 2 * slot], fin = c->sev[17 + 2 * slot];
         HIP_TRY(hipEventRecord(prod, st));
+        tl_open(o.id, IRS_OP_ALLREDUCE, o.stage, -1, 0, stamp(st));
         HIP_TRY(hipStreamWaitEvent(cs, prod, 0));
         if (comm_allreduce(c->comm, buf, count, mx, cs)) return 1;
         HIP_TRY(hipEventRecord(fin, cs));
+        if (tl) c->tl_rec[o.id].eR = stamp(cs);
         pending[o.id] = fin;
         return 0;
     }
@@ -808,6 +829,10 @@ void slab_release(irs_ctx* c) {
         if (c->sev[i]) (void)hipEventDestroy(c->sev[i]);
     if (c->cs) (void)hipStreamDestroy(c->cs);
     if (c->plan_hint) (void)hipHostFree(c->plan_hint);
+    for (int i = 0; i < c->tl_ev_n; ++i) (void)hipEventDestroy(c->tl_ev[i]);
+    free(c->tl_ev);
+    c->tl_ev = nullptr;
+    c->tl_ev_n = 0;
 }
 }  // namespace irs
 
@@ -891,6 +916,61 @@ int irs_slab_create(const irs_config* cfg, const irs_slab_config* scfg, irs_comm
     return 0;
 }
 
+int irs_slab_timeline_arm(irs_ctx* c, int transitions) {
+    if (!c || !c->sl.on) return fail("irs_slab_timeline_arm: not a slab context");
+    if (transitions > 0 && !c->tl_ev) {  // four events per hand-over (at most 128 of them) + the two ends of the transition
+        const int n = 4 * 128 + 2;
+        c->tl_ev = (hipEvent_t*)calloc((size_t)n, sizeof(hipEvent_t));
+        if (!c->tl_ev) return fail("irs_slab_timeline_arm: out of host memory");
+        for (c->tl_ev_n = 0; c->tl_ev_n < n; ++c->tl_ev_n)
+            if (hipEventCreate(&c->tl_ev[c->tl_ev_n]) != hipSuccess) return fail("irs_slab_timeline_arm: hipEventCreate failed");
+    }
+    c->tl_arm = transitions > 0 ? transitions : 0;
+    return 0;
+}
+
+int irs_slab_timeline_get(irs_ctx* c, irs_slab_timeline_entry* out, int max_entries, int32_t* n_entries, float* total_us, void* stream) {
+    if (!c || !c->sl.on || !n_entries) return fail("irs_slab_timeline_get: not a slab context / null argument");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize(c->cs));
+    *n_entries = 0;
+    if (total_us) *total_us = 0.0f;
+    if (!c->tl_have) return fail("irs_slab_timeline_get: no sampled transition (irs_slab_timeline_arm, then irs_slab_transition)");
+    auto us = [&](int a, int b, float* o) {  // elapsed a -> b in microseconds; false if either event is missing
+        if (a < 0 || b < 0) return false;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->tl_ev[a], c->tl_ev[b]) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        *o = 1000.0f * ms;
+        return true;
+    };
+    float t = 0.0f;
+    if (total_us && us(c->tl_t0, c->tl_t1, &t)) *total_us = t;
+    int n = 0;
+    for (int id = 0; id < c->tl_n; ++id) {
+        const irs_ctx::TlRec& r = c->tl_rec[id];
+        if (r.kind < 0) continue;
+        if (out && n < max_entries) {
+            irs_slab_timeline_entry e;
+            e.kind = r.kind;
+            e.stage = r.stage;
+            e.k = r.k;
+            e.width = r.width;
+            e.ready_us = e.handover_us = e.stall_us = 0.0f;
+            e.wait_at_us = -1.0f;
+            (void)us(c->tl_t0, r.eP, &e.ready_us);
+            (void)us(r.eP, r.eR, &e.handover_us);
+            if (us(c->tl_t0, r.eW0, &e.wait_at_us)) (void)us(r.eW0, r.eW1, &e.stall_us);
+            out[n] = e;
+        }
+        ++n;
+    }
+    *n_entries = n;
+    return 0;
+}
+
 int irs_slab_get_layout(const irs_ctx* c, irs_slab_layout* out) {
     if (!c || !out || !c->sl.on) return fail("irs_slab_get_layout: not a slab context");
     const SlabInfo& s = c->sl;
@@ -961,6 +1041,15 @@ int slab_transition_once(irs_ctx* c, const irs_io* io_in, hipStream_t st) {
     ex.stats_op = 3;
     ex.in_transition = true;
     ex.planned_ = planned;
+    if (c->tl_arm > 0 && c->tl_ev) {  // sampled transition: timing events around every hand-over (irs_slab_timeline_get)
+        --c->tl_arm;
+        ex.tl = true;
+        c->tl_ev_used = 0;
+        c->tl_n = 0;
+        for (int i = 0; i < 128; ++i) c->tl_rec[i] = irs_ctx::TlRec{-1, -1, -1, 0, -1, -1, -1, -1};
+        c->tl_t0 = ex.stamp(st);
+        c->tl_have = false;
+    }
     Sched sch(s, cfg, C);
     sch.nbuf_ = grad_buffers(c);
     sch.want_split_ = c->kn.slab_split != 0;
@@ -994,6 +1083,10 @@ int slab_transition_once(irs_ctx* c, const irs_io* io_in, hipStream_t st) {
         fprintf(stderr, "[slab] transition %llu %s: h =", (unsigned long long)c->n_enqueued, planned ? "planned" : "exact");
         for (int k = 0; k < n; ++k) fprintf(stderr, " %d", plan.h[k]);
         fprintf(stderr, "\n");
+    }
+    if (ex.tl) {
+        c->tl_t1 = ex.stamp(st);
+        c->tl_have = c->tl_t0 >= 0 && c->tl_t1 >= 0;
     }
     HIP_TRY(hipEventRecord(c->ra_ev[c->n_enqueued % 4], st));
     ++c->n_enqueued;

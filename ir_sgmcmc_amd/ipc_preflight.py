@@ -61,9 +61,43 @@ def _child(name, rank, world, device_index):
         L.check(lib.irs_comm_probe(h, 3 * 256 * 256 * 12, 21, 50, None, C.byref(us)))   # three ghost planes of a 256^3 field
         buf = C.create_string_buffer(256)
         L.check(lib.irs_comm_describe(h, buf, 256))
-        print(json.dumps({'exchange_us': round(us[0], 2), 'allreduce_us': round(us[1], 2), 'info': buf.value.decode()}), flush=True)
+        res = {'exchange_us': round(us[0], 2), 'allreduce_us': round(us[1], 2), 'info': buf.value.decode()}
     finally:
         lib.irs_comm_destroy(h)
+    res.update(_probe_device_flags(lib, name, rank, world))
+    print(json.dumps(res), flush=True)
+
+
+def _probe_device_flags(lib, name, rank, world):
+    """Do sequence flags in DEVICE memory work here?  (csrc/ipc.hip: IRS_IPC_FLAGS=device puts them into the landing areas -- polled
+    locally, raised by the peer through its mapping; with two processes on ONE device a poll never saw the other's store, across
+    devices nobody could try.)  A second communicator with that placement and a 3 s device-side timeout runs the same self-test and
+    timing: a flag that never arrives is a clean error (the transport's timeouts are fail-safe), reported as `device_flags: false`."""
+    import ctypes as C
+
+    from . import _lib as L
+    if os.environ.get('IRS_IPC_PREFLIGHT_SIMULATE_NO_DEVICE_FLAGS') == '1':   # (tests: a node where the placement does not work)
+        return {'device_flags': False, 'device_flags_error': 'simulated'}
+    old = {k: os.environ.get(k) for k in ('IRS_IPC_FLAGS', 'IRS_IPC_TIMEOUT_S')}
+    os.environ.update(IRS_IPC_FLAGS='device', IRS_IPC_TIMEOUT_S='3')
+    h = C.c_void_p()
+    try:
+        L.check(lib.irs_comm_create_ipc((name + '_df').encode(), rank, world, C.byref(h)))
+        try:
+            L.check(lib.irs_comm_selftest(h, None))
+            us = (C.c_double * 2)()
+            L.check(lib.irs_comm_probe(h, 3 * 256 * 256 * 12, 21, 50, None, C.byref(us)))
+            return {'device_flags': True, 'exchange_us_device_flags': round(us[0], 2), 'allreduce_us_device_flags': round(us[1], 2)}
+        finally:
+            lib.irs_comm_destroy(h)
+    except L.IrsError as e:
+        return {'device_flags': False, 'device_flags_error': str(e)[:200]}
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 if __name__ == '__main__':

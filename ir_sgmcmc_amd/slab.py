@@ -274,6 +274,23 @@ class SlabEngine(TransitionEngine):
         L.check(self.lib.irs_slab_transition(self._ctx, C.byref(io), self._stream()))
         return None
 
+    def timeline_arm(self, transitions=1):
+        """the next `transitions` transitions record timing events around every exchange / all-reduce (the last one is kept)"""
+        L.check(self.lib.irs_slab_timeline_arm(self._ctx, int(transitions)))
+
+    @_on_device
+    def timeline(self):
+        """hand-overs of the last sampled transition, in schedule order: (entries, total_us).  Per entry: when the data was ready on
+        the compute stream, how long the hand-over took on the communication stream (push, waiting for the peer, drain / reduce),
+        when the compute stream reached the launch that needs it and how long it STALLED there (0: hidden behind interior work)"""
+        n, tot = C.c_int32(0), C.c_float(0.0)
+        buf = (L.IrsSlabTimelineEntry * 128)()
+        L.check(self.lib.irs_slab_timeline_get(self._ctx, buf, 128, C.byref(n), C.byref(tot), self._stream()))
+        names = {L.IRS_OP_EXCHANGE: 'exchange', L.IRS_OP_ALLREDUCE: 'all-reduce'}
+        return [{'kind': names.get(e.kind, str(e.kind)), 'stage': e.stage, 'k': e.k, 'width': e.width, 'ready_us': round(e.ready_us, 1),
+                 'handover_us': round(e.handover_us, 1), 'wait_at_us': round(e.wait_at_us, 1), 'stall_us': round(e.stall_us, 1)}
+                for e in buf[:min(n.value, 128)]], float(tot.value)
+
     @_on_device
     def status(self):
         st = L.IrsSlabStatus()

@@ -61,7 +61,11 @@ def test_bench_auto_transport_survives_a_transport_that_fails():
     assert list(d['slab']['transport_trials_ms']) == ['ipc'] and 'rccl' in d['slab_transport_failure']
     assert 'ipc:' in d['slab']['transport_info'] and d['slab']['mispredictions'] == 0
     # (one rank per device, a node: the transport is first brought up, self-tested and timed by a child of every rank)
-    assert d['slab']['ipc_preflight']['exchange_us'] > 0 and 'ipc:' in d['slab']['ipc_preflight']['info']
+    pre = d['slab']['ipc_preflight']
+    assert pre['exchange_us'] > 0 and 'ipc:' in pre['info']
+    # ... and the children probed the flag placement: device-memory flags are used exactly where every child saw them work
+    assert isinstance(pre['device_flags'], bool) and (pre['device_flags'] or pre['device_flags_error'])
+    assert ('sequence flags in the landing areas' in d['slab']['transport_info']) == pre['device_flags']
 
 
 def test_bench_auto_transport_survives_a_preflight_child_that_dies():
@@ -83,6 +87,19 @@ def test_bench_four_ranks_ipc():
     d = _run(['--gpus', '4', '--size', '64', '--steps', '4', '--warmup', '2', '--no-cpu-baseline'], {'IRS_BENCH_DEVICE': '0'})
     assert d['n_gpus'] == 4 and d['scaling'] == 'strong' and d['slab']['transport'] == 'ipc'
     assert d['slab']['planes_owned'] == 16 and d['slab']['mispredictions'] == 0 and d['value'] > 0
+    # the self-diagnosis of a first run on a node: every rank's own time, and per hand-over of one sampled transition how long the
+    # communication stream took and how long the compute stream stalled (include/irsgmcmc.h: irs_slab_timeline_*)
+    s = d['slab']
+    per = s['ms_per_transition_by_rank']
+    assert len(per['all']) == 4 and 0 < per['min'] <= per['max'] and abs(per['max'] - d['ms_per_step']) < 1e-3 * d['ms_per_step'] + 1e-6
+    assert [r['rank'] for r in s['round_wait_us']] == [0, 1, 2, 3]
+    for r in s['round_wait_us']:
+        assert 'timeline_error' not in r, r
+        assert r['transition_us'] > 0 and r['handover_us'] > 0 and r['stall_us'] >= 0
+        kinds = {e[0][0] for e in r['rounds']}
+        assert kinds == {'e', 'a'} and len(r['rounds']) >= 5          # exchanges and all-reduces, in schedule order
+        assert all(e[3] >= 0 and e[4] >= 0 for e in r['rounds'])
+        assert sum(1 for e in r['rounds'] if e[0][0] == 'a') >= 3      # bounds, statistics, data-term sums
 
 
 def test_bench_exits_non_zero_without_a_slab_transport():
