@@ -197,7 +197,8 @@ int irs_velocity_dims(const irs_ctx* ctx, int32_t out[3]);
 
 /* pre-normalise the fixed image for the LCC map (iteration-invariant half of model/loss.py:103-105). */
 int irs_set_fixed(irs_ctx* ctx, const float* fixed_im, int fixed_chains, void* stream);
-/* blocking copies of the small state / scalars */
+/* blocking copies of the small state / scalars.  (A slab context whose transport has failed -- a peer gone, irs_slab_transition /
+ * irs_flush return that error -- still answers these two: the device holds the state after the last good transition.) */
 int irs_get_state(irs_ctx* ctx, irs_state* out, void* stream);
 int irs_set_state(irs_ctx* ctx, const irs_state* in, void* stream);
 int irs_get_scalars(irs_ctx* ctx, irs_scalars* out, void* stream);

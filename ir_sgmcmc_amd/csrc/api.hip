@@ -9,6 +9,7 @@
 #include <mutex>
 #include <new>
 
+#include "comm.h"
 #include "ctx.h"
 
 using namespace irs;
@@ -691,9 +692,20 @@ int irs_set_fixed(irs_ctx* c, const float* fixed_im, int fixed_chains, void* str
     return 0;
 }
 
+// A slab context whose transport has FAILED (a peer gone: csrc/ipc.hip, fail-safe timeout) cannot flush -- nothing can be re-run --
+// but what the device holds is well defined: the state after the last GOOD transition (the failed one was a no-op).  Reading it
+// must still work: it is what a dying run checkpoints.
+static int flush_or_failed_transport(irs_ctx* c, void* stream) {
+    if (!irs_flush(c, stream)) return 0;
+    if (!(c->sl.on && c->comm && irs::comm_check(c->comm))) return 1;
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    if (c->cs) (void)hipStreamSynchronize(c->cs);
+    return 0;
+}
+
 int irs_get_state(irs_ctx* c, irs_state* out, void* stream) {
     if (!c || !out) return fail("irs_get_state: null argument");
-    if (irs_flush(c, stream)) return 1;  // transitions that ended as no-ops are re-run first: the state is final
+    if (flush_or_failed_transport(c, stream)) return 1;  // transitions that ended as no-ops are re-run first: the state is final
     HIP_TRY(hipMemcpyAsync(out, &c->state->st, sizeof(irs_state), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return 0;
@@ -717,7 +729,7 @@ int irs_set_state(irs_ctx* c, const irs_state* in, void* stream) {
 
 int irs_get_scalars(irs_ctx* c, irs_scalars* out, void* stream) {
     if (!c || !out) return fail("irs_get_scalars: null argument");
-    if (irs_flush(c, stream)) return 1;
+    if (flush_or_failed_transport(c, stream)) return 1;
     HIP_TRY(hipMemcpyAsync(out, &c->state->sc, sizeof(irs_scalars), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return 0;

@@ -295,7 +295,7 @@ __device__ __forceinline__ void adjoint_self(const int x, const int y, const int
 // timing experiment (tools/lds_phase_trace.py; build with tools/build_variant.sh ldstrace -DIRS_LDS_TRACE): wall-clock stamps
 // (100 MHz) of one thread of one workgroup at the phase boundaries of its tiles, plus the source box it walked
 __device__ unsigned long long g_lds_trace[8 * 32];
-extern "C" int irs_debug_lds_trace(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int irs_debug_lds_trace(unsigned long long* out) {  // (trace builds only: the library is compiled -fvisibility=hidden)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lds_trace), sizeof(g_lds_trace)) == hipSuccess ? 0 : 1;
 }
 #define IRS_LT(slot, val)                                                                                  \
@@ -686,6 +686,9 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #ifndef IRS_BWD_LAYC
 #define IRS_BWD_LAYC 0
 #endif
+#ifndef IRS_BWD_TAPS
+#define IRS_BWD_TAPS 0  // 1: the eight corner reads of the own term as single ds_read_b64 / ds_read_b32 (volatile, as IRS_FWD_TAPS); A/B in round 5
+#endif
 #ifndef IRS_BWD_R1_FALLBACK
 #define IRS_BWD_R1_FALLBACK 1
 #endif
@@ -798,7 +801,7 @@ __device__ __forceinline__ void exp_bwd_generic_column(const float* __restrict__
 // timing experiment (tools/bwd_phase_trace.py; build with tools/build_variant.sh bwdtrace -DIRS_BWD_TRACE): clock stamps of one wave
 // of one workgroup at the phase boundaries of the marching loop.  For reading proportions, not for timing the kernel.
 __device__ unsigned long long g_bwd_trace[8 * 64];
-extern "C" int irs_debug_bwd_trace(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int irs_debug_bwd_trace(unsigned long long* out) {  // (trace builds only: the library is compiled -fvisibility=hidden)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_trace), sizeof(g_bwd_trace)) == hipSuccess ? 0 : 1;
 }
 #define IRS_BT(slot)                                                                                  \
@@ -1097,8 +1100,16 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
                             for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
                                 for (int cx = 0; cx < 2; ++cx) {
+#if IRS_BWD_TAPS == 1
+                                    typedef float VF2 __attribute__((ext_vector_type(2)));
+                                    const VF2 tv = *(const volatile __attribute__((address_space(3))) VF2*)(&q_d[bs + cy * PX + cx]);
+                                    const float2 v01 = make_float2(tv.x, tv.y);
+                                    const float vz = *(const volatile __attribute__((address_space(3))) float*)(&q_dz[bs + cy * PX + cx]);
+#else
                                     const float2 v01 = q_d[bs + cy * PX + cx];
-                                    dot[cz][cy][cx] = fmaf(q_dz[bs + cy * PX + cx], G2, fmaf(v01.y, G1, v01.x * G0));
+                                    const float vz = q_dz[bs + cy * PX + cx];
+#endif
+                                    dot[cz][cy][cx] = fmaf(vz, G2, fmaf(v01.y, G1, v01.x * G0));
                                 }
                         }
                     };
@@ -1237,24 +1248,15 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
 #define IRS_FWD_PITCH_ALIGN 16
 #endif
 #ifndef IRS_FWD_TAPS
-#define IRS_FWD_TAPS 0  // 0: the compiler's LDS reads (ds_read2_b64 / ds_read2_b32 corner pairs); 1: one ds_read_b64 + ds_read_b32 per corner
+// How the eight corner taps of a sample leave the LDS ring.  0: plain reads -- the compiler pairs the cx = 0 / 1 corners into
+// ds_read2_b64 + ds_read2_b32.  1 (round 5): every corner its own ds_read_b64 + ds_read_b32, through VOLATILE LDS pointers (the
+// load / store optimiser leaves volatile accesses unpaired; the compiler still counts and schedules them).  A ds_read2_b64 holds the
+// LDS for 8 cycles where two ds_read_b64 take 4, and is banked per 16 lanes (MI355X_MICROARCH.md, LDS table): with per-lane cell
+// shifts the isolated tap pattern costs 99 against 69 clocks per wave tap-set (tools/probes/lds_tap_probe.hip, white shifts; 71
+// against 60 with runs of four lanes), and this kernel 95.8 against 104.5 us per launch at 256^3 on one box (profiles/r05_fwd_taps_ab.txt).
+// Same values, same products, same order of the additions: chains bit-identical (tools/debug/chain_bits.py).
+#define IRS_FWD_TAPS 1
 #endif
-// LDS reads the compiler cannot pair (inline asm; it does not count them either: lds_wait_all before their first use).
-// The byte address of a __shared__ object is the low half of its flat address.
-__device__ __forceinline__ unsigned lds_byte_addr(const void* p) { return (unsigned)(uintptr_t)p; }
-template <int OFF>
-__device__ __forceinline__ float2 lds_rd64(unsigned a) {
-    float2 v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
-    return v;
-}
-template <int OFF>
-__device__ __forceinline__ float lds_rd32(unsigned a) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
-    return v;
-}
-__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // FROWS is a template parameter of the radius-1 kernel: two rows per thread (256 threads) where the launch fills the chip; ONE row
 // per thread (512 threads, 8 waves per tile) on small volumes and thin slabs, where a launch has a workgroup or two per CU and
 // twice the waves per tile hide more of a plane step's latency (128^3: 22.9 against 24.7 us per step; at 256^3 it loses, 142
@@ -1276,7 +1278,7 @@ struct MarchF {
 // wave of one workgroup at six points of the marching loop.  The stamps serialise the wave's LDS / scalar-memory queue, so the
 // build is for reading proportions, not for timing the kernel.
 __device__ unsigned long long g_fwd_trace[8 * 64];
-extern "C" int irs_debug_fwd_trace(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int irs_debug_fwd_trace(unsigned long long* out) {  // (trace builds only: the library is compiled -fvisibility=hidden)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_trace), sizeof(g_fwd_trace)) == hipSuccess ? 0 : 1;
 }
 #define IRS_TR(slot)                                                                           \
@@ -1447,56 +1449,19 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                         sl1 = rel == q ? ((a + q + 1 + NS) % NS) * PNP : sl1;
                     }
                     const int off = by0 * PITCH + bx0;
-#if IRS_FWD_TAPS == 1 || IRS_FWD_TAPS == 2
-                    // every corner its own ds_read_b64 + ds_read_b32: the compiler pairs the cx = 0 / 1 corners into ds_read2_b64 +
-                    // ds_read2_b32, and a ds_read2_b64 occupies the LDS for 8 cycles where two ds_read_b64 take 4 (MI355X_MICROARCH.md,
-                    // LDS table; tools/probes/lds_tap_probe.hip measures the tap pattern of this kernel under both).  Same values,
-                    // same products, same order of the additions.  IRS_FWD_TAPS 1: the sixteen reads of a voxel in one batch
-                    // (24 registers of corner data at once); 2: the two z corners one after the other (12).
-                    const unsigned bxy = lds_byte_addr(r_xy), bzz = lds_byte_addr(r_z);
-                    float2 txy[2][2][2];
-                    float tzz[2][2][2];
-                    auto issue = [&](int cz) {
-                        const unsigned e = (unsigned)((cz ? sl1 : sl0) + off);
-                        const unsigned xa = bxy + 8u * e, za = bzz + 4u * e;
-                        txy[cz][0][0] = lds_rd64<0>(xa);
-                        txy[cz][0][1] = lds_rd64<8>(xa);
-                        txy[cz][1][0] = lds_rd64<8 * PITCH>(xa);
-                        txy[cz][1][1] = lds_rd64<8 * PITCH + 8>(xa);
-                        tzz[cz][0][0] = lds_rd32<0>(za);
-                        tzz[cz][0][1] = lds_rd32<4>(za);
-                        tzz[cz][1][0] = lds_rd32<4 * PITCH>(za);
-                        tzz[cz][1][1] = lds_rd32<4 * PITCH + 4>(za);
-                    };
-                    if (IRS_FWD_TAPS == 1) {
-                        issue(0);
-                        issue(1);
-                        lds_wait_all();
-                    }
-#endif
 #pragma unroll
                     for (int cz = 0; cz < 2; ++cz) {
                         const int bs = (cz ? sl1 : sl0) + off;
-#if IRS_FWD_TAPS == 2
-                        issue(cz);
-                        lds_wait_all();
-#endif
 #pragma unroll
                         for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
                             for (int cx = 0; cx < 2; ++cx) {
                                 const float w = __fmul_rn(wxy[cy][cx], cz ? tz.w1 : tz.w0);
-#if IRS_FWD_TAPS == 3
-                                // volatile: the load / store optimiser leaves such accesses alone (no ds_read2 pairs), the compiler still
-                                // counts and schedules them
+#if IRS_FWD_TAPS == 1
                                 typedef float VF2 __attribute__((ext_vector_type(2)));
                                 const VF2 tv = *(const volatile __attribute__((address_space(3))) VF2*)(&r_xy[bs + cy * PITCH + cx]);
                                 const float2 t2 = make_float2(tv.x, tv.y);
                                 const float t1 = *(const volatile __attribute__((address_space(3))) float*)(&r_z[bs + cy * PITCH + cx]);
-#elif IRS_FWD_TAPS >= 1
-                                (void)bs;
-                                const float2 t2 = txy[cz][cy][cx];
-                                const float t1 = tzz[cz][cy][cx];
 #else
                                 const float2 t2 = r_xy[bs + cy * PITCH + cx];
                                 const float t1 = r_z[bs + cy * PITCH + cx];

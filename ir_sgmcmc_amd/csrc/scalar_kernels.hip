@@ -12,7 +12,7 @@ namespace irs {
 #endif
 #ifdef IRS_SCALAR_TRACE
 __device__ unsigned long long g_scalar_trace[8];
-extern "C" int irs_debug_scalar_trace(unsigned long long* out) {
+extern "C" __attribute__((visibility("default"))) int irs_debug_scalar_trace(unsigned long long* out) {  // (trace builds only: the library is compiled -fvisibility=hidden)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scalar_trace), sizeof(g_scalar_trace)) == hipSuccess ? 0 : 1;
 }
 #define IRS_ST(i) do { if (threadIdx.x == 0) g_scalar_trace[i] = wall_clock64(); } while (0)

@@ -9,6 +9,8 @@
 //   layout 2  three planar float arrays (compiler: ds_read2_b32 pairs)
 //   layout 3  16-byte records (d0, d1, d2, -), one ds_read_b128 per corner
 //   layout 4  float2 (d0, d1) + float2 (d2[x], d2[x + 1]): three ds_read_b64 per corner PAIR
+//   layout 6  layout 0's arrays through volatile LDS pointers: single ds_read_b64 + ds_read_b32 issued by the COMPILER (no pairing, its
+//             own waits) -- the form the kernel ships (IRS_FWD_TAPS=3)
 //   layout 5  layout 1's arrays, FIXED columns x - 1, x, x + 1 in the lane's two rows and planes (12 corner reads, 4 of them
 //             with weight 0): no per-lane x shift, so no bank conflict whatever the field does
 //   pitch     row pitch in records (80 = the shipped 16-record alignment of 66; 66 = unpadded; 81 / 82 = a row start rotated by one
@@ -30,25 +32,13 @@ constexpr int FTX = 64, FTY = 8, R = 1, NS = 4, PX = FTX + 2 * R, PY = FTY + 2 *
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-template <int OFF>
-__device__ __forceinline__ f2 rd64(unsigned a) {
-    f2 v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
-    return v;
-}
-template <int OFF>
-__device__ __forceinline__ float rd32(unsigned a) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
-    return v;
-}
-template <int OFF>
-__device__ __forceinline__ f4 rd128(unsigned a) {
-    f4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
-    return v;
-}
-__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// The asm layouts issue ALL reads of a tap-set and the wait for them in ONE asm statement: the compiler does not know that a
+// ds_read's result arrives later, and between separate statements it is free to copy an "output" before it has landed (the first
+// version of this probe -- and an asm variant of the kernel -- read garbage that way).  Early-clobber outputs, the row / plane
+// bases as separate address registers so that every immediate offset is 0, 8 or 16 whatever the pitch.
+#define RD64(o, a, off) "ds_read_b64 %" #o ", %" #a " offset:" #off "\n"
+#define RD32(o, a, off) "ds_read_b32 %" #o ", %" #a " offset:" #off "\n"
+#define RD128(o, a, off) "ds_read_b128 %" #o ", %" #a " offset:" #off "\n"
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }
 
 __device__ __forceinline__ float ring_value(int slot, int row, int col, int ch) {  // what the ring holds (any layout)
@@ -120,7 +110,28 @@ __global__ __launch_bounds__(kBlock, 4) void tap_probe(float* __restrict__ out, 
             const int sl0 = ((a - sz) & (NS - 1)) * PNP, sl1 = ((a - sz + 1) & (NS - 1)) * PNP;
             const int ctr = a * PNP + (ly + R) * PITCH + lx + R;
             const int off = by0 * PITCH + bx0;
-            if (LAYOUT == 0) {
+            if (LAYOUT == 6) {  // layout 0's arrays read through volatile LDS pointers: the compiler issues, counts and schedules the reads, but
+                                // its load / store optimiser leaves volatile accesses unpaired -- what IRS_FWD_TAPS=3 does in the kernel
+                typedef const volatile __attribute__((address_space(3))) f2* VQ;
+                typedef const volatile __attribute__((address_space(3))) float* VZ;
+                const VQ q = (VQ)(reinterpret_cast<const f2*>(xy));
+                const VZ zq = (VZ)zz;
+                const f2 c = q[ctr];
+                a0 += c.x + zq[ctr];
+                a1 += c.y;
+#pragma unroll
+                for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+                    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                        for (int cx = 0; cx < 2; ++cx) {
+                            const int e = (cz ? sl1 : sl0) + off + cy * PITCH + cx;
+                            const f2 t = q[e];
+                            a0 = fmaf(t.x, w0, a0);
+                            a1 = fmaf(t.y, w1, a1);
+                            a2 = fmaf(zq[e], w2, a2);
+                        }
+            } else if (LAYOUT == 0) {
                 const f2* q = reinterpret_cast<const f2*>(xy);
                 const f2 c = q[ctr];
                 a0 += c.x + zz[ctr];
@@ -155,18 +166,20 @@ __global__ __launch_bounds__(kBlock, 4) void tap_probe(float* __restrict__ out, 
                 const unsigned bxy = lds_addr(xy), bz = lds_addr(zz);
                 const unsigned cA = bxy + 8u * (unsigned)ctr, cB = bz + 4u * (unsigned)ctr;
                 const unsigned e0 = (unsigned)(sl0 + off), e1 = (unsigned)(sl1 + off);
-                const unsigned x0 = bxy + 8u * e0, x1 = bxy + 8u * e1, z0 = bz + 4u * e0, z1 = bz + 4u * e1;
-                const f2 c = rd64<0>(cA);
-                const float cz_ = rd32<0>(cB);
-                const f2 t000 = rd64<0>(x0), t001 = rd64<8>(x0), t010 = rd64<8 * PITCH>(x0), t011 = rd64<8 * PITCH + 8>(x0);
-                const f2 t100 = rd64<0>(x1), t101 = rd64<8>(x1), t110 = rd64<8 * PITCH>(x1), t111 = rd64<8 * PITCH + 8>(x1);
-                const float u000 = rd32<0>(z0), u001 = rd32<4>(z0), u010 = rd32<4 * PITCH>(z0), u011 = rd32<4 * PITCH + 4>(z0);
-                const float u100 = rd32<0>(z1), u101 = rd32<4>(z1), u110 = rd32<4 * PITCH>(z1), u111 = rd32<4 * PITCH + 4>(z1);
-                wait_lds();
+                const unsigned x00 = bxy + 8u * e0, x01 = x00 + 8u * PITCH, x10 = bxy + 8u * e1, x11 = x10 + 8u * PITCH;
+                const unsigned z00 = bz + 4u * e0, z01 = z00 + 4u * PITCH, z10 = bz + 4u * e1, z11 = z10 + 4u * PITCH;
+                f2 c, t[8];
+                float cz_, u[8];
+                asm volatile(RD64(0, 18, 0) RD32(1, 19, 0)
+                             RD64(2, 20, 0) RD64(3, 20, 8) RD64(4, 21, 0) RD64(5, 21, 8) RD64(6, 22, 0) RD64(7, 22, 8) RD64(8, 23, 0) RD64(9, 23, 8)
+                             RD32(10, 24, 0) RD32(11, 24, 4) RD32(12, 25, 0) RD32(13, 25, 4) RD32(14, 26, 0) RD32(15, 26, 4) RD32(16, 27, 0) RD32(17, 27, 4)
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(c), "=&v"(cz_), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+                               "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
+                             : "v"(cA), "v"(cB), "v"(x00), "v"(x01), "v"(x10), "v"(x11), "v"(z00), "v"(z01), "v"(z10), "v"(z11)
+                             : "memory");
                 a0 += c.x + cz_;
                 a1 += c.y;
-                const f2 t[8] = {t000, t001, t010, t011, t100, t101, t110, t111};
-                const float u[8] = {u000, u001, u010, u011, u100, u101, u110, u111};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     a0 = fmaf(t[k].x, w0, a0);
@@ -174,12 +187,15 @@ __global__ __launch_bounds__(kBlock, 4) void tap_probe(float* __restrict__ out, 
                     a2 = fmaf(u[k], w2, a2);
                 }
             } else if (LAYOUT == 3) {
-                const unsigned b = lds_addr(lds);
-                const unsigned cA = b + 16u * (unsigned)ctr, x0 = b + 16u * (unsigned)(sl0 + off), x1 = b + 16u * (unsigned)(sl1 + off);
-                const f4 c = rd128<0>(cA);
-                const f4 t[8] = {rd128<0>(x0), rd128<16>(x0), rd128<16 * PITCH>(x0), rd128<16 * PITCH + 16>(x0),
-                                 rd128<0>(x1), rd128<16>(x1), rd128<16 * PITCH>(x1), rd128<16 * PITCH + 16>(x1)};
-                wait_lds();
+                const unsigned bb = lds_addr(lds);
+                const unsigned cA = bb + 16u * (unsigned)ctr, x00 = bb + 16u * (unsigned)(sl0 + off), x01 = x00 + 16u * PITCH,
+                               x10 = bb + 16u * (unsigned)(sl1 + off), x11 = x10 + 16u * PITCH;
+                f4 c, t[8];
+                asm volatile(RD128(0, 9, 0) RD128(1, 10, 0) RD128(2, 10, 16) RD128(3, 11, 0) RD128(4, 11, 16) RD128(5, 12, 0) RD128(6, 12, 16)
+                             RD128(7, 13, 0) RD128(8, 13, 16) "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(c), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                             : "v"(cA), "v"(x00), "v"(x01), "v"(x10), "v"(x11)
+                             : "memory");
                 a0 += c.x + c.z;
                 a1 += c.y;
 #pragma unroll
@@ -192,13 +208,17 @@ __global__ __launch_bounds__(kBlock, 4) void tap_probe(float* __restrict__ out, 
                 const unsigned bxy = lds_addr(xy), bz = lds_addr(zz);
                 const unsigned cA = bxy + 8u * (unsigned)ctr, cB = bz + 8u * (unsigned)ctr;
                 const unsigned e0 = (unsigned)(sl0 + off), e1 = (unsigned)(sl1 + off);
-                const unsigned x0 = bxy + 8u * e0, x1 = bxy + 8u * e1, z0 = bz + 8u * e0, z1 = bz + 8u * e1;
-                const f2 c = rd64<0>(cA);
-                const float cz_ = rd32<0>(cB);
-                const f2 t[8] = {rd64<0>(x0), rd64<8>(x0), rd64<8 * PITCH>(x0), rd64<8 * PITCH + 8>(x0),
-                                 rd64<0>(x1), rd64<8>(x1), rd64<8 * PITCH>(x1), rd64<8 * PITCH + 8>(x1)};
-                const f2 u[4] = {rd64<0>(z0), rd64<8 * PITCH>(z0), rd64<0>(z1), rd64<8 * PITCH>(z1)};  // (d2[x0], d2[x0 + 1]) per (cz, cy)
-                wait_lds();
+                const unsigned x00 = bxy + 8u * e0, x01 = x00 + 8u * PITCH, x10 = bxy + 8u * e1, x11 = x10 + 8u * PITCH;
+                const unsigned z00 = bz + 8u * e0, z01 = z00 + 8u * PITCH, z10 = bz + 8u * e1, z11 = z10 + 8u * PITCH;
+                f2 c, t[8], u[4];  // u: (d2[x0], d2[x0 + 1]) per (cz, cy)
+                float cz_;
+                asm volatile(RD64(0, 14, 0) RD32(1, 15, 0)
+                             RD64(2, 16, 0) RD64(3, 16, 8) RD64(4, 17, 0) RD64(5, 17, 8) RD64(6, 18, 0) RD64(7, 18, 8) RD64(8, 19, 0) RD64(9, 19, 8)
+                             RD64(10, 20, 0) RD64(11, 21, 0) RD64(12, 22, 0) RD64(13, 23, 0) "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(c), "=&v"(cz_), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+                               "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
+                             : "v"(cA), "v"(cB), "v"(x00), "v"(x01), "v"(x10), "v"(x11), "v"(z00), "v"(z01), "v"(z10), "v"(z11)
+                             : "memory");
                 a0 += c.x + cz_;
                 a1 += c.y;
 #pragma unroll
@@ -211,14 +231,23 @@ __global__ __launch_bounds__(kBlock, 4) void tap_probe(float* __restrict__ out, 
                 const unsigned bxy = lds_addr(xy), bz = lds_addr(zz);
                 const unsigned cA = bxy + 8u * (unsigned)ctr, cB = bz + 4u * (unsigned)ctr;
                 const unsigned e0 = (unsigned)(sl0 + by0 * PITCH + lx + R - 1), e1 = (unsigned)(sl1 + by0 * PITCH + lx + R - 1);
-                const unsigned x0 = bxy + 8u * e0, x1 = bxy + 8u * e1, z0 = bz + 4u * e0, z1 = bz + 4u * e1;
-                const f2 c = rd64<0>(cA);
-                const float cz_ = rd32<0>(cB);
-                const f2 t[12] = {rd64<0>(x0), rd64<8>(x0), rd64<16>(x0), rd64<8 * PITCH>(x0), rd64<8 * PITCH + 8>(x0), rd64<8 * PITCH + 16>(x0),
-                                  rd64<0>(x1), rd64<8>(x1), rd64<16>(x1), rd64<8 * PITCH>(x1), rd64<8 * PITCH + 8>(x1), rd64<8 * PITCH + 16>(x1)};
-                const float u[12] = {rd32<0>(z0), rd32<4>(z0), rd32<8>(z0), rd32<4 * PITCH>(z0), rd32<4 * PITCH + 4>(z0), rd32<4 * PITCH + 8>(z0),
-                                     rd32<0>(z1), rd32<4>(z1), rd32<8>(z1), rd32<4 * PITCH>(z1), rd32<4 * PITCH + 4>(z1), rd32<4 * PITCH + 8>(z1)};
-                wait_lds();
+                const unsigned x00 = bxy + 8u * e0, x01 = x00 + 8u * PITCH, x10 = bxy + 8u * e1, x11 = x10 + 8u * PITCH;
+                const unsigned z00 = bz + 4u * e0, z01 = z00 + 4u * PITCH, z10 = bz + 4u * e1, z11 = z10 + 4u * PITCH;
+                f2 c, t[12];
+                float cz_, u[12];
+                asm volatile(RD64(0, 14, 0) RD32(1, 15, 0)
+                             RD64(2, 16, 0) RD64(3, 16, 8) RD64(4, 16, 16) RD64(5, 17, 0) RD64(6, 17, 8) RD64(7, 17, 16)
+                             RD32(8, 18, 0) RD32(9, 18, 4) RD32(10, 18, 8) RD32(11, 19, 0) RD32(12, 19, 4) RD32(13, 19, 8) "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(c), "=&v"(cz_), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]),
+                               "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5])
+                             : "v"(cA), "v"(cB), "v"(x00), "v"(x01), "v"(z00), "v"(z01)
+                             : "memory");  // (26 results + 10 addresses exceed the 30 operands of one statement: two blocks, each with its wait)
+                asm volatile(RD64(0, 12, 0) RD64(1, 12, 8) RD64(2, 12, 16) RD64(3, 13, 0) RD64(4, 13, 8) RD64(5, 13, 16)
+                             RD32(6, 14, 0) RD32(7, 14, 4) RD32(8, 14, 8) RD32(9, 15, 0) RD32(10, 15, 4) RD32(11, 15, 8) "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(t[6]), "=&v"(t[7]), "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]),
+                               "=&v"(u[6]), "=&v"(u[7]), "=&v"(u[8]), "=&v"(u[9]), "=&v"(u[10]), "=&v"(u[11])
+                             : "v"(x10), "v"(x11), "v"(z10), "v"(z11)
+                             : "memory");
                 a0 += c.x + cz_;
                 a1 += c.y;
                 const float m0 = sx ? 1.0f : 0.0f, m2 = sx ? 0.0f : 1.0f;  // column -1 counts for a shifted lane, column +1 for an unshifted one
@@ -281,6 +310,7 @@ int main(int argc, char** argv) {
         run<0, 80>(out, host, L, steps);
         run<0, 66>(out, host, L, steps);
         run<0, 81>(out, host, L, steps);
+        run<6, 80>(out, host, L, steps);
         run<1, 80>(out, host, L, steps);
         run<1, 66>(out, host, L, steps);
         run<1, 81>(out, host, L, steps);
