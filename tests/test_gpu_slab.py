@@ -356,7 +356,9 @@ def _stall_worker(rank, world, port, q, stall_s):
         st2 = eng.state()
         same = (list(st1.gmm_log_std), list(st1.gmm_logits), list(st1.gmm_adam_step), list(st1.reg_param)) == \
                (list(st2.gmm_log_std), list(st2.gmm_logits), list(st2.gmm_adam_step), list(st2.reg_param))
-        q.put((rank, err, bool(torch.equal(v, v1)), int(st1.iteration), int(st2.iteration), same))
+        # (the OWNED planes: a ghost plane of v is refreshed by the transition's first exchange, which on the rank that stalled still
+        # succeeds -- the other rank had pushed it before its own wait gave up)
+        q.put((rank, err, bool(torch.equal(eng.owned(v), eng.owned(v1))), int(st1.iteration), int(st2.iteration), same))
         dist.barrier()
         del eng
         comm.close()
