@@ -1184,6 +1184,9 @@ void launch_reg_energy_march(const float* v, double* partials, int blocks, int C
 // goes through an LDS ring of planes (one-voxel halo), the other streams are read and written once, coalesced.
 // ------------------------------------------------------------------------------------------------
 constexpr int UPX = QTX + 2, UPY = QTY + 2, UPN = UPX * UPY, UNS = 4;
+#ifndef IRS_SWZ_UPDATE_ROWS
+#define IRS_SWZ_UPDATE_ROWS 4
+#endif
 
 // `energy_partials` (optional, [C][tiles per chain]): the regulariser energy sum (forward difference)^2 of v_s as a by-product -- the
 // stencil above is built from exactly those differences and weights.  Used for the regularisers whose coefficient does not depend
@@ -1200,7 +1203,11 @@ __global__ __launch_bounds__(kStBlock) void sgld_update_march_kernel(float* __re
     __shared__ float F[UNS * 3 * UPN];
     __shared__ double esm[kStBlock / kWave];
     double eacc[1] = {0.0};
-    const int tile = xcd_swizzle_runs((int)blockIdx.x, (int)gridDim.x, ntx * IRS_SWZ_STENCIL_ROWS);  // x-neighbouring tiles on one XCD
+    // x-neighbouring tiles AND four y-neighbouring rows of tiles on one XCD: this kernel's 64 x 4 tile reads two halo rows per four
+    // rows of v_s, and it is the one memory-bound kernel of a transition (0.57 of the roofline, 1.36 x its algorithmic bytes in
+    // round 4); with the halo rows of three of four tile rows served by the XCD's L2: 172 against 186 us at 256^3, three alternating
+    // runs on one box (profiles/r05_swz_ab.txt).  The same grouping for the other stencil kernels measured flat: theirs stays 1.
+    const int tile = xcd_swizzle_runs((int)blockIdx.x, (int)gridDim.x, ntx * IRS_SWZ_UPDATE_ROWS);
     const int chain = tile / (ntx * nty * nseg);
     const int t_ = tile % (ntx * nty * nseg);
     const int ox = (t_ % ntx) * QTX, oy = ((t_ / ntx) % nty) * QTY, seg = t_ / (ntx * nty);

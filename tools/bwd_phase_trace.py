@@ -54,6 +54,8 @@ def main():
     for j, nme in enumerate(names + ['loop back']):
         col = [r[j] for r in rows]
         print(f'  {nme:18s} mean {sum(col) / len(col):8.1f}   min {min(col):6d}   max {max(col):6d}')
+    for i, r in enumerate(rows):   # every plane step: the first ones of a workgroup run cold
+        print(f'    step {i:2d}: ' + ' '.join(f'{x:6d}' for x in r) + f'   = {sum(r):6d}')
     tot = [sum(r) for r in rows]
     print(f'  per plane step     mean {sum(tot) / len(tot):8.1f}')
 

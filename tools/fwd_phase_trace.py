@@ -55,6 +55,9 @@ def main():
     for j, nme in enumerate(names + ['loop back']):
         col = [r[j] for r in rows]
         print(f'  {nme:18s} mean {sum(col) / len(col):8.1f}   min {min(col):6d}   max {max(col):6d}')
+    if os.environ.get('IRS_TRACE_ROWS', '1') != '0':   # every plane step: the first ones of a workgroup run cold (first loads, first pass over each unrolled ring phase)
+        for i, r in enumerate(rows):
+            print(f'    step {i:2d}: ' + ' '.join(f'{x:6d}' for x in r) + f'   = {sum(r):6d}')
     tot = [sum(r) for r in rows]
     print(f'  per plane step     mean {sum(tot) / len(tot):8.1f}')
     if e[0] and e[2] > e[0] and e[3] > e[1]:
