@@ -64,6 +64,7 @@ static Knobs knobs_from_env() {
     k.slab_exact = env_or("IRS_SLAB_EXACT", k.slab_exact);
     k.slab_force_h = env_or("IRS_SLAB_FORCE_H", k.slab_force_h);
     k.launch_log = env_or("IRS_LAUNCH_LOG", k.launch_log);
+    k.chain_overlap = env_or("IRS_CHAIN_OVERLAP", k.chain_overlap);
     return k;
 }
 
@@ -112,7 +113,7 @@ int knob_set(Knobs& k, const char* name, int value, bool on_context) {
     static const Entry table[] = {
         {"predict_variants", &Knobs::predict_variants, KN_CTX}, {"run_ahead", &Knobs::run_ahead, KN_CTX}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd, KN_CTX},
         {"energy_in_update", &Knobs::energy_in_update, KN_CTX}, {"fuse_noise", &Knobs::fuse_noise, KN_CTX}, {"recover", &Knobs::recover, KN_CTX},
-        {"slab_split", &Knobs::slab_split, KN_CTX}, {"slab_buffers", &Knobs::slab_buffers, KN_CTX}, {"slab_exact", &Knobs::slab_exact, KN_CTX}, {"slab_force_h", &Knobs::slab_force_h, KN_CTX},
+        {"chain_overlap", &Knobs::chain_overlap, KN_CTX}, {"slab_split", &Knobs::slab_split, KN_CTX}, {"slab_buffers", &Knobs::slab_buffers, KN_CTX}, {"slab_exact", &Knobs::slab_exact, KN_CTX}, {"slab_force_h", &Knobs::slab_force_h, KN_CTX},
         {"fwd_rows1", &Knobs::fwd_rows1, KN_GLOBAL}, {"coarse_box", &Knobs::coarse_box, KN_GLOBAL}, {"lds_from", &Knobs::lds_from, KN_GLOBAL},
         {"fwd_pf", &Knobs::fwd_pf, KN_GLOBAL}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1, KN_GLOBAL}, {"sobolev_tile", &Knobs::sobolev_tile, KN_GLOBAL},
         {"march_seg", &Knobs::march_seg, KN_GLOBAL}, {"march_seg_fwd", &Knobs::march_seg_fwd, KN_GLOBAL}, {"swz_run", &Knobs::swz_run, KN_GLOBAL},
@@ -630,6 +631,10 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 64 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev_bwd[i]);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ra_ev[i], hipEventDisableTiming);
+    if (c->C > 1 && !c->sl.on && c->kn.chain_overlap) {  // the fused engine with several chains: side stream of the per-chain stage (off by default)
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+        for (int i = 0; i < 2 * c->C && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->hint, sizeof(unsigned) * kHintWords, hipHostMallocDefault);
     if (e == hipSuccess)
         for (int i = 0; i < kHintWords; ++i) c->hint[i] = i < kHintWords - 8 ? 0x7f800000u : 0u;  // +inf: nothing known yet, launch every variant; flags clear
@@ -657,6 +662,9 @@ void irs_destroy(irs_ctx* c) {
         if (c->ev_bwd[i]) (void)hipEventDestroy(c->ev_bwd[i]);
     for (int i = 0; i < 4; ++i)
         if (c->ra_ev[i]) (void)hipEventDestroy(c->ra_ev[i]);
+    for (int i = 0; i < 2 * IRS_MAX_CHAINS; ++i)
+        if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->lin.dev) (void)hipFree(c->lin.dev);
     if (c->hint) (void)hipHostFree(c->hint);
     if (c->slab) (void)hipFree(c->slab);
@@ -900,16 +908,31 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
         launch_reg_scalar(c->state, c->energy_partials, energy_blocks(volv), c->dcfg, st, vd);
     }
 
-    // per chain, serially (trainer.py:316-327): VD factor -> GMM step -> data term with the UPDATED mixture
+    // per chain, serially (trainer.py:316-327): VD factor -> GMM step -> data term with the UPDATED mixture.  The serial part is the
+    // mixture: the statistics of chain c + 1 need the parameters chain c's step left, and that step must not touch them while the
+    // data term of chain c still reads them -- but the data term of chain c (a 36 us launch of 1024 workgroups at 128^3, alone on
+    // the chip) and the statistics of chain c + 1 (24 us) only READ the same parameters: with `chain_overlap` the former runs on a
+    // side stream, the next chain's scalar stage waits for it.  Same kernels, same inputs, same order of every sum: chains
+    // bit-identical (tests/test_gpu_transition.py).  Measured SLOWER than the serial form (the two half-filled launches get in each
+    // other's way and every chain pays two event hand-overs; profiles/r05_chain_overlap_ab.txt): off by default.
     const int sb = stats_blocks(vol);
+    const bool overlap = C > 1 && c->side && c->kn.chain_overlap != 0;
     for (int ch = 0; ch < C; ++ch) {
         const uint8_t* mask = io->mask + (io->mask_chains == 1 ? 0 : (int64_t)ch * vol.V);
         const float* zc = z + (int64_t)ch * vol.V;
         launch_stats(cfg.virtual_decimation, zc, mask, c->state, c->stat_partials, vol, st, c->dcfg.K);
+        if (overlap && ch > 0) HIP_TRY(hipStreamWaitEvent(st, c->ev_side[2 * (ch - 1) + 1], 0));  // data term of chain ch - 1 has read the mixture
         launch_chain_scalar(c->state, c->stat_partials, sb, ch, ch == 0 ? 7 : 3, c->dcfg, st, vd);  // chain 0: + the verdict
         const float* f = cfg.data_loss == IRS_DATA_GMM_LCC ? c->fhat + (c->fhat_chains == 1 ? 0 : (int64_t)ch * vol.V) : nullptr;
+        hipStream_t ds = st;
+        if (overlap && ch + 1 < C) {  // (the last chain's data term has nothing to overlap with: it stays on the caller's stream)
+            HIP_TRY(hipEventRecord(c->ev_side[2 * ch], st));
+            HIP_TRY(hipStreamWaitEvent(c->side, c->ev_side[2 * ch], 0));
+            ds = c->side;
+        }
         launch_data_bwd(cfg.data_loss, f, 0, zc, c->sigM + (int64_t)ch * vol.V, mask, 0, nullptr, c->state, ch,
-                        c->gM + (int64_t)ch * vol.V, c->nll_partials + (int64_t)ch * c->nll_blocks, cfg.lcc_s, 1, vol, st);
+                        c->gM + (int64_t)ch * vol.V, c->nll_partials + (int64_t)ch * c->nll_blocks, cfg.lcc_s, 1, vol, ds);
+        if (ds != st) HIP_TRY(hipEventRecord(c->ev_side[2 * ch + 1], c->side));
     }
     // back through the warp and the squaring steps
     if (!fuse_warp_bwd)

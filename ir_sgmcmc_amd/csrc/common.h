@@ -101,6 +101,9 @@ struct Knobs {
     int slab_split = 1;        // IRS_SLAB_SPLIT        interior / boundary split around an exchange
     int slab_exact = 0;        // IRS_SLAB_EXACT        every transition in measuring mode
     int slab_force_h = 0;      // IRS_SLAB_FORCE_H      test hook: a deliberately wrong ghost-width plan
+    int chain_overlap = 0;     // IRS_CHAIN_OVERLAP     C > 1: data term of chain c on a side stream, overlapping the statistics of chain c + 1
+                               //                       (round 5, asked for; measured SLOWER: 0.728 against 0.711 ms per chain-transition at 128^3
+                               //                       C = 2, 1.931 against 1.917 at 192^3, three alternating runs -- off; read when a context is created)
     int launch_log = 0;        // IRS_LAUNCH_LOG        print the shape of every distinct marching launch once (stderr; tools/launch_shapes.py)
 };
 Knobs& global_knobs();                                   // api.hip; initialised from the environment on first use

@@ -66,6 +66,10 @@ struct irs_ctx {
     hipEvent_t ev[8];
     hipEvent_t ev_bwd[64];
     hipEvent_t ra_ev[4];     // end of the last transitions: bounds how far the host may run ahead of the device
+    // several chains: the data term of chain c runs on a side stream while the statistics of chain c + 1 run on the caller's
+    // (api.hip: the per-chain stage); created with the context when C > 1
+    hipStream_t side = nullptr;
+    hipEvent_t ev_side[2 * IRS_MAX_CHAINS] = {};
     uint64_t n_enqueued = 0;
     irs::Knobs kn;            // copy of the process-wide switches, taken by irs_create (irs_option_set changes it)
     bool dmax_clean = false;  // the bound scratch was cleared by the finalize kernel of the last transition

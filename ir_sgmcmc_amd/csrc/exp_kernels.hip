@@ -689,6 +689,12 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #ifndef IRS_BWD_TAPS
 #define IRS_BWD_TAPS 0  // 1: the eight corner reads of the own term as single ds_read_b64 / ds_read_b32 (volatile, as IRS_FWD_TAPS); A/B in round 5
 #endif
+#ifndef IRS_FWD_BUFLOAD
+#define IRS_FWD_BUFLOAD 0  // marching forward step: staging loads as buffer loads; A/B in round 5
+#endif
+#ifndef IRS_BWD_BUFLOAD
+#define IRS_BWD_BUFLOAD 0  // marching adjoint: staging loads as buffer loads (descriptor + 32-bit lane offset); A/B in round 5
+#endif
 #ifndef IRS_BWD_R1_FALLBACK
 #define IRS_BWD_R1_FALLBACK 1
 #endif
@@ -724,6 +730,22 @@ __device__ __forceinline__ void st3_off(float* __restrict__ base, unsigned byte_
 }
 __device__ __forceinline__ void st_off(float* __restrict__ base, unsigned byte_off, float v) {
     *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+// buffer loads: a raw descriptor over "everything from `base` on" (in SGPRs: the base is wave-uniform), 32-bit lane byte offset
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld1(const float* __restrict__ base, unsigned byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(buf_rsrc(base), (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ F3 buf_ld3(const float* __restrict__ base, unsigned byte_off) {
+    typedef unsigned U3 __attribute__((ext_vector_type(3)));
+    const U3 v = __builtin_amdgcn_raw_buffer_load_b96(buf_rsrc(base), (int)byte_off, 0, 0);
+    F3 f;
+    f.x = __uint_as_float(v.x);
+    f.y = __uint_as_float(v.y);
+    f.z = __uint_as_float(v.z);
+    return f;
 }
 __device__ __forceinline__ float clamp01(float t) { return __builtin_amdgcn_fmed3f(t, 0.0f, 1.0f); }
 __device__ __forceinline__ float hat01(float t) { return clamp01(1.0f - fabsf(t)); }
@@ -894,6 +916,38 @@ __device__ __forceinline__ void exp_bwd_march_tile(const float* __restrict__ G, 
         const float* __restrict__ p3_ = Gx_ + zo * LG.em;
         const float* __restrict__ p4_ = Gy_ + zo * LG.em;
         const float* __restrict__ p5_ = Gz_ + zo * LG.em;
+        if (IRS_BWD_BUFLOAD && R == 1) {
+        // the staging loads as BUFFER loads: descriptor of the plane in SGPRs, 32-bit lane offset -- no 64-bit VALU address arithmetic
+        // and no 64-bit lane-offset pairs (the global_load form cost one v_lshl_add_u64 per load and six VGPR pairs: the address is
+        // formed in the block in front of the layout branch, so instruction selection never saw base + offset at the load)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (sxy[it] < 0) continue;
+            const unsigned g = (unsigned)sxy[it] * 4u, gd = g * (unsigned)LD.em, gg = g * (unsigned)LG.em;
+            if (LD.em == 3) {
+                const F3 v = buf_ld3(p0_, gd);
+                pre[it][0] = v.x;
+                pre[it][1] = v.y;
+                pre[it][2] = v.z;
+            } else {
+                pre[it][0] = buf_ld1(p0_, gd);
+                pre[it][1] = buf_ld1(p1_, gd);
+                pre[it][2] = buf_ld1(p2_, gd);
+            }
+            if (LG.em == 3) {
+                const F3 v = buf_ld3(p3_, gg);
+                pre[it][3] = v.x;
+                pre[it][4] = v.y;
+                pre[it][5] = v.z;
+            } else {
+                pre[it][3] = buf_ld1(p3_, gg);
+                pre[it][4] = buf_ld1(p4_, gg);
+                pre[it][5] = buf_ld1(p5_, gg);
+            }
+            if (gs_) pgs[it] = buf_ld1(gs_ + zo, g);
+        }
+        return;
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
@@ -1351,7 +1405,18 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
             const unsigned g = (unsigned)sxy[it] * 4u * (unsigned)LD.em;
-            if (LD.em == 3) {
+            if (IRS_FWD_BUFLOAD) {  // buffer loads: plane descriptor in SGPRs + 32-bit lane offset (see the adjoint's staging)
+                if (LD.em == 3) {
+                    const F3 v = buf_ld3(px_, g);
+                    pre[it][0] = v.x;
+                    pre[it][1] = v.y;
+                    pre[it][2] = v.z;
+                } else {
+                    pre[it][0] = buf_ld1(px_, g);
+                    pre[it][1] = buf_ld1(py_, g);
+                    pre[it][2] = buf_ld1(pz_, g);
+                }
+            } else if (LD.em == 3) {
                 const F3 v = ld3_off(px_, g);
                 pre[it][0] = v.x;
                 pre[it][1] = v.y;
