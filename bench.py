@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is 
 BYTES_PER_VOXEL = {'gmm': 878.0, 'ssd': 854.0}  # algorithmic bytes / voxel / chain / transition
 BWD_STEP_BYTES_PER_VOXEL = 36.0
 FWD_STEP_BYTES_PER_VOXEL = 24.0
-TRAFFIC_PROFILE = os.path.join('profiles', 'r04_pmc_traffic.json')  # written by tools/profile_round.sh for THIS library build
+TRAFFIC_PROFILE = os.path.join('profiles', 'r05_pmc_traffic.json')  # written by tools/profile_round.sh for THIS library build
 
 
 def traffic_from_profile(n):

@@ -713,8 +713,12 @@ __device__ __forceinline__ float rel_hat(float r, int c);
 
 // hat function max(0, 1 - |t|).  v_med3_f32 folds into the clamp output modifier of the subtraction (one VALU op);
 // HIP's __saturatef compiles to two compares and two selects.
-// load p[byte_off / 4] with the address formed as (uniform 64-bit base) + (32-bit lane byte offset): the global_load
-// saddr form, no 64-bit VALU address arithmetic per load.  Planes are < 4 GiB, so a 32-bit byte offset always suffices.
+// load p[byte_off / 4] with the address written as (uniform 64-bit base) + (32-bit lane byte offset).  Planes are < 4 GiB, so a
+// 32-bit byte offset always suffices.  (What the compiler makes of it in the marching kernels is NOT the global_load saddr form the
+// expression invites: the sum is formed in the block in front of the layout branch, so each staging load costs one v_lshl_add_u64
+// and the lane offsets live in 64-bit VGPR pairs -- 146 of the adjoint's 148 global loads, as the round-4 review found in the ISA.
+// Buffer loads -- descriptor in SGPRs, 32-bit lane offset: IRS_BWD_BUFLOAD / IRS_FWD_BUFLOAD -- remove both (122 instead of 128
+// VGPRs in the adjoint, 28 VALU instructions fewer in its loop) and measured no faster: profiles/r05_bufload_ab.txt.)
 __device__ __forceinline__ float ld_off(const float* __restrict__ base, unsigned byte_off) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
