@@ -870,6 +870,7 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
     // (max|d_k| < 1, the radius-1 gather has no fallback), so it goes into the verdict the device evaluates after the forward
     // pass (scalar_kernels.h: Verdict): if it does not hold the transition is a no-op and is re-run (irs_transition below).
     bool skip_any[32], skip_r2[32];
+    note_hint_trend(c);
     Verdict vd = no_verdict();
     vd.bounds = c->dmax;
     vd.n = cfg.no_steps;

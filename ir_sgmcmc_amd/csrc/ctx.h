@@ -79,6 +79,9 @@ struct irs_ctx {
     uint64_t fails_total = 0;       // statistics
     uint64_t force_all_until = 0;   // transitions enqueued before this count make no assumptions
     uint64_t exact_until = 0;       // slab: transitions enqueued before this count measure their ghost widths
+    float hint_seen[32] = {}, hint_before[32] = {};  // per squaring step: the bound (max over chains / axes) the host last saw published,
+                                    // and the DIFFERENT value it saw before that: how fast the bound moves per published snapshot
+    bool hint_trend[32] = {};       // both are real observations (not the +inf of a fresh context)
     irs_io last_io;                 // the io of the last irs_transition call (irs_flush re-runs with it)
     bool have_last_io = false;
     // ---- z-slab decomposition (slab.hip)
@@ -142,8 +145,46 @@ inline bool predicted_small(const irs_ctx* c, int k) { return predicted_below(c,
 // from the production heuristic only, with a 2.5x margin -- d_k moves by O(0.1) voxel per transition and the host is at most
 // two transitions behind -- and (b) VALIDATED on the device: finalize_kernel compares the bounds of the steps whose variant
 // was skipped with 1 and raises a sticky flag that the next irs_transition returns as an error.
+// Round 5: ... or below 0.66 voxel while the bound has been moving by less than 10 % per published snapshot (observed, not assumed:
+// irs_ctx::hint_seen / hint_before, refreshed by note_hint_trend at every call): two snapshots on that is < 0.8 voxel.  A chain at
+// rest in the bench regime carries max|d_10| ~ 0.45 voxel: with the fixed 0.4 rule alone its radius-2 adjoint variant was launched,
+// found nothing to do and cost ~8 us (5 us of launch + the gap to the next kernel) every transition -- 1 % of a 128^3 transition.
 inline bool predicted_tiny(const irs_ctx* c, int k) {
-    return c->kn.predict_variants == 3 || (c->kn.predict_variants == 1 && predicted_below(c, k, 0.4f));  // 3: test hook, always
+    if (c->kn.predict_variants == 3) return true;  // test hook, always
+    if (c->kn.predict_variants != 1) return false;
+    if (predicted_below(c, k, 0.4f)) return true;
+#ifdef IRS_NO_TREND  // (A/B builds: the fixed rule alone)
+    return false;
+#endif
+    if (k >= 32 || !c->hint_trend[k] || !predicted_below(c, k, 0.66f)) return false;
+    const float a = c->hint_before[k], b = c->hint_seen[k];
+    return a > 0.0f && b < 1.1f * a;
+}
+// refresh the observed trend of the published bounds (host side, unsynchronised reads of the pinned hint -- a hint, like the rest)
+inline void note_hint_trend(irs_ctx* c) {
+    if (!c->hint) return;
+    for (int k = 0; k < c->cfg.no_steps && k < 32; ++k) {
+        const volatile unsigned* h = c->hint + (size_t)k * c->C * 4;
+        float m = 0.0f;
+        bool ok = true;
+        for (int i = 0; i < c->C * 4; ++i) {
+            const unsigned bits = h[i];
+            float f;
+            memcpy(&f, &bits, sizeof(f));
+            if (!(f >= 0.0f) || f > 1.0e6f) ok = false;  // NaN / +inf (nothing published yet) / garbage
+            m = f > m ? f : m;
+        }
+        if (!ok) {
+            c->hint_trend[k] = false;
+            c->hint_seen[k] = 0.0f;
+            continue;
+        }
+        if (m != c->hint_seen[k]) {
+            c->hint_trend[k] = c->hint_seen[k] > 0.0f;  // a second DIFFERENT observation
+            c->hint_before[k] = c->hint_seen[k];
+            c->hint_seen[k] = m;
+        }
+    }
 }
 
 // Layouts of the INTERNAL fields of the fused path (exp_kernels.hip: Lay3; bits 1 displacement in, 2 gradient in, 4 out):
