@@ -725,6 +725,11 @@ int irs_set_state(irs_ctx* c, const irs_state* in, void* stream) {
     if (!c || !in) return fail("irs_set_state: null argument");
     // The chain is being replaced (resume, hand-over from the VI stage): transitions of the OLD chain that were dropped by a
     // failed prediction and not re-run yet must not be re-run on the restored one.  Wait, take note of the count, forget them.
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+        if (cap != hipStreamCaptureStatusNone) return fail("irs_set_state: the stream is being captured -- this call waits for the stream, which a capture forbids");
+    }
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (c->sl.on) irs::slab_drop_pending(c);
     else drop_pending(c);
@@ -990,6 +995,13 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
     c->dmax_clean = true;
     LAUNCH_CHECK();
     if (timed) HIP_TRY(hipEventRecord(c->ev[5], st));
+    {
+        // (under stream capture nothing has been enqueued on the device -- the launch sequence became graph nodes, and an event
+        // recorded inside a capture cannot be waited for by the host: the run-ahead bookkeeping counts executed transitions only)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) return 0;
+    }
     HIP_TRY(hipEventRecord(c->ra_ev[c->n_enqueued % 4], st));
     ++c->n_enqueued;
     return 0;
@@ -1020,7 +1032,14 @@ static int transition_impl(irs_ctx* c, const irs_io* io, hipStream_t st, int tim
         // baked into it (a replay whose verdict failed would stay a no-op on every replay) and no pending re-run belongs in it.
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cap);
-        if (cap != hipStreamCaptureStatusNone) return enqueue_transition(c, io, st, 0, true);
+        if (cap != hipStreamCaptureStatusNone) {
+            // (timing events are read back by the host right after the call, which a captured stream never executed: refused.
+            // The io of this call is still "the last one": irs_flush re-runs with it.)
+            if (timed) return fail("irs_transition_timed: the stream is being captured -- per-stage timings need a stream that executes");
+            c->last_io = *io;
+            c->have_last_io = true;
+            return enqueue_transition(c, io, st, 0, true);
+        }
     }
     // Bounded run-ahead: the host may be at most IRS_RUN_AHEAD (default 2) transitions ahead of the device.  The variant
     // prediction reads bounds the device published at the end of an earlier transition; a host that has queued twenty

@@ -139,7 +139,20 @@ inline bool predicted_below(const irs_ctx* c, int k, float bound) {
 // (0.9: the radius-2 FORWARD variant only has work at max|d_k| >= 1, and the radius-1 kernel that remains reads a tap that leaves its
 // ring from global memory -- a bound that crosses 1 between this guess and the launch costs that one step some speed, nothing else.
 // With 0.75 a chain whose d_11 sits between 0.75 and 1 voxel -- the bench's -- paid an idle launch (~5 us) per transition for nothing.)
-inline bool predicted_small(const irs_ctx* c, int k) { return predicted_below(c, k, 0.9f); }
+// (Round 5: ... and from 0.97 while the bound has been moving by less than 10 % per published snapshot -- the same observed trend as
+// predicted_tiny below.  The chain at rest of the bench carries max|d_11| ~ 0.9 voxel: its radius-2 forward launch was idle every time.)
+inline bool bound_is_steady(const irs_ctx* c, int k) {
+    if (k >= 32 || !c->hint_trend[k]) return false;
+    const float a = c->hint_before[k], b = c->hint_seen[k];
+    return a > 0.0f && b < 1.1f * a;
+}
+inline bool predicted_small(const irs_ctx* c, int k) {
+    if (predicted_below(c, k, 0.9f)) return true;
+#ifdef IRS_NO_TREND
+    return false;
+#endif
+    return c->kn.predict_variants == 1 && bound_is_steady(c, k) && predicted_below(c, k, 0.97f);
+}
 // "max |d_k| is nowhere near one voxel": the radius-2 ADJOINT variant is not even launched.  Unlike the guesses above this one
 // is not backed by a fallback inside the kernel that remains (the radius-1 gather only covers |d| < 1), so it is (a) taken
 // from the production heuristic only, with a 2.5x margin -- d_k moves by O(0.1) voxel per transition and the host is at most
@@ -156,9 +169,7 @@ inline bool predicted_tiny(const irs_ctx* c, int k) {
 #ifdef IRS_NO_TREND  // (A/B builds: the fixed rule alone)
     return false;
 #endif
-    if (k >= 32 || !c->hint_trend[k] || !predicted_below(c, k, 0.66f)) return false;
-    const float a = c->hint_before[k], b = c->hint_seen[k];
-    return a > 0.0f && b < 1.1f * a;
+    return bound_is_steady(c, k) && predicted_below(c, k, 0.66f);
 }
 // refresh the observed trend of the published bounds (host side, unsynchronised reads of the pinned hint -- a hint, like the rest)
 inline void note_hint_trend(irs_ctx* c) {

@@ -453,6 +453,52 @@ def test_chain_overlap_never_changes_the_result(data_loss):
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
 
 
+def test_transition_under_stream_capture_replays_the_plain_chain():
+    """A transition captured into a HIP graph (torch.cuda.CUDAGraph on the current stream: the library launches on the stream it is
+    handed) carries no host prediction -- every variant is launched, nothing is re-run -- and its replays are the plain chain, bit for
+    bit (in-kernel Philox noise: the counter lives on the device and advances per replay).  What a capture cannot carry is refused,
+    loudly: per-stage timings (their events are read back right after the call) and irs_set_state (it waits for the stream)."""
+    from ir_sgmcmc_amd import _lib as L
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    N = 24
+    f1, m1 = synthetic_pair((N, N, N), seed=0)
+    fixed = to_dev({k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'})
+    moving = to_dev({k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'})
+
+    def fresh():
+        eng = TransitionEngine(EngineConfig(dims=(N, N, N), seed=7), DEV)
+        fd, md = eng.prepare(fixed, moving)
+        eng.gmm_init(fd, md)
+        return eng, fd, md
+
+    eng, fd, md = fresh()
+    v_plain = torch.zeros(1, 3, N, N, N, device=DEV)
+    for _ in range(4):
+        eng.transition(fd, md, v_plain)
+    eng.flush()
+    st_plain = eng.state()
+
+    eng, fd, md = fresh()
+    v = torch.zeros(1, 3, N, N, N, device=DEV)
+    eng.transition(fd, md, v)                     # (one plain transition first: lazily created resources exist before the capture)
+    eng.flush()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.transition(fd, md, v)
+        with pytest.raises(L.IrsError, match='captured'):
+            eng.transition(fd, md, v, timed=True)
+        with pytest.raises(L.IrsError, match='captured'):
+            eng.set_state(st_plain)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    eng.flush()
+    assert torch.equal(v, v_plain)
+    st = eng.state()
+    assert int(st.iteration) == int(st_plain.iteration) == 4
+    assert list(st.gmm_log_std) == list(st_plain.gmm_log_std) and list(st.gmm_logits) == list(st_plain.gmm_logits)
+
+
 def test_misprediction_is_recovered_not_fatal():
     """A transition launched WITHOUT a kernel variant its displacement then needs (forced: predict_variants = 3 always predicts
     'tiny', so the radius-2 adjoint is never launched, while the field carries several voxels) must not end the chain: the
