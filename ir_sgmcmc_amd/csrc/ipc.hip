@@ -9,13 +9,14 @@
 //   bootstrap   a POSIX shared-memory segment named by the caller: every rank publishes the hipIpcMemHandle_t of ONE device
 //               allocation (its landing area) there and opens its peers'.  The same segment, page-locked and mapped into every
 //               rank's device address space (hipHostRegister), holds the sequence flags: uncached system memory, so a store
-//               of one process's kernel is what the next poll of another's reads.  (Flags inside the landing areas -- polled
-//               locally, written through the peer mapping -- were built and do NOT work: on this driver a system-scope poll of
-//               hipMalloc memory never saw the other process's store, even with both ranks on one device.)
+//               of one process's kernel is what the next poll of another's reads.  (Round 4: flags inside landing areas of plain
+//               hipMalloc memory -- polled locally, written through the peer mapping -- did NOT work: a system-scope poll never saw
+//               the other process's store, even with both ranks on one device.)
 //               IRS_IPC_FLAGS=device (round 5) places them in the header of every rank's LANDING AREA instead -- polled locally,
 //               raised by the peer through its mapping: on a node a hand-over is then one xGMI store and local polls instead of
-//               two PCIe round trips.  Whether a poll of (uncached) device memory sees another DEVICE's store is exactly what a
-//               one-GPU box cannot tell: the pre-flight child (ir_sgmcmc_amd/ipc_preflight.py) probes it with a short timeout --
+//               two PCIe round trips.  With the landing area in UNCACHED device memory this works with two ranks on one device
+//               (tests/test_gpu_slab.py) and a hand-over is 10-16 % cheaper (profiles/r05_comm_probe_flags.json).  Whether a poll
+//               of device memory sees another DEVICE's store is exactly what a one-GPU box cannot tell: the pre-flight child (ir_sgmcmc_amd/ipc_preflight.py) probes it with a short timeout --
 //               a flag that never arrives is a clean error since round 5 -- and bench.py uses device flags only where every
 //               rank's child proved them.
 //   exchange    push kernel: packs this rank's strips into slot (seq & 1) of each neighbour's landing area; when its last

@@ -392,3 +392,16 @@ def test_ipc_timeout_is_fail_safe(monkeypatch):
     for rank, err, v_same, it1, it2, params_same in res:
         assert err is not None and 'timed out' in err, (rank, err)
         assert v_same and params_same and it1 == it2 == 1, (rank, v_same, params_same, it1, it2)
+
+
+def test_slab_sequence_flags_in_device_memory(monkeypatch):
+    """IRS_IPC_FLAGS=device: the sequence flags of the peer-mapped transport in the (uncached) landing areas instead of host shared
+    memory -- polled locally, raised by the peer through its mapping (csrc/ipc.hip).  bench.py uses that placement on a node where the
+    pre-flight children of every rank proved it; here two ranks on the one device run the same exchange test over it: same chain."""
+    monkeypatch.setenv('IRS_IPC_FLAGS', 'device')   # (inherited by the spawned ranks)
+    monkeypatch.setenv('IRS_IPC_TIMEOUT_S', '10')
+    dv, dd, ds, st = _launch(2, 'GMM', 1, 32, True, 9.0, 'RegLoss_LogNormal', 4, transport='ipc')
+    from tests._report import check
+    check('slab_ipc_device_flags/GMM_C1_N32_ranks2_g4_amp9', 'v_new (rel to max)', dv, 0.0, 1e-5)
+    check('slab_ipc_device_flags/GMM_C1_N32_ranks2_g4_amp9', 'displacement [voxels]', dd, 0.0, 1e-5)
+    check('slab_ipc_device_flags/GMM_C1_N32_ranks2_g4_amp9', 'loss terms (rel)', ds, 0.0, 1e-6)
