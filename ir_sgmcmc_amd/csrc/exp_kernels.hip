@@ -689,6 +689,9 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #ifndef IRS_BWD_TAPS
 #define IRS_BWD_TAPS 0  // 1: the eight corner reads of the own term as single ds_read_b64 / ds_read_b32 (volatile, as IRS_FWD_TAPS); A/B in round 5
 #endif
+#ifndef IRS_FWD_FMA
+#define IRS_FWD_FMA 0  // forward step: the 24 tap products accumulated with fused multiply-adds (gives up ATen's rounding order); A/B in round 5
+#endif
 #ifndef IRS_FWD_BUFLOAD
 #define IRS_FWD_BUFLOAD 0  // marching forward step: staging loads as buffer loads; A/B in round 5
 #endif
@@ -1535,9 +1538,15 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                                 const float2 t2 = r_xy[bs + cy * PITCH + cx];
                                 const float t1 = r_z[bs + cy * PITCH + cx];
 #endif
+#if IRS_FWD_FMA
+                                a0 = fmaf(t2.x, w, a0);
+                                a1 = fmaf(t2.y, w, a1);
+                                a2 = fmaf(t1, w, a2);
+#else
                                 a0 = __fadd_rn(a0, __fmul_rn(t2.x, w));
                                 a1 = __fadd_rn(a1, __fmul_rn(t2.y, w));
                                 a2 = __fadd_rn(a2, __fmul_rn(t1, w));
+#endif
                             }
                     }
                 };
@@ -1557,9 +1566,15 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                             for (int cx = 0; cx < 2; ++cx) {
                                 const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
                                 const int64_t idx = (((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0)) * LD.em;
+#if IRS_FWD_FMA
+                                a0 = fmaf(ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.rnm1[0], sc.inv_pow), w, a0);
+                                a1 = fmaf(ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.rnm1[1], sc.inv_pow), w, a1);
+                                a2 = fmaf(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.rnm1[2], sc.inv_pow), w, a2);
+#else
                                 a0 = __fadd_rn(a0, __fmul_rn(ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.rnm1[0], sc.inv_pow), w));
                                 a1 = __fadd_rn(a1, __fmul_rn(ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.rnm1[1], sc.inv_pow), w));
                                 a2 = __fadd_rn(a2, __fmul_rn(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.rnm1[2], sc.inv_pow), w));
+#endif
                             }
                 }
                 const int64_t pl = (int64_t)zo * vol.H * vol.W * LO.em;
