@@ -238,8 +238,9 @@ struct Lin {
 
 // ------------------------------------------------------------------------------------------------
 // trilinear sampling, ATen semantics (bilinear / border / align_corners=True).
-// Arithmetic order follows ATen's CPU grid_sampler_3d (no FMA contraction) so that the forward pass is
-// near bit-identical to the reference's CPU path: i = ((g + 1) / 2) * (n - 1); clip to [0, n-1] with a zero
+// Arithmetic order follows ATen's CPU grid_sampler_3d (no FMA contraction in the coordinate arithmetic) so that positions, cell
+// indices and weights are the reference's CPU path's bit for bit (the squaring step accumulates its tap PRODUCTS with FMAs since
+// round 5, exp_kernels.hip: IRS_FWD_FMA): i = ((g + 1) / 2) * (n - 1); clip to [0, n-1] with a zero
 // gradient on and outside the border; weights (i0 + 1 - i) and (i - i0); corners accumulated x fastest.
 // ------------------------------------------------------------------------------------------------
 struct AxisTap {

@@ -690,7 +690,14 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #define IRS_BWD_TAPS 0  // 1: the eight corner reads of the own term as single ds_read_b64 / ds_read_b32 (volatile, as IRS_FWD_TAPS); A/B in round 5
 #endif
 #ifndef IRS_FWD_FMA
-#define IRS_FWD_FMA 0  // forward step: the 24 tap products accumulated with fused multiply-adds (gives up ATen's rounding order); A/B in round 5
+// The 24 tap products of a sample accumulated with fused multiply-adds (round 5).  The COORDINATE arithmetic -- positions, cell
+// indices, weights: what decides which cell a sample falls into and what the reference's gradient is compared against -- keeps
+// ATen's order (common.h: axis_tap); the accumulation a += t * w rounds once instead of twice per tap.  Until round 4 it was kept
+// FMA-free for bit-identity with ATen's CPU sampler; measured now that the LDS is no longer what the kernel waits for: 87.0-88.1
+// against 93.5-94.8 us per step at 256^3, 4.296-4.331 against 4.385-4.404 ms per transition, 2 spilled VGPRs instead of 10 --
+// and every parity test with unchanged margins (256^3: 1.037e-4 voxels against the oracle, as before; the 32^3 fixtures go from
+// exactly 0 to 1.6e-6 of a tolerance of 1e-4): profiles/r05_fwdfma_ab.txt, profiles/parity_report_r05.json.
+#define IRS_FWD_FMA 1
 #endif
 #ifndef IRS_FWD_BUFLOAD
 #define IRS_FWD_BUFLOAD 0  // marching forward step: staging loads as buffer loads; A/B in round 5
