@@ -689,6 +689,9 @@ constexpr int MTX = IRS_MTX, MTY = IRS_MTY, kMarchBlock = MTX * MTY;
 #ifndef IRS_BWD_TAPS
 #define IRS_BWD_TAPS 0  // 1: the eight corner reads of the own term as single ds_read_b64 / ds_read_b32 (volatile, as IRS_FWD_TAPS); A/B in round 5
 #endif
+#ifndef IRS_FWD_REC16
+#define IRS_FWD_REC16 0
+#endif
 #ifndef IRS_FWD_FMA
 // The 24 tap products of a sample accumulated with fused multiply-adds (round 5).  The COORDINATE arithmetic -- positions, cell
 // indices, weights: what decides which cell a sample falls into and what the reference's gradient is compared against -- keeps
@@ -1368,9 +1371,16 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
     constexpr int PX = M::PX, PN = M::PN, NIT = M::NIT, PITCH = M::PITCH, PNP = M::PNP, kFwdBlock = M::kFwdBlock;
     // ring of 2R+2 slots: one more than a sample can reach, so that the commit of the next source plane never overwrites
     // a plane another wavefront is still sampling -> ONE barrier per plane instead of two
-    constexpr int NS = M::NP + 1;
-    __shared__ float2 r_xy[NS * PNP];  // (d0, d1): one ds_read_b64 per tap
-    __shared__ float r_z[NS * PNP];    // d2
+    // (IRS_FWD_REC16, A/B of round 5: 16-byte records (d0, d1, d2, -), one ds_read_b128 per tap -- the layout the tap probe ranks
+    // first in isolation.  At 16 bytes per record only 2R+1 slots fit the 40 KB that four workgroups per CU allow, so the one-barrier
+    // trick above goes: a second barrier per plane step.  Radius-1 kernel with one plane of prefetch only.)
+    // (IRS_FWD_REC16 = 2: also the one-row variant of small launches -- two workgroups of 512 threads per CU either way, so it keeps
+    // its spare slot and its single barrier at 51 KB)
+    constexpr bool REC16 = R == 1 && ((IRS_FWD_REC16 >= 1 && PF == 1) || IRS_FWD_REC16 >= 2);
+    constexpr int NS = REC16 && PF == 1 ? M::NP : M::NP + 1;
+    __shared__ float2 r_xy[REC16 ? 1 : NS * PNP];  // (d0, d1): one ds_read_b64 per tap
+    __shared__ float r_z[REC16 ? 1 : NS * PNP];    // d2
+    __shared__ float4 r_q[REC16 ? NS * PNP : 1];
     __shared__ float red[3 * (kFwdBlock / kWave)];
     const int tile_ = xcd_swizzle_runs(tile_id, (int)(tiles.x * tiles.y * tiles.z), swz_run);
     const int tbx = tile_ % tiles.x, tby = (tile_ / tiles.x) % tiles.y, tbz = tile_ / (tiles.x * tiles.y);
@@ -1447,6 +1457,12 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
         for (int it = 0; it < NIT; ++it) {
             if (sxy[it] < 0) continue;
             const int i = slot * PNP + sld[it];
+            if (REC16) {
+                r_q[i] = make_float4(PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.rnm1[0], sc.inv_pow) : pre[it][0],
+                                     PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.rnm1[1], sc.inv_pow) : pre[it][1],
+                                     PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.rnm1[2], sc.inv_pow) : pre[it][2], 0.0f);
+                continue;
+            }
             r_xy[i] = make_float2(PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.rnm1[0], sc.inv_pow) : pre[it][0],
                                   PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.rnm1[1], sc.inv_pow) : pre[it][1]);
             r_z[i] = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.rnm1[2], sc.inv_pow) : pre[it][2];
@@ -1506,8 +1522,19 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
                 const float liny = liny_[j];
                 const int a = (PH - R + NS) % NS;  // slot of plane zo (compile-time)
                 const int ci = a * PNP + (ly + R) * PITCH + (lx + R);
-                const float2 dxy = r_xy[ci];
-                const float d0 = dxy.x, d1 = dxy.y, d2 = r_z[ci];
+                float d0, d1, d2;
+                if (REC16) {
+                    typedef float VF4 __attribute__((ext_vector_type(4)));  // (volatile: a plain read of three components becomes a ds_read_b96, 8 LDS cycles)
+                    const VF4 c4 = *(const volatile __attribute__((address_space(3))) VF4*)(&r_q[ci]);
+                    d0 = c4.x;
+                    d1 = c4.y;
+                    d2 = c4.z;
+                } else {
+                    const float2 dxy = r_xy[ci];
+                    d0 = dxy.x;
+                    d1 = dxy.y;
+                    d2 = r_z[ci];
+                }
                 const AxisTap tx = axis_tap(__fadd_rn(linx, d0), vol.W);
                 const AxisTap ty = axis_tap(__fadd_rn(liny, d1), vol.H);
                 const AxisTap tz = axis_tap(__fadd_rn(linz, d2), vol.D);
@@ -1536,15 +1563,24 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
 #pragma unroll
                             for (int cx = 0; cx < 2; ++cx) {
                                 const float w = __fmul_rn(wxy[cy][cx], cz ? tz.w1 : tz.w0);
+                                float2 t2;
+                                float t1;
+                                if (REC16) {
+                                    typedef float VF4 __attribute__((ext_vector_type(4)));
+                                    const VF4 tv = *(const volatile __attribute__((address_space(3))) VF4*)(&r_q[bs + cy * PITCH + cx]);
+                                    t2 = make_float2(tv.x, tv.y);
+                                    t1 = tv.z;
+                                } else {
 #if IRS_FWD_TAPS == 1
-                                typedef float VF2 __attribute__((ext_vector_type(2)));
-                                const VF2 tv = *(const volatile __attribute__((address_space(3))) VF2*)(&r_xy[bs + cy * PITCH + cx]);
-                                const float2 t2 = make_float2(tv.x, tv.y);
-                                const float t1 = *(const volatile __attribute__((address_space(3))) float*)(&r_z[bs + cy * PITCH + cx]);
+                                    typedef float VF2 __attribute__((ext_vector_type(2)));
+                                    const VF2 tv = *(const volatile __attribute__((address_space(3))) VF2*)(&r_xy[bs + cy * PITCH + cx]);
+                                    t2 = make_float2(tv.x, tv.y);
+                                    t1 = *(const volatile __attribute__((address_space(3))) float*)(&r_z[bs + cy * PITCH + cx]);
 #else
-                                const float2 t2 = r_xy[bs + cy * PITCH + cx];
-                                const float t1 = r_z[bs + cy * PITCH + cx];
+                                    t2 = r_xy[bs + cy * PITCH + cx];
+                                    t1 = r_z[bs + cy * PITCH + cx];
 #endif
+                                }
 #if IRS_FWD_FMA
                                 a0 = fmaf(t2.x, w, a0);
                                 a1 = fmaf(t2.y, w, a1);
@@ -1603,6 +1639,7 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
             IRS_TR(5);
             ++trace_it;
 #endif
+            if (NS == M::NP) __syncthreads();  // (a ring without the spare slot: the next commit overwrites the oldest plane of this step)
         }
     }
 #ifdef IRS_FWD_TRACE
