@@ -438,9 +438,13 @@ def main():
                         rounds=[[e['kind'][0] + str(e['stage']), e['k'], e['width'], e['handover_us'], e['stall_us']] for e in entries])
         except Exception as e:  # noqa: BLE001  (a diagnostic must not cost the measurement)
             mine['timeline_error'] = f'{type(e).__name__}: {e}'
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
-        slab_diag = gathered
+        try:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)   # (nccl backend: staged through the current device, set above)
+            slab_diag = gathered
+        except Exception as e:  # noqa: BLE001  (a diagnostic must not cost the measurement: rank 0 then reports itself only)
+            mine['gather_error'] = f'{type(e).__name__}: {e}'
+            slab_diag = [mine]
 
     # ---- side measurements on rank 0 (outside the timed region) ------------------------------------------------------------
     extras = {}
@@ -544,7 +548,7 @@ def main():
                                                          'all': [round(d['ms_per_transition'], 4) for d in slab_diag]},
                            # per rank, one sampled transition: [kind + stage ('e' exchange of buffer IRS_SB_*, 'a' all-reduce IRS_AR_*), adjoint step,
                            # ghost planes, hand-over us on the communication stream, stall us of the compute stream]
-                           'round_wait_us': [{k: d.get(k) for k in ('rank', 'transition_us', 'handover_us', 'stall_us', 'rounds', 'timeline_error') if k in d} for d in slab_diag]}
+                           'round_wait_us': [{k: d.get(k) for k in ('rank', 'transition_us', 'handover_us', 'stall_us', 'rounds', 'timeline_error', 'gather_error') if k in d} for d in slab_diag]}
         if world == 1 and not args.no_extras:
             also = {}
             print('[bench] extras: SSD, displaced start, 128^3, sustained run ...', file=sys.stderr, flush=True)
