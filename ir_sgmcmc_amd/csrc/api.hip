@@ -65,6 +65,7 @@ static Knobs knobs_from_env() {
     k.slab_force_h = env_or("IRS_SLAB_FORCE_H", k.slab_force_h);
     k.launch_log = env_or("IRS_LAUNCH_LOG", k.launch_log);
     k.chain_overlap = env_or("IRS_CHAIN_OVERLAP", k.chain_overlap);
+    k.data_batch = env_or("IRS_DATA_BATCH", k.data_batch);
     return k;
 }
 
@@ -113,7 +114,7 @@ int knob_set(Knobs& k, const char* name, int value, bool on_context) {
     static const Entry table[] = {
         {"predict_variants", &Knobs::predict_variants, KN_CTX}, {"run_ahead", &Knobs::run_ahead, KN_CTX}, {"fuse_warp_bwd", &Knobs::fuse_warp_bwd, KN_CTX},
         {"energy_in_update", &Knobs::energy_in_update, KN_CTX}, {"fuse_noise", &Knobs::fuse_noise, KN_CTX}, {"recover", &Knobs::recover, KN_CTX},
-        {"chain_overlap", &Knobs::chain_overlap, KN_CTX}, {"slab_split", &Knobs::slab_split, KN_CTX}, {"slab_buffers", &Knobs::slab_buffers, KN_CTX}, {"slab_exact", &Knobs::slab_exact, KN_CTX}, {"slab_force_h", &Knobs::slab_force_h, KN_CTX},
+        {"chain_overlap", &Knobs::chain_overlap, KN_CTX}, {"data_batch", &Knobs::data_batch, KN_CTX}, {"slab_split", &Knobs::slab_split, KN_CTX}, {"slab_buffers", &Knobs::slab_buffers, KN_CTX}, {"slab_exact", &Knobs::slab_exact, KN_CTX}, {"slab_force_h", &Knobs::slab_force_h, KN_CTX},
         {"fwd_rows1", &Knobs::fwd_rows1, KN_GLOBAL}, {"coarse_box", &Knobs::coarse_box, KN_GLOBAL}, {"lds_from", &Knobs::lds_from, KN_GLOBAL},
         {"fwd_pf", &Knobs::fwd_pf, KN_GLOBAL}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1, KN_GLOBAL}, {"sobolev_tile", &Knobs::sobolev_tile, KN_GLOBAL},
         {"march_seg", &Knobs::march_seg, KN_GLOBAL}, {"march_seg_fwd", &Knobs::march_seg_fwd, KN_GLOBAL}, {"swz_run", &Knobs::swz_run, KN_GLOBAL},
@@ -557,7 +558,11 @@ int irs::create_ctx(const irs_config* cfg, const SlabInfo* sl, irs_ctx** out) {
         const size_t planes = (size_t)(c->vol.V / ((int64_t)H * W)), g1 = c->volv.H, g2 = c->volv.W;
         ffd_tmp = sizeof(float) * (size_t)C * 3 * planes * ((size_t)g1 * g2 + (size_t)H * g2 + (size_t)H * W);
     }
-    c->nll_blocks = data_bwd_blocks(cfg->data_loss, c->vol);
+    // several chains in one (unsharded) engine: their data terms run as ONE launch (transition: `data_batch`), so the segment length
+    // is the one that fits ALL chains into a resident set -- at 128^3, C = 2: 7-plane segments, 1216 workgroups of 11 plane steps in
+    // one round instead of two launches of 1024 with 8 each
+    c->nll_seg_C = (C > 1 && !sl && cfg->data_loss == IRS_DATA_GMM_LCC && c->kn.data_batch != 0) ? C : 1;
+    c->nll_blocks = data_bwd_blocks(cfg->data_loss, c->vol, c->nll_seg_C);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o_steps = take(fieldI * cfg->no_steps);
@@ -921,14 +926,21 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
     // side stream, the next chain's scalar stage waits for it.  Same kernels, same inputs, same order of every sum: chains
     // bit-identical (tests/test_gpu_transition.py).  Measured SLOWER than the serial form (the two half-filled launches get in each
     // other's way and every chain pays two event hand-overs; profiles/r05_chain_overlap_ab.txt): off by default.
+    //
+    // `data_batch` (default): what the data term of chain c needs from the mixture are 2K derived constants -- chain c's scalar stage
+    // leaves a snapshot of them (DevState::snapA), the serial loop is then statistics -> step only, and the data terms of ALL chains
+    // run as one launch behind it (grid.z = segments x C: one launch that fills the chip instead of C half-filled ones, C - 1 launch
+    // gaps less).  Same kernel arithmetic on the same values, same partial-sum slots: chains bit-identical to the serial form.
     const int sb = stats_blocks(vol);
     const bool overlap = C > 1 && c->side && c->kn.chain_overlap != 0;
+    const bool batch = C > 1 && !overlap && cfg.data_loss == IRS_DATA_GMM_LCC && c->kn.data_batch != 0;
     for (int ch = 0; ch < C; ++ch) {
         const uint8_t* mask = io->mask + (io->mask_chains == 1 ? 0 : (int64_t)ch * vol.V);
         const float* zc = z + (int64_t)ch * vol.V;
         launch_stats(cfg.virtual_decimation, zc, mask, c->state, c->stat_partials, vol, st, c->dcfg.K);
         if (overlap && ch > 0) HIP_TRY(hipStreamWaitEvent(st, c->ev_side[2 * (ch - 1) + 1], 0));  // data term of chain ch - 1 has read the mixture
-        launch_chain_scalar(c->state, c->stat_partials, sb, ch, ch == 0 ? 7 : 3, c->dcfg, st, vd);  // chain 0: + the verdict
+        launch_chain_scalar(c->state, c->stat_partials, sb, ch, (ch == 0 ? 7 : 3) | (batch ? 8 : 0), c->dcfg, st, vd);  // chain 0: + the verdict
+        if (batch) continue;
         const float* f = cfg.data_loss == IRS_DATA_GMM_LCC ? c->fhat + (c->fhat_chains == 1 ? 0 : (int64_t)ch * vol.V) : nullptr;
         hipStream_t ds = st;
         if (overlap && ch + 1 < C) {  // (the last chain's data term has nothing to overlap with: it stays on the caller's stream)
@@ -937,9 +949,12 @@ static int enqueue_transition(irs_ctx* c, const irs_io* io, hipStream_t st, int 
             ds = c->side;
         }
         launch_data_bwd(cfg.data_loss, f, 0, zc, c->sigM + (int64_t)ch * vol.V, mask, 0, nullptr, c->state, ch,
-                        c->gM + (int64_t)ch * vol.V, c->nll_partials + (int64_t)ch * c->nll_blocks, cfg.lcc_s, 1, vol, ds);
+                        c->gM + (int64_t)ch * vol.V, c->nll_partials + (int64_t)ch * c->nll_blocks, cfg.lcc_s, 1, vol, ds, c->nll_seg_C);
         if (ds != st) HIP_TRY(hipEventRecord(c->ev_side[2 * ch + 1], c->side));
     }
+    if (batch)
+        launch_data_bwd(cfg.data_loss, c->fhat, c->fhat_chains == 1 ? 0 : vol.V, z, c->sigM, io->mask, io->mask_chains == 1 ? 0 : vol.V, nullptr,
+                        c->state, 0, c->gM, c->nll_partials, cfg.lcc_s, C, vol, st, c->nll_seg_C);
     // back through the warp and the squaring steps
     if (!fuse_warp_bwd)
         launch_warp_bwd(io->moving_im, io->moving_chains == 1 ? 0 : vol.V, d_last, io->unif,

@@ -101,6 +101,7 @@ struct Knobs {
     int slab_split = 1;        // IRS_SLAB_SPLIT        interior / boundary split around an exchange
     int slab_exact = 0;        // IRS_SLAB_EXACT        every transition in measuring mode
     int slab_force_h = 0;      // IRS_SLAB_FORCE_H      test hook: a deliberately wrong ghost-width plan
+    int data_batch = 1;        // IRS_DATA_BATCH        C > 1, GMM / LCC: the data terms of all chains in ONE launch behind the serial statistics -> step loop
     int chain_overlap = 0;     // IRS_CHAIN_OVERLAP     C > 1: data term of chain c on a side stream, overlapping the statistics of chain c + 1
                                //                       (round 5, asked for; measured SLOWER: 0.728 against 0.711 ms per chain-transition at 128^3
                                //                       C = 2, 1.931 against 1.917 at 192^3, three alternating runs -- off; read when a context is created)
@@ -127,12 +128,16 @@ inline int pick_seg_len(int nz, int64_t tiles_per_layer, int min_len, int forced
 // The power-of-two rule above can land badly on sizes that are not powers of two: two chains at 192^3 are 1728 adjoint workgroups
 // of 34 plane steps on 1024 slots (two rounds, the second 70 % full) where 7 segments of 28 planes are 2016 workgroups of 30 steps
 // -- config 5 runs 454 -> 474 samples/s.  At 256^3, 128^3 and on a slab rank of eight the two rules agree or measure the same.
-inline int pick_seg_len_fit(int nz, int nzb, int64_t tiles_per_layer, int min_len, int run_in, int64_t resident, int forced) {
+// `max_len` > 32 (the adjoint squaring step, round 5): 256 x 256 tiles in-plane are two rounds of 34 plane steps with 32-plane segments
+// and ONE round of 66 with 64-plane ones -- 4.43-4.51 -> 4.38-4.41 ms per transition at 256^3 (profiles/r05_bwd_long_seg_sweep.txt;
+// the forward step, whose 32-plane launch is one round already, is slower with longer segments)
+inline int pick_seg_len_fit(int nz, int nzb, int64_t tiles_per_layer, int min_len, int run_in, int64_t resident, int forced,
+                            int max_len = 32) {
     if (forced > 0) return forced;
     const int longest = nz > nzb ? nz : nzb;
     int best = 32;
     int64_t best_cost = -1;
-    for (int len = 32; len >= min_len; --len) {
+    for (int len = max_len; len >= min_len; --len) {
         if (len > longest && len != 32) continue;
         const int64_t nseg = (nz + len - 1) / len + (nzb + len - 1) / len;
         const int64_t rounds = (tiles_per_layer * nseg + resident - 1) / resident;

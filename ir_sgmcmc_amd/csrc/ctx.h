@@ -63,6 +63,7 @@ struct irs_ctx {
     int fhat_chains;
     bool fixed_set;
     int nll_blocks;
+    int nll_seg_C;  // chains the data term's segment length (and so nll_blocks) was chosen for: C with `data_batch`, else 1
     hipEvent_t ev[8];
     hipEvent_t ev_bwd[64];
     hipEvent_t ra_ev[4];     // end of the last transitions: bounds how far the host may run ahead of the device

@@ -33,24 +33,22 @@ __global__ __launch_bounds__(kBlock) void ssd_bwd_kernel(const float* __restrict
     if (threadIdx.x == 0) nll_out[blockIdx.x] = acc[0];
 }
 
-int data_bwd_blocks(int mode, Vol vol) {
+int data_bwd_blocks(int mode, Vol vol, int seg_C) {
     if (mode == IRS_DATA_SSD) return stats_blocks(vol);
-    return lcc_data_bwd_march_blocks(vol);
+    return lcc_data_bwd_march_blocks(vol, seg_C);
 }
 
 void launch_data_bwd(int mode, const float* fhat_or_fixed, int64_t f_stride, const float* z, const float* sigma_m,
                      const uint8_t* mask, int64_t mask_stride, const float* g_z_override, const void* dev_state,
-                     int chain, float* g_warped, double* nll_partials, int s, int C_launch, Vol vol, hipStream_t st) {
-    (void)f_stride;
-    (void)mask_stride;
-    (void)C_launch;
+                     int chain, float* g_warped, double* nll_partials, int s, int C_launch, Vol vol, hipStream_t st, int seg_C) {
     const DevState* state = (const DevState*)dev_state;
     if (mode == IRS_DATA_SSD) {
         hipLaunchKernelGGL(ssd_bwd_kernel, dim3(stats_blocks(vol)), dim3(kBlock), 0, st, z, mask, state, chain, g_warped,
                            nll_partials, vol);
         return;
     }
-    launch_lcc_data_bwd_march(fhat_or_fixed, z, sigma_m, mask, g_z_override, dev_state, chain, g_warped, nll_partials, s, vol, st);
+    launch_lcc_data_bwd_march(fhat_or_fixed, z, sigma_m, mask, g_z_override, dev_state, chain, g_warped, nll_partials, s, vol, st,
+                              C_launch > 1 ? C_launch : 0, f_stride, mask_stride, seg_C);
 }
 
 int stats_blocks(Vol vol) {

@@ -1264,6 +1264,9 @@ __global__ __launch_bounds__(kMarchBlock, R == 1 ? IRS_MARCH_WAVES : IRS_MARCH_W
 }
 
 
+#ifndef IRS_BWD_MAX_SEG
+#define IRS_BWD_MAX_SEG 64  // longest z-segment the resident-set rule may give the adjoint step (common.h: pick_seg_len_fit)
+#endif
 constexpr int kRareGrid = 256 * IRS_MARCH_WAVES_R2;  // persistent grid of the rarely selected radius-2 variant (what the chip holds at once)
 
 
@@ -1276,7 +1279,7 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
     if (global_knobs().seg_fit && seg_env <= 0) {
         static int cache = 0;
         const int64_t res = resident_blocks((const void*)exp_bwd_march_kernel<false, 1>, kMarchBlock, &cache);
-        if (res > 0) seg_len = pick_seg_len_fit(vol.nz, vol.nzb, per_layer, 8, 2, res, 0);
+        if (res > 0) seg_len = pick_seg_len_fit(vol.nz, vol.nzb, per_layer, 8, 2, res, 0, IRS_BWD_MAX_SEG);
     }
     const int nseg = vol_nseg(vol, seg_len);  // segments of both windows
     const dim3 tiles((vol.W + MTX - 1) / MTX, (vol.H + MTY - 1) / MTY, (unsigned)(nseg * C));
@@ -1685,6 +1688,9 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
 #ifndef IRS_FWD_WAVES
 #define IRS_FWD_WAVES 4
 #endif
+#ifndef IRS_FWD_SMALL_TILES
+#define IRS_FWD_SMALL_TILES 1024  // launches of at most this many tiles (power-of-two segment rule) take the one-row-per-thread kernel
+#endif
 template <bool PRESCALE, int R, int FROWS = FROWS_BIG, int PF = 1>
 __global__ __launch_bounds__(FTX * FTY / FROWS, R == 1 ? IRS_FWD_WAVES : 1) void exp_fwd_march_kernel(const float* __restrict__ din, float* __restrict__ dout,
                                                                   Vol vol, Lin lin, Scale3L sc,
@@ -1703,10 +1709,14 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
     const int seg_env = global_knobs().march_seg_fwd;
     const int64_t per_layer = (int64_t)((vol.W + FTX - 1) / FTX) * ((vol.H + FTY - 1) / FTY) * C;
     int seg_len = pick_seg_len(vol.nz + vol.nzb, per_layer, 8, seg_env);
-    // small launches (at most two workgroups of tiles per CU under the power-of-two rule): the radius-1 kernel with one output row
-    // per thread
+    // small launches (the power-of-two rule is down at its shortest segments and still has at most four workgroups of tiles per CU):
+    // the radius-1 kernel with one output row per thread -- 512 threads per tile, so a resident set is 512 tiles and the fitted
+    // segments come out twice as long (two chains at 128^3: 512 workgroups of 18 plane steps instead of 1024 of 10, the run-in a
+    // ninth instead of a fifth of the march: 0.699 -> 0.686 ms per chain-transition; up to 640 tiles until round 5).  Not beyond
+    // 8-plane segments: four chains at 128^3 are 1024 tiles of 16 planes, and 512 workgroups of 34 steps are SLOWER there than 1024
+    // of 18 (0.632 against 0.621) -- profiles/r05_fwd_small_tiles_ab.txt
     const int small_env = global_knobs().fwd_rows1;
-    const bool small = FROWS_BIG != 1 && (small_env >= 0 ? small_env != 0 : per_layer * vol_nseg(vol, seg_len) <= 640);
+    const bool small = FROWS_BIG != 1 && (small_env >= 0 ? small_env != 0 : seg_len <= 8 && per_layer * vol_nseg(vol, seg_len) <= IRS_FWD_SMALL_TILES);
     if (global_knobs().seg_fit && seg_env <= 0) {
         static int cache_big = 0, cache_small = 0;
         const int64_t res = small ? resident_blocks((const void*)exp_fwd_march_kernel<false, 1, 1, 2>, FTX * FTY, &cache_small)

@@ -74,21 +74,25 @@ void launch_perturb_sobolev_march(const float* v, const float* sigma, const floa
 void launch_lcc_fwd_march(const float* fhat, int64_t fhat_stride, const float* im, float* z, float* sigma_out, int s, int C,
                     Vol vol, hipStream_t st);  // z-marching version (stencil_kernels.hip)
 struct GmmDev;  // device-side mixture parameters (scalar_kernels.hip)
-// data term + its gradient w.r.t. the warped image (LCC adjoint fused); mode: IRS_DATA_*
+// data term + its gradient w.r.t. the warped image (LCC adjoint fused); mode: IRS_DATA_*.  C_launch > 1 (GMM / LCC only): that many
+// chains from `chain` on in one launch -- z, sigma_m, g_warped and the partial sums at their chain offsets, fhat / mask every
+// f_stride / mask_stride elements, the mixture of each chain from its snapshot (scalar_kernels.h: DevState::snapA)
 void launch_data_bwd(int mode, const float* fhat_or_fixed, int64_t f_stride, const float* z, const float* sigma_m,
                      const uint8_t* mask, int64_t mask_stride, const float* g_z_override, const void* dev_state,
-                     int chain, float* g_warped, double* nll_partials, int s, int C_launch, Vol vol, hipStream_t st);
+                     int chain, float* g_warped, double* nll_partials, int s, int C_launch, Vol vol, hipStream_t st, int seg_C = 1);
 // K: number of mixture components if the caller knows it (selects the K <= 4 build of the kernel), 0 = unknown
 void launch_stats(int want_vd, const float* z, const uint8_t* mask, const void* dev_state, double* partials, Vol vol,
                   hipStream_t st, int K = 0);
 void launch_residual_ssd(const float* fixed, int64_t f_stride, const float* warped, float* z, int C, Vol vol,
                          hipStream_t st);
 // z-marching fused data-term backward (stencil_kernels.hip)
-int lcc_data_bwd_march_blocks(Vol vol);
+// seg_C: chains the segment length is chosen for (1: a launch per chain; C: all chains in one launch -- longer segments, one resident set)
+int lcc_data_bwd_march_blocks(Vol vol, int seg_C = 1);
 void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* sigma_m, const uint8_t* mask,
                                const float* g_z_override, const void* dev_state, int chain, float* g_warped,
-                               double* nll_partials, int s, Vol vol, hipStream_t st);
-int data_bwd_blocks(int mode, Vol vol);
+                               double* nll_partials, int s, Vol vol, hipStream_t st, int batch = 0, int64_t f_stride = 0,
+                               int64_t m_stride = 0, int seg_C = 1);  // batch > 0: chains chain .. chain + batch - 1 in one launch, each against its snapshot
+int data_bwd_blocks(int mode, Vol vol, int seg_C = 1);
 void launch_masked_moments(const float* z, const uint8_t* mask, double* partials, Vol vol, hipStream_t st);
 void launch_reg_energy(const float* v, double* partials, int C, Vol vol, hipStream_t st);
 void launch_reduce_partials(const double* partials, int nblocks, int nvals, double* out, hipStream_t st);

@@ -25,6 +25,10 @@ struct DevState {
     unsigned bad_now;             // verdict about the transition in flight (Verdict below), written by the first scalar stage
     unsigned fails;               // transitions that ended as no-ops because an assumption about max|d_k| did not hold
     const unsigned* comm_err;     // slab over the peer-mapped transport: its sticky device error word (ipc.hip), else nullptr
+    // the derived mixture constants as chain c's GMM step left them (chain_scalar_kernel, op bit 3): the data terms of ALL chains then
+    // run as one launch after the serial statistics -> step loop, each chain against its own snapshot (api.hip: data_batch)
+    float snapA[IRS_MAX_CHAINS][IRS_MAX_COMPONENTS];
+    float snap_inv_var[IRS_MAX_CHAINS][IRS_MAX_COMPONENTS];
 };
 
 // A wait of the peer-mapped transport timed out (a peer is gone or late beyond IRS_IPC_TIMEOUT_S): whatever the exchanges after it
@@ -91,8 +95,10 @@ struct MixEval {
 
 // KMAX: compile-time bound of the component loops (the caller knows K <= KMAX): the arrays of a K = 4 mixture then take 4
 // registers each instead of IRS_MAX_COMPONENTS
+// mixA / mix_iv: the constants A_k and 1 / sigma_k^2 to evaluate with (DevState::A / inv_var, or a chain's snapshot of them)
 template <bool WANT_RESP, int KMAX = IRS_MAX_COMPONENTS>
-__device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict__ s, float* resp, float* q) {
+__device__ __forceinline__ MixEval mix_eval_with(float z, const DevState* __restrict__ s, const float* __restrict__ mixA,
+                                                 const float* __restrict__ mix_iv, float* resp, float* q) {
     MixEval e;
     if (s->mode == IRS_DATA_SSD) {
         const float u = z * s->ssd_inv_sigma;
@@ -108,8 +114,8 @@ __device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict_
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
-            qq[k] = z2 * s->inv_var[k];  // (z / sigma_k)^2 with the square of z shared by the components
-            t[k] = fmaf(-0.5f, qq[k], s->A[k]);
+            qq[k] = z2 * mix_iv[k];  // (z / sigma_k)^2 with the square of z shared by the components
+            t[k] = fmaf(-0.5f, qq[k], mixA[k]);
             m = fmaxf(m, t[k]);
         }
     }
@@ -130,7 +136,7 @@ __device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict_
         if (k < K) {
             const float r = t[k] * inv;
             e.x += r * qq[k];
-            gs += r * s->inv_var[k];
+            gs += r * mix_iv[k];
             if (WANT_RESP) {
                 resp[k] = r;
                 q[k] = qq[k];
@@ -140,10 +146,15 @@ __device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict_
     e.gz = z * gs;
     return e;
 }
+template <bool WANT_RESP, int KMAX = IRS_MAX_COMPONENTS>
+__device__ __forceinline__ MixEval mix_eval(float z, const DevState* __restrict__ s, float* resp, float* q) {
+    return mix_eval_with<WANT_RESP, KMAX>(z, s, s->A, s->inv_var, resp, q);
+}
 
 void launch_refresh_derived(DevState* s, DevCfg cfg, hipStream_t st);
 // op bit 0: recompute the VD factor alpha; bit 1: take one GMM Adam step (with the stored alpha); bit 2: evaluate the verdict
-// about the transition in flight into DevState::bad_now (the first scalar stage of a transition; the others read it)
+// about the transition in flight into DevState::bad_now (the first scalar stage of a transition; the others read it); bit 3: leave
+// a snapshot of the mixture constants for this chain's data term (DevState::snapA)
 void launch_chain_scalar(DevState* s, const double* stat_partials, int nblocks, int chain, int op, DevCfg cfg,
                          hipStream_t st, Verdict vd = no_verdict());
 void launch_reg_scalar(DevState* s, const double* energy_partials, int nblocks, DevCfg cfg, hipStream_t st,

@@ -173,7 +173,13 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
     }
     __syncthreads();
     IRS_ST(3);
-    if (!(cfg.mode == IRS_DATA_GMM_LCC && (op & 2)) || bad) return;
+    if (!(cfg.mode == IRS_DATA_GMM_LCC && (op & 2)) || bad) {
+        if ((op & 8) && (int)threadIdx.x < cfg.K) {  // no step: the snapshot is the mixture as it stands
+            s->snapA[chain][threadIdx.x] = s->A[threadIdx.x];
+            s->snap_inv_var[chain][threadIdx.x] = s->inv_var[threadIdx.x];
+        }
+        return;
+    }
     // one GMM Adam step (trainer.py:68-77), one lane per parameter: lanes 0 .. K-1 the log std, K .. 2K-1 the logits (the
     // fp64 pow / exp / sqrt of sixteen serial updates on one lane were 20 us of every transition)
     const int K = cfg.K;
@@ -229,6 +235,11 @@ __global__ __launch_bounds__(kBlock) void chain_scalar_kernel(DevState* s, const
         s->st.gmm_adam_step[0] += 1;
         s->st.gmm_adam_step[1] += 1;
         refresh_derived(s, cfg);
+        if (op & 8)
+            for (int j = 0; j < K; ++j) {
+                s->snapA[chain][j] = s->A[j];
+                s->snap_inv_var[chain][j] = s->inv_var[j];
+            }
     }
     IRS_ST(5);
 }

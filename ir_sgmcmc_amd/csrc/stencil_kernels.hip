@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __
 // still beat 16 and 32
 template <int S, bool G>
 __global__ void lcc_data_bwd_march_kernel(const float*, const float*, const float*, const uint8_t*, const float*, const DevState*, int,
-                                          float*, double*, Vol, int, int);
+                                          float*, double*, Vol, int, int, int, int64_t, int64_t);
 static int lcc_seg_len(Vol vol, int C, bool bwd) {
     const int seg_env = global_knobs().lcc_seg;
     const int64_t per_layer = (int64_t)((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * C;
@@ -725,7 +725,8 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
                                                                       const float* __restrict__ gz_in,
                                                                       const DevState* __restrict__ state, int chain,
                                                                       float* __restrict__ g_m, double* __restrict__ nll_out,
-                                                                      Vol vol, int seg_len, int nseg) {
+                                                                      Vol vol, int seg_len, int nseg, int batch,
+                                                                      int64_t f_stride, int64_t m_stride) {
     constexpr int NT = 2 * S + 1, NS1 = S + 1, NS2 = S + 2;
     constexpr int AX = LMX + 4 * S, AY = LMY + 4 * S, AN = AX * AY, NITA = (AN + kStBlock - 1) / kStBlock;
     constexpr int BX = LMX + 2 * S, BY = LMY + 2 * S, BN = BX * BY, NITB = (BN + kStBlock - 1) / kStBlock;
@@ -735,7 +736,24 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
     __shared__ double red[kStBlock / kWave];
 
     const Blk3 blk = swizzled_block();
-    const int seg = blk.z;
+    int seg = blk.z;
+    // `batch` chains in one launch (grid.z = nseg x batch, chain-major): chain `chain + cl` against the snapshot its GMM step left
+    // (scalar_kernels.h: DevState::snapA), planes and partial sums at its chain offset -- the same values, sums and slots as `batch`
+    // launches of one chain each, every one right behind its chain's step
+    const float* mixA = state->A;
+    const float* mix_iv = state->inv_var;
+    if (!EXPLICIT_GZ && batch > 0) {
+        const int cl = blk.z / nseg;
+        seg = blk.z - cl * nseg;
+        chain += cl;
+        fhat += cl * f_stride;
+        mask += cl * m_stride;
+        z += cl * vol.V;
+        sigma_m += cl * vol.V;
+        g_m += cl * vol.V;
+        mixA = state->snapA[chain];
+        mix_iv = state->snap_inv_var[chain];
+    }
     const int ox = blk.x * LMX, oy = blk.y * LMY;
     const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
     const int64_t HW = (int64_t)vol.H * vol.W;
@@ -829,7 +847,8 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
                     gzv = 0.0f;
                     if (pm[it]) {
                         // (uniform branch: the component loops of a K <= 4 mixture are half as long)
-                        const MixEval e = k_le4 ? mix_eval<false, 4>(zz, state, nullptr, nullptr) : mix_eval<false>(zz, state, nullptr, nullptr);
+                        const MixEval e = k_le4 ? mix_eval_with<false, 4>(zz, state, mixA, mix_iv, nullptr, nullptr)
+                                                 : mix_eval_with<false>(zz, state, mixA, mix_iv, nullptr, nullptr);
                         gzv = alpha * e.gz;
                         if (acentre[it] && pin >= z0 && pin < z1) nll += (double)e.nll;
                     }
@@ -913,29 +932,34 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
     }
 }
 
-int lcc_data_bwd_march_blocks(Vol vol) {
-    const int seg_len = lcc_seg_len(vol, 1, true);
+int lcc_data_bwd_march_blocks(Vol vol, int seg_C) {
+    const int seg_len = lcc_seg_len(vol, seg_C, true);
     return ((vol.W + LMX - 1) / LMX) * ((vol.H + LMY - 1) / LMY) * ((vol.nz + seg_len - 1) / seg_len);
 }
 
 void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* sigma_m, const uint8_t* mask,
                                const float* g_z_override, const void* dev_state, int chain, float* g_warped,
-                               double* nll_partials, int s, Vol vol, hipStream_t st) {
-    const int seg_len = lcc_seg_len(vol, 1, true);
+                               double* nll_partials, int s, Vol vol, hipStream_t st, int batch, int64_t f_stride,
+                               int64_t m_stride, int seg_C) {
+    // the segment length is the one the context sized its partial sums for (lcc_data_bwd_march_blocks), whether the chains come in
+    // one launch or one by one: the sums keep their slots and their order
+    const int seg_len = lcc_seg_len(vol, seg_C, true);
     const int nseg = (vol.nz + seg_len - 1) / seg_len;
-    const dim3 grid((vol.W + LMX - 1) / LMX, (vol.H + LMY - 1) / LMY, (unsigned)nseg);
+    if (g_z_override) batch = 0;
+    const dim3 grid((vol.W + LMX - 1) / LMX, (vol.H + LMY - 1) / LMY, (unsigned)(nseg * (batch > 0 ? batch : 1)));
     const DevState* state = (const DevState*)dev_state;
     if (global_knobs().launch_log) {
         static int cache_l = 0;
-        log_launch("lcc_data_bwd_march_kernel (per chain)", LMX, LMY, (int64_t)grid.x * grid.y * grid.z, kStBlock, seg_len, 4 * s, vol.nz, 1,
+        log_launch(batch > 0 ? "lcc_data_bwd_march_kernel (all chains)" : "lcc_data_bwd_march_kernel (per chain)", LMX, LMY,
+                   (int64_t)grid.x * grid.y * grid.z, kStBlock, seg_len, 4 * s, vol.nz, batch > 0 ? batch : 1,
                    resident_blocks((const void*)lcc_data_bwd_march_kernel<1, false>, kStBlock, &cache_l));
     }
 #define IRS_LCC_BWD(SS)                                                                                                      \
     if (g_z_override) hipLaunchKernelGGL((lcc_data_bwd_march_kernel<SS, true>), grid, dim3(kStBlock), 0, st, fhat, z,       \
                                          sigma_m, mask, g_z_override, state, chain, g_warped, nll_partials, vol, seg_len,   \
-                                         nseg);                                                                             \
+                                         nseg, batch, f_stride, m_stride);                                                  \
     else hipLaunchKernelGGL((lcc_data_bwd_march_kernel<SS, false>), grid, dim3(kStBlock), 0, st, fhat, z, sigma_m, mask,    \
-                            g_z_override, state, chain, g_warped, nll_partials, vol, seg_len, nseg);
+                            g_z_override, state, chain, g_warped, nll_partials, vol, seg_len, nseg, batch, f_stride, m_stride);
     if (s == 1) { IRS_LCC_BWD(1) } else { IRS_LCC_BWD(2) }
 #undef IRS_LCC_BWD
 }

@@ -415,6 +415,40 @@ def test_variant_prediction_never_changes_the_result(amp):
             assert torch.equal(res[mode][i], res[0][i]), (mode, what, float((res[mode][i] - res[0][i]).abs().max()))
 
 
+@pytest.mark.parametrize('N,C,kw', [(28, 3, {}), (40, 2, {'lcc_s': 2}), (33, 4, {'virtual_decimation': False})])
+def test_one_data_term_launch_for_all_chains_is_the_serial_chain(N, C, kw):
+    """Several chains in one engine (every reference config runs two; trainer.py:316-330 steps the shared mixture chain after chain
+    and evaluates each chain's data term with the mixture ITS step left).  By default the serial loop is statistics -> step only,
+    every step leaves a snapshot of the mixture constants, and the data terms of all chains run as ONE launch behind the loop, each
+    chain against its snapshot (csrc/api.hip, `data_batch`).  Same arithmetic on the same values, same partial-sum slots: bit for
+    bit the chain of the serial form (`data_batch` 0) -- velocity, mixture and optimiser state, loss terms."""
+    from ir_sgmcmc_amd.data_loader import synthetic_pair
+    f1, m1 = synthetic_pair((N, N, N), seed=3)
+    fixed = to_dev({k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'})
+    moving = to_dev({k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'})
+    g = torch.Generator().manual_seed(12)
+    v0 = (2.0 * torch.randn(C, 3, N, N, N, generator=g)).to(DEV)
+    res = {}
+    for mode in (1, 0):
+        eng = TransitionEngine(EngineConfig(dims=(N, N, N), no_chains=C, data_loss='GMM', seed=6, **kw), DEV)
+        eng.option('data_batch', mode)
+        fd, md = eng.prepare(fixed, moving)
+        eng.gmm_init(fd, md)
+        v = v0.clone()
+        sc = []
+        for _ in range(4):
+            eng.transition(fd, md, v)
+            sc.append(eng.scalars())
+        eng.flush()
+        torch.cuda.synchronize()
+        st = eng.state()
+        res[mode] = (v.clone(), (list(st.gmm_log_std), list(st.gmm_logits), [list(r) for r in st.gmm_adam_m], [list(r) for r in st.gmm_adam_v], list(st.reg_param)),
+                     [(list(s['alpha']), list(s['data_term']), list(s['reg_term'])) for s in sc])
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert all(len(set(x[1])) == C for x in res[1][2])    # (and the chains are C different chains)
+
+
 @pytest.mark.parametrize('data_loss', ['GMM', 'SSD'])
 def test_chain_overlap_never_changes_the_result(data_loss):
     """Several chains in one engine (every reference config runs two): the data term of chain c runs on a side stream while the

@@ -1,5 +1,5 @@
 """The shape of every marching launch of one transition -- workgroups, threads, segment length, run-in planes, plane steps per
-workgroup, workgroups the chip holds at once, rounds -- at 256^3, at 128^3 and for one rank of eight of a 256^3 slab run (32 owned
+workgroup, workgroups the chip holds at once, rounds -- at 256^3, at 128^3 (one and two chains) and for one rank of eight of a 256^3 slab run (32 owned
 planes of 256 x 256), as the launchers themselves report it under IRS_LAUNCH_LOG=1 (csrc/api.hip: log_launch).
 
     python tools/launch_shapes.py            # on the GPU box; writes gpurun_out/r05_launch_shapes.json and prints a table
@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     ('256^3', [sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-extras']),
     ('128^3', [sys.executable, 'bench.py', '--size', '128', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-extras']),
+    ('128^3, two chains', [sys.executable, 'tools/two_chain_run.py', '--steps', '2']),
     ('rank of 8 of 256^3', [sys.executable, 'tools/slab_probe.py', '--size', '256', '--worlds', '8']),
 ]
 
