@@ -1292,14 +1292,23 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
         log_launch("exp_bwd_march_kernel<R=1>", MTX, MTY, total, kMarchBlock, seg_len, 2, vol.nz + vol.nzb, C,
                    resident_blocks((const void*)exp_bwd_march_kernel<false, 1>, kMarchBlock, &cache_l));
     }
-#define IRS_BWM(P, RR, LO, GRID) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, seg_len, nseg, LO, r2_owns_rest ? 1 : 0, (GRID) == total ? swz_run : 0, tiles, gscale, lay)
-    const int rare = total < kRareGrid ? total : kRareGrid;
+#define IRS_BWM(P, RR, LO, GRID, SEG, NSEG, TILES, TOTAL) hipLaunchKernelGGL((exp_bwd_march_kernel<P, RR>), dim3(GRID), dim3(kMarchBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, SEG, NSEG, LO, r2_owns_rest ? 1 : 0, (GRID) == (TOTAL) ? swz_run : 0, TILES, gscale, lay)
     // the radius-1 kernel first (the one the roofline is quoted on: `after_primary` brackets exactly its launch), then the
     // rarely selected radius-2 variant on the small persistent grid
-    if (prescale_in) IRS_BWM(true, 1, 0, total); else IRS_BWM(false, 1, 0, total);
+    if (prescale_in) IRS_BWM(true, 1, 0, total, seg_len, nseg, tiles, total); else IRS_BWM(false, 1, 0, total, seg_len, nseg, tiles, total);
     if (after_primary) (void)hipEventRecord(after_primary, st);
     if (max_radius >= 2) {
-        if (prescale_in) IRS_BWM(true, 2, 1, rare); else IRS_BWM(false, 2, 1, rare);
+        // its own segments: the variant walks its tiles on a persistent grid of what the chip holds of IT (three workgroups per CU,
+        // four run-in planes), and a whole number of rounds of that grid is not the radius-1 kernel's (256^3: 6 segments of 43 planes
+        // = 1536 tiles, two rounds of 47 steps, instead of 2048 tiles of 36 in three)
+        int seg2 = seg_len;
+        if (global_knobs().seg_fit && seg_env <= 0)
+            seg2 = pick_seg_len_fit(vol.nz, vol.nzb, per_layer, 8, 4, kRareGrid, 0, IRS_BWD_MAX_SEG);
+        const int nseg2 = vol_nseg(vol, seg2);
+        const dim3 tiles2(tiles.x, tiles.y, (unsigned)(nseg2 * C));
+        const int total2 = (int)(tiles2.x * tiles2.y * tiles2.z);
+        const int rare = total2 < kRareGrid ? total2 : kRareGrid;
+        if (prescale_in) IRS_BWM(true, 2, 1, rare, seg2, nseg2, tiles2, total2); else IRS_BWM(false, 2, 1, rare, seg2, nseg2, tiles2, total2);
     }
 #undef IRS_BWM
 }
@@ -1737,12 +1746,29 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
                          : resident_blocks((const void*)exp_fwd_march_kernel<false, 1, FROWS_BIG, 1>, FTX * FTY / FROWS_BIG, &cache_lb));
     }
 #define IRS_FWM(P, RR, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, RR>), dim3(GRID), dim3(FTX * FTY / FROWS_BIG), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
-#define IRS_FW2(P, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 2, 1>), dim3(GRID), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, (GRID) == total ? swz_run : 0, tiles, lay)
+#define IRS_FWM2(P, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 2>), dim3(GRID), dim3(FTX * FTY / FROWS_BIG), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg2, nseg2, LO, HI, (GRID) == total2 ? swz_run : 0, tiles2, lay)
+#define IRS_FW2(P, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 2, 1>), dim3(GRID), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg2, nseg2, LO, HI, (GRID) == total2 ? swz_run : 0, tiles2, lay)
 #define IRS_FWS(P, LO, HI)                                                                                                      \
     if (global_knobs().fwd_pf >= 2) IRS_FWS_(P, 2, LO, HI);                                                                     \
     else IRS_FWS_(P, 1, LO, HI)
 #define IRS_FWS_(P, PFF, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 1, 1, PFF>), dim3(total), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run, tiles, lay)
-    const int rare = total < kRareGrid ? total : kRareGrid;
+    // the radius-2 variant's own segments (as for the adjoint): a persistent grid of what the chip holds of it, four run-in planes
+    const bool r2_rows1 = global_knobs().fwd_r2_rows1 != 0;
+    int seg2 = seg_len;
+    int64_t res2 = kRareGrid;
+    if (global_knobs().seg_fit && seg_env <= 0) {
+        static int cache_r2a = 0, cache_r2b = 0;
+        const int64_t r = r2_rows1 ? resident_blocks((const void*)exp_fwd_march_kernel<false, 2, 1>, FTX * FTY, &cache_r2a)
+                                   : resident_blocks((const void*)exp_fwd_march_kernel<false, 2>, FTX * FTY / FROWS_BIG, &cache_r2b);
+        if (r > 0) {
+            res2 = r;
+            seg2 = pick_seg_len_fit(vol.nz, vol.nzb, per_layer, 8, 4, res2, 0, 64);
+        }
+    }
+    const int nseg2 = vol_nseg(vol, seg2);
+    const dim3 tiles2(tiles.x, tiles.y, (unsigned)(nseg2 * C));
+    const int total2 = (int)(tiles2.x * tiles2.y * tiles2.z);
+    const int rare = total2 < res2 ? total2 : (int)res2;
     if (!dmax_in || only_r1) {  // no bound / predicted small: the radius-1 ring is correct for any displacement (far taps go to global memory)
         if (small) { if (prescale_in) IRS_FWS(true, -1, 1 << 30); else IRS_FWS(false, -1, 1 << 30); }
         else if (prescale_in) IRS_FWM(true, 1, -1, 1 << 30, total); else IRS_FWM(false, 1, -1, 1 << 30, total);
@@ -1751,8 +1777,9 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
         else if (prescale_in) IRS_FWM(true, 1, -1, 1, total); else IRS_FWM(false, 1, -1, 1, total);
         // radius-2 ring: 59 KB, two workgroups per CU -- with one output row per thread they are 16 waves instead of 8
         if (global_knobs().fwd_r2_rows1) { if (prescale_in) IRS_FW2(true, 1, 1 << 30, rare); else IRS_FW2(false, 1, 1 << 30, rare); }
-        else if (prescale_in) IRS_FWM(true, 2, 1, 1 << 30, rare); else IRS_FWM(false, 2, 1, 1 << 30, rare);
+        else if (prescale_in) IRS_FWM2(true, 1, 1 << 30, rare); else IRS_FWM2(false, 1, 1 << 30, rare);
     }
+#undef IRS_FWM2
 #undef IRS_FWS
 #undef IRS_FWS_
 #undef IRS_FW2

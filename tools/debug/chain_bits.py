@@ -10,14 +10,18 @@ from ir_sgmcmc_amd.data_loader import synthetic_pair
 from ir_sgmcmc_amd.engine import TransitionEngine
 
 dev = torch.device('cuda', 0)
-for N, loss, chains in ((48, 'gmm', 2), (64, 'ssd', 1), (128, 'gmm', 1)):
+CASES = [(48, 'gmm', 2, 0.0), (64, 'ssd', 1, 0.0), (128, 'gmm', 1, 0.0)]
+if os.environ.get('CHAIN_BITS_DISPLACED'):   # chains started several voxels away: the radius-2 and any-radius variants of the squaring steps
+    CASES += [(128, 'gmm', 1, 3.0), (256, 'gmm', 1, 6.0), (96, 'gmm', 2, 6.0)]
+for N, loss, chains, amp in CASES:
     f1, m1 = synthetic_pair((N, N, N), seed=0)
     eng = TransitionEngine(engine_config(N, loss, 1, chains=chains), dev)
     fd, md = eng.prepare({k: v.unsqueeze(0).to(dev) for k, v in f1.items() if k != 'seg'},
                          {k: v.unsqueeze(0).to(dev) for k, v in m1.items() if k != 'seg'})
     if loss == 'gmm':
         eng.gmm_init(fd, md)
-    v = torch.zeros(chains, 3, N, N, N, device=dev)
+    from bench import initial_velocity
+    v = initial_velocity('wave' if amp else 'identity', amp, N, dev).expand(chains, 3, N, N, N).contiguous()
     for _ in range(8):
         eng.transition(fd, md, v)
     eng.flush()
@@ -25,5 +29,5 @@ for N, loss, chains in ((48, 'gmm', 2), (64, 'ssd', 1), (128, 'gmm', 1)):
     st = eng.state()
     sc = eng.scalars()
     h = lambda b: hashlib.sha256(b).hexdigest()[:16]
-    print(N, loss, chains, 'v', h(v.cpu().numpy().tobytes()), 'state', h(bytes(st) if not isinstance(st, dict) else repr(sorted(st.items())).encode()),
+    print(N, loss, chains, 'amp', amp, 'v', h(v.cpu().numpy().tobytes()), 'state', h(bytes(st) if not isinstance(st, dict) else repr(sorted(st.items())).encode()),
           'scalars', h(bytes(sc) if not isinstance(sc, dict) else repr(sorted(sc.items())).encode()))

@@ -16,6 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--size', type=int, default=128)
 ap.add_argument('--chains', type=int, default=2)
 ap.add_argument('--steps', type=int, default=100)
+ap.add_argument('--init', default='identity', help="'wave': a chain started --amp voxels away (bench.py: initial_velocity)")
+ap.add_argument('--amp', type=float, default=0.0)
 a = ap.parse_args()
-r = bench.side_run(a.size, 'gmm', 'identity', 0.0, a.steps, 10, torch.device('cuda', 0), chains=a.chains)
+r = bench.side_run(a.size, 'gmm', a.init, a.amp, a.steps, 10, torch.device('cuda', 0), chains=a.chains)
 print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if not isinstance(v, (dict, list))})
