@@ -636,7 +636,7 @@ __global__ __launch_bounds__(kStBlock) void lcc_fwd_march_kernel(const float* __
 
 // the LCC kernels re-read 4S planes per segment; measured at 128^3: 8-plane segments (1.5x staging, 4x the workgroups)
 // still beat 16 and 32
-template <int S, bool G>
+template <int S, bool G, bool BATCH>
 __global__ void lcc_data_bwd_march_kernel(const float*, const float*, const float*, const uint8_t*, const float*, const DevState*, int,
                                           float*, double*, Vol, int, int, int, int64_t, int64_t);
 static int lcc_seg_len(Vol vol, int C, bool bwd) {
@@ -648,7 +648,7 @@ static int lcc_seg_len(Vol vol, int C, bool bwd) {
     // 192^3 data stage 0.267 -> 0.248 ms, 256^3 0.511 -> 0.496, 128^3 unchanged (the rule's 4-plane segments)
     if (global_knobs().seg_fit && seg_env <= 0) {
         static int cache_f = 0, cache_b = 0;
-        const int64_t res = bwd ? resident_blocks((const void*)lcc_data_bwd_march_kernel<1, false>, kStBlock, &cache_b)
+        const int64_t res = bwd ? resident_blocks((const void*)lcc_data_bwd_march_kernel<1, false, false>, kStBlock, &cache_b)
                                 : resident_blocks((const void*)lcc_fwd_march_kernel<1, true>, kStBlock, &cache_f);
         if (res > 0) len = pick_seg_len_fit(vol.nz, 0, per_layer, 4, 4, res, 0);
     }
@@ -717,7 +717,11 @@ __device__ __forceinline__ float adjoint_ring_sum(const float (&ring)[2 * S + 1]
     return acc;
 }
 
-template <int S, bool EXPLICIT_GZ>
+// BATCH: several chains in one launch.  A template parameter, not a run-time switch: with the mixture constants behind a pointer that
+// is one of two (DevState::A or a chain's snapshot) the compiler fetched them with vector loads inside the plane loop -- 132 global
+// loads instead of 24 in the kernel, 187 instead of 141 us at 256^3 with ONE chain; each instantiation reads its constants through
+// `state` directly and keeps the scalar loads
+template <int S, bool EXPLICIT_GZ, bool BATCH>
 __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const float* __restrict__ fhat,
                                                                       const float* __restrict__ z,
                                                                       const float* __restrict__ sigma_m,
@@ -740,10 +744,8 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
     // `batch` chains in one launch (grid.z = nseg x batch, chain-major): chain `chain + cl` against the snapshot its GMM step left
     // (scalar_kernels.h: DevState::snapA), planes and partial sums at its chain offset -- the same values, sums and slots as `batch`
     // launches of one chain each, every one right behind its chain's step
-    const float* mixA = state->A;
-    const float* mix_iv = state->inv_var;
-    if (!EXPLICIT_GZ && batch > 0) {
-        const int cl = blk.z / nseg;
+    if (BATCH) {
+        const int cl = __builtin_amdgcn_readfirstlane(blk.z / nseg);  // (uniform, but the quotient comes out of the vector ALU)
         seg = blk.z - cl * nseg;
         chain += cl;
         fhat += cl * f_stride;
@@ -751,9 +753,9 @@ __global__ __launch_bounds__(kStBlock) void lcc_data_bwd_march_kernel(const floa
         z += cl * vol.V;
         sigma_m += cl * vol.V;
         g_m += cl * vol.V;
-        mixA = state->snapA[chain];
-        mix_iv = state->snap_inv_var[chain];
     }
+    const float* __restrict__ mixA = BATCH ? state->snapA[chain] : state->A;
+    const float* __restrict__ mix_iv = BATCH ? state->snap_inv_var[chain] : state->inv_var;
     const int ox = blk.x * LMX, oy = blk.y * LMY;
     const int z0 = vol.z0 + seg * seg_len, z1 = min(z0 + seg_len, vol.z0 + vol.nz);
     const int64_t HW = (int64_t)vol.H * vol.W;
@@ -952,13 +954,15 @@ void launch_lcc_data_bwd_march(const float* fhat, const float* z, const float* s
         static int cache_l = 0;
         log_launch(batch > 0 ? "lcc_data_bwd_march_kernel (all chains)" : "lcc_data_bwd_march_kernel (per chain)", LMX, LMY,
                    (int64_t)grid.x * grid.y * grid.z, kStBlock, seg_len, 4 * s, vol.nz, batch > 0 ? batch : 1,
-                   resident_blocks((const void*)lcc_data_bwd_march_kernel<1, false>, kStBlock, &cache_l));
+                   resident_blocks((const void*)lcc_data_bwd_march_kernel<1, false, false>, kStBlock, &cache_l));
     }
 #define IRS_LCC_BWD(SS)                                                                                                      \
-    if (g_z_override) hipLaunchKernelGGL((lcc_data_bwd_march_kernel<SS, true>), grid, dim3(kStBlock), 0, st, fhat, z,       \
+    if (g_z_override) hipLaunchKernelGGL((lcc_data_bwd_march_kernel<SS, true, false>), grid, dim3(kStBlock), 0, st, fhat, z,       \
                                          sigma_m, mask, g_z_override, state, chain, g_warped, nll_partials, vol, seg_len,   \
                                          nseg, batch, f_stride, m_stride);                                                  \
-    else hipLaunchKernelGGL((lcc_data_bwd_march_kernel<SS, false>), grid, dim3(kStBlock), 0, st, fhat, z, sigma_m, mask,    \
+    else if (batch > 0) hipLaunchKernelGGL((lcc_data_bwd_march_kernel<SS, false, true>), grid, dim3(kStBlock), 0, st, fhat, z, sigma_m, mask, \
+                                           g_z_override, state, chain, g_warped, nll_partials, vol, seg_len, nseg, batch, f_stride, m_stride); \
+    else hipLaunchKernelGGL((lcc_data_bwd_march_kernel<SS, false, false>), grid, dim3(kStBlock), 0, st, fhat, z, sigma_m, mask,    \
                             g_z_override, state, chain, g_warped, nll_partials, vol, seg_len, nseg, batch, f_stride, m_stride);
     if (s == 1) { IRS_LCC_BWD(1) } else { IRS_LCC_BWD(2) }
 #undef IRS_LCC_BWD
