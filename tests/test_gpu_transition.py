@@ -415,7 +415,7 @@ def test_variant_prediction_never_changes_the_result(amp):
             assert torch.equal(res[mode][i], res[0][i]), (mode, what, float((res[mode][i] - res[0][i]).abs().max()))
 
 
-@pytest.mark.parametrize('N,C,kw', [(28, 3, {}), (40, 2, {'lcc_s': 2}), (33, 4, {'virtual_decimation': False})])
+@pytest.mark.parametrize('N,C,kw', [(28, 3, {}), (40, 2, {'lcc_s': 2}), (33, 4, {'virtual_decimation': False}), (30, 3, {'per_chain_images': True})])
 def test_one_data_term_launch_for_all_chains_is_the_serial_chain(N, C, kw):
     """Several chains in one engine (every reference config runs two; trainer.py:316-330 steps the shared mixture chain after chain
     and evaluates each chain's data term with the mixture ITS step left).  By default the serial loop is statistics -> step only,
@@ -423,9 +423,19 @@ def test_one_data_term_launch_for_all_chains_is_the_serial_chain(N, C, kw):
     chain against its snapshot (csrc/api.hip, `data_batch`).  Same arithmetic on the same values, same partial-sum slots: bit for
     bit the chain of the serial form (`data_batch` 0) -- velocity, mixture and optimiser state, loss terms."""
     from ir_sgmcmc_amd.data_loader import synthetic_pair
+    kw = dict(kw)
     f1, m1 = synthetic_pair((N, N, N), seed=3)
-    fixed = to_dev({k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'})
-    moving = to_dev({k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'})
+    if kw.pop('per_chain_images', False):
+        # every chain its own fixed image and mask (the interface takes one per chain): the single launch strides through them
+        fixed = {k: torch.stack([v] * C) for k, v in f1.items() if k != 'seg'}
+        moving = {k: torch.stack([v] * C) for k, v in m1.items() if k != 'seg'}
+        for c in range(1, C):
+            fixed['mask'][c, ..., : 3 * c, :] = 0                         # chain c ignores a band of rows
+            fixed['im'][c] = fixed['im'][c].roll(c, dims=-1)              # ... and sees a shifted image
+        fixed, moving = to_dev(fixed), to_dev(moving)
+    else:
+        fixed = to_dev({k: v.unsqueeze(0) for k, v in f1.items() if k != 'seg'})
+        moving = to_dev({k: v.unsqueeze(0) for k, v in m1.items() if k != 'seg'})
     g = torch.Generator().manual_seed(12)
     v0 = (2.0 * torch.randn(C, 3, N, N, N, generator=g)).to(DEV)
     res = {}
