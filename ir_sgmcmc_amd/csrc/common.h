@@ -90,6 +90,9 @@ struct Knobs {
     int fwd_rows1 = -1;        // IRS_FWD_ROWS1         forward squaring step with one output row per thread (512 threads): -1 by launch size, 0 / 1
     int lds_from = 3;          // IRS_LDS_FROM          adjoint: smallest source halo (floor(max|d_k|) + 1) the any-radius kernel takes; 3 = radius-2 gather in front of it, 2 = not
     int fwd_r2_rows1 = 1;      // IRS_FWD_R2_ROWS1      radius-2 forward squaring step with one output row per thread (512 threads)
+    int fwd_z2 = 0;            // IRS_FWD_Z2            one-row forward variant (small launches): two planes per marching step (exp_fwd_march_z2_kernel);
+                               //                       bit-identical, 0.837 against 0.843 ms at 128^3, flat with two chains and on slab ranks: off
+                               //                       (profiles/r05_fwd_z2_ab.txt)
     int fwd_pf = 2;            // IRS_FWD_PF            one-row forward variant (small launches): planes of global loads in flight ahead of the commit (1 / 2)
     int seg_fit = 1;           // IRS_SEG_FIT           squaring-step kernels: segment length from the resident-set cost model (0: power-of-two rule)
     int coarse_box = 1;        // IRS_COARSE_BOX        any-radius adjoint: source boxes from the coarse displacement extrema

@@ -1330,6 +1330,9 @@ void launch_exp_step_bwd_march(const float* G, const float* dk, float* gout, boo
 #ifndef IRS_FWD_PITCH_ALIGN
 #define IRS_FWD_PITCH_ALIGN 16
 #endif
+#ifndef IRS_FWD_WAVES
+#define IRS_FWD_WAVES 4
+#endif
 #ifndef IRS_FWD_TAPS
 // How the eight corner taps of a sample leave the LDS ring.  0: plain reads -- the compiler pairs the cx = 0 / 1 corners into
 // ds_read2_b64 + ds_read2_b32.  1 (round 5): every corner its own ds_read_b64 + ds_read_b32, through VOLATILE LDS pointers (the
@@ -1694,9 +1697,6 @@ __device__ __forceinline__ void exp_fwd_march_tile(const float* __restrict__ din
     }
 }
 
-#ifndef IRS_FWD_WAVES
-#define IRS_FWD_WAVES 4
-#endif
 #ifndef IRS_FWD_SMALL_TILES
 #define IRS_FWD_SMALL_TILES 1024  // launches of at most this many tiles (power-of-two segment rule) take the one-row-per-thread kernel
 #endif
@@ -1709,6 +1709,240 @@ __global__ __launch_bounds__(FTX * FTY / FROWS, R == 1 ? IRS_FWD_WAVES : 1) void
     const int total = (int)(tiles.x * tiles.y * tiles.z);
     for (int id = blockIdx.x; id < total; id += gridDim.x) {
         exp_fwd_march_tile<PRESCALE, R, FROWS, PF>(din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, h_lo, h_hi, swz_run, id, tiles, lay);
+        __syncthreads();  // the ring and the reduction scratch are reused by the next tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward step of SMALL launches, TWO planes per marching step (round 5, late).  The one-row-per-thread kernel above pays its
+// per-step fixed work -- barrier, loop, the wait for the newest loads, the z coordinate -- once per plane (0.5 of the 1.9 us of a
+// plane step at 128^3, profiles/r05_phase_trace_128.txt); here a step commits planes s and s + 1, passes ONE barrier and samples
+// the output planes s - 1 and s.  Radius 1, one row per thread (512 threads), ring of SIX slots (the planes s - 2 .. s + 1 being
+// sampled and the two the next step commits before its barrier: 58 KB, two workgroups per CU as before), the loads of the next
+// step's two planes in flight during the sampling.  The arithmetic of an output -- taps, weights, order of the FMAs -- is the
+// one-plane kernel's: chains bit-identical (tools/debug/chain_bits.py).
+// MEASURED (profiles/r05_fwd_z2_ab.txt): 0.835-0.839 against 0.842-0.845 ms per transition at 128^3 (-0.7 %), 0.678-0.680 against
+// 0.680-0.681 with two chains, flat at 96^3 / 64^3 and on slab ranks of 4 / 8 -- the per-step fixed work is not what the small
+// forward step loses to; what remains per row is the staging (660 halo elements on 512 threads: two passes, the second 29 % full)
+// and the sampling itself.  Below the round's 1 % line: built, kept behind `fwd_z2`, OFF.
+// ------------------------------------------------------------------------------------------------
+template <bool PRESCALE>
+__device__ __forceinline__ void exp_fwd_march_tile_z2(const float* __restrict__ din, float* __restrict__ dout, const Vol vol,
+                                                      const Lin lin, const Scale3L sc, const unsigned* __restrict__ dmax_in,
+                                                      unsigned* __restrict__ dmax_out, const int seg_len, const int nseg,
+                                                      const int h_lo, const int h_hi, const int swz_run, const int tile_id,
+                                                      const dim3 tiles, const int lay) {
+    constexpr int R = 1;
+    using M = MarchF<R, 1>;
+    constexpr int PX = M::PX, PN = M::PN, NIT = M::NIT, PITCH = M::PITCH, PNP = M::PNP, kFwdBlock = M::kFwdBlock;
+    constexpr int NS = 6;
+    __shared__ float2 r_xy[NS * PNP];  // (d0, d1)
+    __shared__ float r_z[NS * PNP];    // d2
+    __shared__ float red[3 * (kFwdBlock / kWave)];
+    const int tile_ = xcd_swizzle_runs(tile_id, (int)(tiles.x * tiles.y * tiles.z), swz_run);
+    const int tbx = tile_ % tiles.x, tby = (tile_ / tiles.x) % tiles.y, tbz = tile_ / (tiles.x * tiles.y);
+    const int chain = tbz / nseg, seg = tbz % nseg;
+    if (dmax_in) {
+        const int need = max(max((int)ceilf(__uint_as_float(dmax_in[chain * 4 + 0])), (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 1]))),
+                             (int)ceilf(__uint_as_float(dmax_in[chain * 4 + 2])));
+        if (need <= h_lo || need > h_hi) return;
+    }
+    const int ox = tbx * FTX, oy = tby * FTY;
+    int z0, z1;
+    seg_range(vol, seg, seg_len, z0, z1);
+    const int64_t V = vol.V;
+    const int64_t cb = (int64_t)chain * 3 * V;
+    auto run = [&](auto LC) {  // layouts as compile-time constants (see exp_fwd_march_tile)
+    constexpr int LAYC = decltype(LC)::value;
+    const Lay3 LD = lay3(LAYC & 1, V), LO = lay3(LAYC & 4, V);
+    const float* __restrict__ dx_ = din + cb;
+    const float* __restrict__ dy_ = dx_ + LD.cs;
+    const float* __restrict__ dz_ = dy_ + LD.cs;
+    float* __restrict__ o = dout + cb;
+    const int lx = threadIdx.x % FTX, ly = threadIdx.x / FTX;
+    const int x = ox + lx, y = oy + ly;
+    const bool live = x < vol.W && y < vol.H;
+    const float linx = x < vol.W ? lin.x[x] : 0.0f;
+    const float liny = lin.y[min(y, vol.H - 1)];
+
+    int sxy[NIT], sld[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * kFwdBlock;
+        const int px = i % PX, py = i / PX;
+        const int cx = min(max(ox - R + px, 0), vol.W - 1), cy = min(max(oy - R + py, 0), vol.H - 1);
+        sxy[it] = i < PN ? cy * vol.W + cx : -1;
+        sld[it] = py * PITCH + px;
+    }
+    float pre[2][NIT][3];
+    auto prefetch = [&](int s, float (&pre)[NIT][3]) {
+        const int sc_ = min(max(s, 0), vol.D - 1);  // planes outside the volume replicate the border plane
+        const int64_t zo = (int64_t)sc_ * vol.H * vol.W * LD.em;
+        const float* __restrict__ px_ = dx_ + zo;
+        const float* __restrict__ py_ = dy_ + zo;
+        const float* __restrict__ pz_ = dz_ + zo;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (sxy[it] < 0) continue;
+            const unsigned g = (unsigned)sxy[it] * 4u * (unsigned)LD.em;
+            if (LD.em == 3) {
+                const F3 v = ld3_off(px_, g);
+                pre[it][0] = v.x;
+                pre[it][1] = v.y;
+                pre[it][2] = v.z;
+            } else {
+                pre[it][0] = ld_off(px_, g);
+                pre[it][1] = ld_off(py_, g);
+                pre[it][2] = ld_off(pz_, g);
+            }
+        }
+    };
+    auto commit = [&](int slot, const float (&pre)[NIT][3]) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (sxy[it] < 0) continue;
+            const int i = slot * PNP + sld[it];
+            r_xy[i] = make_float2(PRESCALE ? prescale(pre[it][0], sc.nm1[0], sc.rnm1[0], sc.inv_pow) : pre[it][0],
+                                  PRESCALE ? prescale(pre[it][1], sc.nm1[1], sc.rnm1[1], sc.inv_pow) : pre[it][1]);
+            r_z[i] = PRESCALE ? prescale(pre[it][2], sc.nm1[2], sc.rnm1[2], sc.inv_pow) : pre[it][2];
+        }
+    };
+
+    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
+    // one output of plane zo, whose own value sits in ring slot `a` (a compile-time constant at every call site)
+    auto sample = [&](const int zo, const int a, const float linz) {
+        const int ci = a * PNP + (ly + R) * PITCH + (lx + R);
+        const float2 dxy = r_xy[ci];
+        const float d0 = dxy.x, d1 = dxy.y, d2 = r_z[ci];
+        const AxisTap tx = axis_tap(__fadd_rn(linx, d0), vol.W);
+        const AxisTap ty = axis_tap(__fadd_rn(liny, d1), vol.H);
+        const AxisTap tz = axis_tap(__fadd_rn(linz, d2), vol.D);
+        const int bx0 = tx.i0 - (ox - R), by0 = ty.i0 - (oy - R), rel = tz.i0 - zo;
+        const bool in_ring = (unsigned)bx0 < (unsigned)(PX - 1) && (unsigned)by0 < (unsigned)(M::PY - 1) && rel >= -R && rel < R;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+        auto ring_taps = [&]() {
+            const float wxy[2][2] = {{__fmul_rn(tx.w0, ty.w0), __fmul_rn(tx.w1, ty.w0)}, {__fmul_rn(tx.w0, ty.w1), __fmul_rn(tx.w1, ty.w1)}};
+            // rel is -1 or 0: planes zo - 1, zo or zo, zo + 1
+            const int sl0 = (rel == 0 ? a : (a - 1 + NS) % NS) * PNP, sl1 = (rel == 0 ? (a + 1) % NS : a) * PNP;
+            const int off = by0 * PITCH + bx0;
+#pragma unroll
+            for (int cz = 0; cz < 2; ++cz) {
+                const int bs = (cz ? sl1 : sl0) + off;
+#pragma unroll
+                for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                    for (int cx = 0; cx < 2; ++cx) {
+                        const float w = __fmul_rn(wxy[cy][cx], cz ? tz.w1 : tz.w0);
+                        typedef float VF2 __attribute__((ext_vector_type(2)));  // single reads: see IRS_FWD_TAPS
+                        const VF2 tv = *(const volatile __attribute__((address_space(3))) VF2*)(&r_xy[bs + cy * PITCH + cx]);
+                        const float t1 = *(const volatile __attribute__((address_space(3))) float*)(&r_z[bs + cy * PITCH + cx]);
+                        a0 = fmaf(tv.x, w, a0);
+                        a1 = fmaf(tv.y, w, a1);
+                        a2 = fmaf(t1, w, a2);
+                    }
+            }
+        };
+        if (__all(in_ring)) {
+            ring_taps();
+        } else if (in_ring) {
+            ring_taps();
+        } else {
+#pragma unroll
+            for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+                for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                    for (int cx = 0; cx < 2; ++cx) {
+                        const float w = __fmul_rn(__fmul_rn(cx ? tx.w1 : tx.w0, cy ? ty.w1 : ty.w0), cz ? tz.w1 : tz.w0);
+                        const int64_t idx = (((int64_t)(cz ? tz.i1 : tz.i0) * vol.H + (cy ? ty.i1 : ty.i0)) * vol.W + (cx ? tx.i1 : tx.i0)) * LD.em;
+                        a0 = fmaf(ldp<PRESCALE>(dx_, idx, sc.nm1[0], sc.rnm1[0], sc.inv_pow), w, a0);
+                        a1 = fmaf(ldp<PRESCALE>(dy_, idx, sc.nm1[1], sc.rnm1[1], sc.inv_pow), w, a1);
+                        a2 = fmaf(ldp<PRESCALE>(dz_, idx, sc.nm1[2], sc.rnm1[2], sc.inv_pow), w, a2);
+                    }
+        }
+        const int64_t pl = (int64_t)zo * vol.H * vol.W * LO.em;
+        const unsigned g = (unsigned)(y * vol.W + x) * 4u * (unsigned)LO.em;
+        const float r0 = __fadd_rn(d0, a0), r1 = __fadd_rn(d1, a1), r2 = __fadd_rn(d2, a2);
+        if (LO.em == 3) {
+            st3_off(o + pl, g, r0, r1, r2);
+        } else {
+            st_off(o + pl, g, r0);
+            st_off(o + LO.cs + pl, g, r1);
+            st_off(o + 2 * LO.cs + pl, g, r2);
+        }
+        m0 = fmaxf(m0, fabsf(r0));
+        m1 = fmaxf(m1, fabsf(r1));
+        m2 = fmaxf(m2, fabsf(r2));
+    };
+
+    // planes sbase .. slast are staged, two per step: step i commits sbase + 2 i and sbase + 2 i + 1 (a plane beyond slast is a clamped,
+    // harmless re-read that nothing samples) and samples the outputs one plane behind each
+    const int sbase = z0 - R, slast = z1 - 1 + R;
+    float linz_a = lin.z[min(max(sbase - R, 0), vol.D - 1)], linz_b = lin.z[min(max(sbase + 1 - R, 0), vol.D - 1)];
+    prefetch(sbase, pre[0]);
+    prefetch(sbase + 1, pre[1]);
+    for (int sb = sbase; sb <= slast; sb += NS) {
+#pragma unroll
+        for (int PH = 0; PH < NS; PH += 2) {
+            const int s = sb + PH;
+            if (s > slast) break;
+            commit(PH, pre[0]);
+            commit(PH + 1, pre[1]);
+            const float lz0 = linz_a, lz1 = linz_b;
+            linz_a = lin.z[min(max(s + 2 - R, 0), vol.D - 1)];  // (before the prefetch: the load counter completes in order)
+            linz_b = lin.z[min(max(s + 3 - R, 0), vol.D - 1)];
+            if (s + 2 <= slast) {
+                prefetch(s + 2, pre[0]);
+                prefetch(s + 3, pre[1]);
+            }
+            __syncthreads();
+            const int zo = s - R;
+            if (live && zo >= z0 && zo < z1) sample(zo, (PH - R + NS) % NS, lz0);
+            if (live && zo + 1 >= z0 && zo + 1 < z1) sample(zo + 1, PH, lz1);
+        }
+    }
+    if (dmax_out) {
+        m0 *= 0.5f * sc.nm1[0];
+        m1 *= 0.5f * sc.nm1[1];
+        m2 *= 0.5f * sc.nm1[2];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            m0 = fmaxf(m0, __shfl_down(m0, off, kWave));
+            m1 = fmaxf(m1, __shfl_down(m1, off, kWave));
+            m2 = fmaxf(m2, __shfl_down(m2, off, kWave));
+        }
+        const int wid = threadIdx.x / kWave;
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            red[wid] = m0;
+            red[(kFwdBlock / kWave) + wid] = m1;
+            red[2 * (kFwdBlock / kWave) + wid] = m2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float m = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kFwdBlock / kWave; ++w) m = fmaxf(m, red[threadIdx.x * (kFwdBlock / kWave) + w]);
+            unsigned* slot = dmax_out + chain * 4 + threadIdx.x;
+            if (__float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_nonneg(slot, m);
+        }
+    }
+    };  // run
+    switch (lay & 5) {
+        case 0: run(LayC<0>{}); break;
+        case 1: run(LayC<1>{}); break;
+        case 4: run(LayC<4>{}); break;
+        default: run(LayC<5>{}); break;
+    }
+}
+
+template <bool PRESCALE>
+__global__ __launch_bounds__(FTX * FTY, IRS_FWD_WAVES) void exp_fwd_march_z2_kernel(const float* __restrict__ din, float* __restrict__ dout, Vol vol, Lin lin,
+                                                                        Scale3L sc, const unsigned* __restrict__ dmax_in,
+                                                                        unsigned* __restrict__ dmax_out, int seg_len, int nseg, int h_lo,
+                                                                        int h_hi, int swz_run, dim3 tiles, int lay) {
+    const int total = (int)(tiles.x * tiles.y * tiles.z);
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+        exp_fwd_march_tile_z2<PRESCALE>(din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, h_lo, h_hi, swz_run, id, tiles, lay);
         __syncthreads();  // the ring and the reduction scratch are reused by the next tile
     }
 }
@@ -1749,7 +1983,8 @@ void launch_exp_step_fwd_march(const float* din, float* dout, bool prescale_in, 
 #define IRS_FWM2(P, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 2>), dim3(GRID), dim3(FTX * FTY / FROWS_BIG), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg2, nseg2, LO, HI, (GRID) == total2 ? swz_run : 0, tiles2, lay)
 #define IRS_FW2(P, LO, HI, GRID) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 2, 1>), dim3(GRID), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg2, nseg2, LO, HI, (GRID) == total2 ? swz_run : 0, tiles2, lay)
 #define IRS_FWS(P, LO, HI)                                                                                                      \
-    if (global_knobs().fwd_pf >= 2) IRS_FWS_(P, 2, LO, HI);                                                                     \
+    if (global_knobs().fwd_z2) hipLaunchKernelGGL((exp_fwd_march_z2_kernel<P>), dim3(total), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run, tiles, lay); \
+    else if (global_knobs().fwd_pf >= 2) IRS_FWS_(P, 2, LO, HI);                                                                \
     else IRS_FWS_(P, 1, LO, HI)
 #define IRS_FWS_(P, PFF, LO, HI) hipLaunchKernelGGL((exp_fwd_march_kernel<P, 1, 1, PFF>), dim3(total), dim3(FTX * FTY), 0, st, din, dout, vol, lin, sc, dmax_in, dmax_out, seg_len, nseg, LO, HI, swz_run, tiles, lay)
     // the radius-2 variant's own segments (as for the adjoint): a persistent grid of what the chip holds of it, four run-in planes
