@@ -1725,6 +1725,8 @@ __global__ __launch_bounds__(FTX * FTY / FROWS, R == 1 ? IRS_FWD_WAVES : 1) void
 // 0.680-0.681 with two chains, flat at 96^3 / 64^3 and on slab ranks of 4 / 8 -- the per-step fixed work is not what the small
 // forward step loses to; what remains per row is the staging (660 halo elements on 512 threads: two passes, the second 29 % full)
 // and the sampling itself.  Below the round's 1 % line: built, kept behind `fwd_z2`, OFF.
+// (A second form staged the halo planes of both source planes as ONE list -- three passes of the 512 threads, 86 % of the lanes,
+// instead of four -- : digests equal again, 0.836-0.838 against 0.835-0.838 ms, no gain at all; not kept.)
 // ------------------------------------------------------------------------------------------------
 template <bool PRESCALE>
 __device__ __forceinline__ void exp_fwd_march_tile_z2(const float* __restrict__ din, float* __restrict__ dout, const Vol vol,
