@@ -409,7 +409,7 @@ int irs_slab_trace(const irs_config* cfg, const irs_slab_config* scfg, int rank,
  * ctx == NULL -- process-wide (the stateless operators and every context created later).  Names: predict_variants,
  * run_ahead, fuse_warp_bwd, energy_in_update, fuse_noise, recover, fwd_rows1, coarse_box, sobolev_tile, march_seg,
  * march_seg_fwd, swz_run, seg_min_blocks, seg_min_len, sobolev_seg, lcc_seg, stats_seg, update_seg, slab_split, slab_exact,
- * slab_force_h, slab_buffers, ps_rows, fwd_z2, data_batch, chain_overlap, launch_log (csrc/common.h: Knobs).  The reference has no counterpart (it has one code path). */
+ * slab_force_h, slab_buffers, ps_rows, fwd_z2, tile_box, data_batch, chain_overlap, launch_log (csrc/common.h: Knobs).  The reference has no counterpart (it has one code path). */
 int irs_option_set(irs_ctx* ctx, const char* name, int value);
 
 const char* irs_last_error(void);

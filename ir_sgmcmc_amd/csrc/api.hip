@@ -47,6 +47,7 @@ static Knobs knobs_from_env() {
     k.seg_fit = env_or("IRS_SEG_FIT", k.seg_fit);
     k.fwd_pf = env_or("IRS_FWD_PF", k.fwd_pf);
     k.fwd_z2 = env_or("IRS_FWD_Z2", k.fwd_z2);
+    k.tile_box = env_or("IRS_TILE_BOX", k.tile_box);
     k.fwd_r2_rows1 = env_or("IRS_FWD_R2_ROWS1", k.fwd_r2_rows1);
     k.ps_rows = env_or("IRS_PS_ROWS", k.ps_rows);
     const char* tile = getenv("IRS_SOBOLEV_TILE");
@@ -117,7 +118,7 @@ int knob_set(Knobs& k, const char* name, int value, bool on_context) {
         {"energy_in_update", &Knobs::energy_in_update, KN_CTX}, {"fuse_noise", &Knobs::fuse_noise, KN_CTX}, {"recover", &Knobs::recover, KN_CTX},
         {"chain_overlap", &Knobs::chain_overlap, KN_CTX}, {"data_batch", &Knobs::data_batch, KN_CTX}, {"slab_split", &Knobs::slab_split, KN_CTX}, {"slab_buffers", &Knobs::slab_buffers, KN_CTX}, {"slab_exact", &Knobs::slab_exact, KN_CTX}, {"slab_force_h", &Knobs::slab_force_h, KN_CTX},
         {"fwd_rows1", &Knobs::fwd_rows1, KN_GLOBAL}, {"coarse_box", &Knobs::coarse_box, KN_GLOBAL}, {"lds_from", &Knobs::lds_from, KN_GLOBAL},
-        {"fwd_pf", &Knobs::fwd_pf, KN_GLOBAL}, {"fwd_z2", &Knobs::fwd_z2, KN_GLOBAL}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1, KN_GLOBAL}, {"sobolev_tile", &Knobs::sobolev_tile, KN_GLOBAL},
+        {"fwd_pf", &Knobs::fwd_pf, KN_GLOBAL}, {"fwd_z2", &Knobs::fwd_z2, KN_GLOBAL}, {"tile_box", &Knobs::tile_box, KN_GLOBAL}, {"fwd_r2_rows1", &Knobs::fwd_r2_rows1, KN_GLOBAL}, {"sobolev_tile", &Knobs::sobolev_tile, KN_GLOBAL},
         {"march_seg", &Knobs::march_seg, KN_GLOBAL}, {"march_seg_fwd", &Knobs::march_seg_fwd, KN_GLOBAL}, {"swz_run", &Knobs::swz_run, KN_GLOBAL},
         {"sobolev_seg", &Knobs::sobolev_seg, KN_GLOBAL}, {"ps_rows", &Knobs::ps_rows, KN_GLOBAL}, {"launch_log", &Knobs::launch_log, KN_GLOBAL},
         {"seg_fit", &Knobs::seg_fit, KN_LAYOUT}, {"seg_min_blocks", &Knobs::seg_min_blocks, KN_LAYOUT}, {"seg_min_len", &Knobs::seg_min_len, KN_LAYOUT},

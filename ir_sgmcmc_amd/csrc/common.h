@@ -93,6 +93,7 @@ struct Knobs {
     int fwd_z2 = 0;            // IRS_FWD_Z2            one-row forward variant (small launches): two planes per marching step (exp_fwd_march_z2_kernel);
                                //                       bit-identical, 0.837 against 0.843 ms at 128^3, flat with two chains and on slab ranks: off
                                //                       (profiles/r05_fwd_z2_ab.txt)
+    int tile_box = 1;          // IRS_TILE_BOX          any-radius adjoint: source boxes / scales of its tiles from tile_box_kernel (0: every workgroup its own)
     int fwd_pf = 2;            // IRS_FWD_PF            one-row forward variant (small launches): planes of global loads in flight ahead of the commit (1 / 2)
     int seg_fit = 1;           // IRS_SEG_FIT           squaring-step kernels: segment length from the resident-set cost model (0: power-of-two rule)
     int coarse_box = 1;        // IRS_COARSE_BOX        any-radius adjoint: source boxes from the coarse displacement extrema

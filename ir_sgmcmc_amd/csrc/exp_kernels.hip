@@ -188,6 +188,79 @@ __global__ __launch_bounds__(kWave) void coarse_minmax_kernel(const float* __res
     }
 }
 
+// Source box and fixed-point scale of every tile of the any-radius kernel, one wavefront per tile (round 5, late): the same two rounds
+// over the coarse cells that a workgroup of exp_bwd_lds_kernel otherwise runs at the start of each of its tiles -- 256 threads, two
+// block reductions, four barriers, two dependent global round trips: 5.8 of the 38 us of a tile (profiles/r05_lds_phase_trace.txt).
+// Minima / maxima do not depend on the order they are taken in: the boxes and scales are the in-kernel ones, bit for bit.
+// boxes[tile]: lo[3], hi[3] (int bits), max |G| of the box, unused.
+constexpr int kBoxWords = 8;
+// (A small persistent grid of four-wavefront workgroups, every wavefront striding over the tiles: launched for a step whose chains all
+// stay with the gather kernels -- the host predicts, the device decides -- it costs the dispatch of 512 workgroups, not of one per tile.)
+constexpr int kBoxBlock = 4 * kWave, kBoxGrid = 512;
+__global__ __launch_bounds__(kBoxBlock) void tile_box_kernel(const float* __restrict__ cmm, float* __restrict__ boxes, Vol vol,
+                                                             const unsigned* __restrict__ dmax, TileGrid tg, int gather_radius) {
+  const int lane = (int)threadIdx.x & (kWave - 1);
+  for (int tile = (int)blockIdx.x * (kBoxBlock / kWave) + (int)threadIdx.x / kWave; tile < tg.total; tile += (int)gridDim.x * (kBoxBlock / kWave)) {
+    int t_ = tile;
+    const int ox = (t_ % tg.ntx) * ETX;
+    t_ /= tg.ntx;
+    const int oy = (t_ % tg.nty) * ETY;
+    t_ /= tg.nty;
+    const int oz = vol.z0 + (t_ % tg.ntz) * ETZ;
+    const int chain = t_ / tg.ntz;
+    const int hx = (int)floorf(__uint_as_float(dmax[chain * 4 + 0])) + 1;
+    const int hy = (int)floorf(__uint_as_float(dmax[chain * 4 + 1])) + 1;
+    const int hz = (int)floorf(__uint_as_float(dmax[chain * 4 + 2])) + 1;
+    if (hx <= gather_radius && hy <= gather_radius && hz <= gather_radius) continue;  // a gather kernel owns this chain
+    const int zend = min(oz + ETZ, vol.z0 + vol.nz) - 1;
+    int lo[3] = {max(ox - hx, 0), max(oy - hy, 0), max(oz - hz, 0)};
+    int hi[3] = {min(ox + ETX - 1 + hx, vol.W - 1), min(oy + ETY - 1 + hy, vol.H - 1), min(zend + hz, vol.D - 1)};
+    float gmax = 0.0f;
+    const int nax[3] = {vol.W, vol.H, vol.D};
+    const int tlo[3] = {ox, oy, oz};
+    const int thi[3] = {min(ox + ETX, vol.W) - 1, min(oy + ETY, vol.H) - 1, min(zend, vol.D - 1)};
+    const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.D + kCell - 1) / kCell;
+    const float* __restrict__ cm = cmm + (int64_t)chain * ncx * ncy * ncz * kCmm;
+    for (int round = 0; round < 2; ++round) {
+        const int c0x = lo[0] / kCell, c0y = lo[1] / kCell, c0z = lo[2] / kCell;
+        const int nx_ = hi[0] / kCell - c0x + 1, ny_ = hi[1] / kCell - c0y + 1, nz_ = hi[2] / kCell - c0z + 1;
+        float m7[kCmm] = {3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 0.0f};
+        for (int i = lane; i < nx_ * ny_ * nz_; i += kWave) {
+            const int cell = ((c0z + i / (nx_ * ny_)) * ncy + c0y + (i / nx_) % ny_) * ncx + c0x + i % nx_;
+#pragma unroll
+            for (int j = 0; j < kCmm; ++j) {
+                const float o = cm[cell * kCmm + j];
+                m7[j] = (j < 6 && !(j & 1)) ? fminf(m7[j], o) : fmaxf(m7[j], o);
+            }
+        }
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1)
+#pragma unroll
+            for (int j = 0; j < kCmm; ++j) {
+                const float o = __shfl_xor(m7[j], off, kWave);
+                m7[j] = (j < 6 && !(j & 1)) ? fminf(m7[j], o) : fmaxf(m7[j], o);
+            }
+        gmax = m7[6];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float mn = m7[2 * a], mx = m7[2 * a + 1];
+            if (!(mn <= mx) || fabsf(mn) > 1.0e6f || fabsf(mx) > 1.0e6f) continue;  // (exp_bwd_lds_kernel: no usable extrema -> keep the box)
+            if (tlo[a] - 1 > 0) lo[a] = max(lo[a], (int)floorf((float)(tlo[a] - 1) - mx - 1e-3f));
+            if (thi[a] + 1 < nax[a] - 1) hi[a] = min(hi[a], (int)ceilf((float)(thi[a] + 1) - mn + 1e-3f));
+        }
+    }
+    if (lane == 0) {
+        float* b = boxes + (int64_t)tile * kBoxWords;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            b[a] = __int_as_float(lo[a]);
+            b[3 + a] = __int_as_float(hi[a]);
+        }
+        b[6] = gmax;
+    }
+  }
+}
+
 // corner contributions of one source voxel that land in the owned tile
 // (gx, gy, gz): the source's sampling coordinates lin[.] + d, formed by the caller
 __device__ __forceinline__ void adjoint_scatter(const float gx, const float gy, const float gz, const int ox, const int oy, const int oz,
@@ -320,7 +393,7 @@ __global__ __launch_bounds__(kExpBlock, H == 0 ? IRS_LDS_WAVES : 2) void exp_bwd
                                                                 float* __restrict__ gout, Vol vol, Lin lin, Scale3L sc,
                                                                 const unsigned* __restrict__ dmax, TileGrid tg,
                                                                 int gather_radius, const float* __restrict__ gscale, int lay,
-                                                                const float* __restrict__ cmm) {
+                                                                const float* __restrict__ cmm, const float* __restrict__ boxes) {
     using B = ExpBox<H>;
     const Lay3 LD = lay3(lay & 1, vol.V), LG = lay3(lay & 2, vol.V), LO = lay3(lay & 4, vol.V);
     constexpr bool STAGED = H > 0;  // H = 0: no staged copy of d at all (sources and taps are far from the tile anyway)
@@ -394,7 +467,15 @@ __global__ __launch_bounds__(kExpBlock, H == 0 ? IRS_LDS_WAVES : 2) void exp_bwd
         }
         __syncthreads();  // bred is reused
     };
-    if (cmm) {
+    if (boxes) {  // source box and max |G| of this tile from tile_box_kernel (the same values as the rounds below produce)
+        const float* __restrict__ b = boxes + (int64_t)tile * kBoxWords;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = __float_as_int(b[a]);
+            hi[a] = __float_as_int(b[3 + a]);
+        }
+        gmax = b[6];
+    } else if (cmm) {
         const int nax[3] = {vol.W, vol.H, vol.D};
         const int tlo[3] = {ox, oy, oz};
         const int thi[3] = {min(ox + ETX, vol.W) - 1, min(oy + ETY, vol.H) - 1, min(zend, vol.D - 1)};
@@ -593,8 +674,14 @@ __global__ __launch_bounds__(kExpBlock, H == 0 ? IRS_LDS_WAVES : 2) void exp_bwd
   }
 }
 
+static size_t coarse_cells_floats(Vol vol, int C) {
+    const size_t n = kCmm * (size_t)C * ((vol.W + kCell - 1) / kCell) * ((vol.H + kCell - 1) / kCell) * ((vol.D + kCell - 1) / kCell);
+    return (n + 63) / 64 * 64;
+}
+// the coarse cells, then the per-tile boxes of tile_box_kernel (a launch window never has more tiles than the whole volume)
 size_t coarse_minmax_bytes(Vol vol, int C) {
-    return sizeof(float) * kCmm * (size_t)C * ((vol.W + kCell - 1) / kCell) * ((vol.H + kCell - 1) / kCell) * ((vol.D + kCell - 1) / kCell);
+    const size_t tiles = (size_t)C * ((vol.W + ETX - 1) / ETX) * ((vol.H + ETY - 1) / ETY) * ((vol.D + ETZ - 1) / ETZ + 1);
+    return sizeof(float) * (coarse_cells_floats(vol, C) + tiles * kBoxWords);
 }
 
 void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool prescale_in, int no_steps, int C, Vol vol,
@@ -611,12 +698,17 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
     (void)exp_grid(vol, C, &tz);
 
     const Scale3L sc = make_scale_l(vol, no_steps);
+    float* boxes = nullptr;
     if (!global_knobs().coarse_box) cmm = nullptr;  // parity test of the two source boxes
     if (cmm) {  // coarse displacement extrema / gradient maxima (coarse_minmax_bytes(vol, C) of scratch)
         const int ncx = (vol.W + kCell - 1) / kCell, ncy = (vol.H + kCell - 1) / kCell, ncz = (vol.D + kCell - 1) / kCell;
         const dim3 cg((unsigned)(((ncx + 7) / 8) * ncy * ncz), (unsigned)C);
         if (prescale_in) hipLaunchKernelGGL((coarse_minmax_kernel<true>), cg, dim3(kWave), 0, st, dk, G, gscale, cmm, vol, sc, dmax, gather_radius, ncx, ncy, ncz, lay);
         else hipLaunchKernelGGL((coarse_minmax_kernel<false>), cg, dim3(kWave), 0, st, dk, G, gscale, cmm, vol, sc, dmax, gather_radius, ncx, ncy, ncz, lay);
+        if (global_knobs().tile_box) {  // ... and from them the source box + scale of every tile, one wavefront each
+            boxes = cmm + coarse_cells_floats(vol, C);
+            hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)min((tz.total + 3) / 4, kBoxGrid)), dim3(kBoxBlock), 0, st, cmm, boxes, vol, dmax, tz, gather_radius);
+        }
     }
     // the persistent grid is ONE resident set of workgroups (asked from the runtime once per variant): a grid that is not a
     // multiple of it leaves a partial last round in which most of the chip idles
@@ -632,7 +724,7 @@ void launch_exp_step_bwd_lds(const float* G, const float* dk, float* gout, bool 
                 resident = kExpGridCap;                                                                                          \
         }                                                                                                                        \
         const dim3 g_((unsigned)(tz.total < resident ? tz.total : resident));                                                    \
-        hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), g_, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay, cmm); \
+        hipLaunchKernelGGL((exp_bwd_lds_kernel<P, HH>), g_, dim3(kExpBlock), 0, st, G, dk, gout, vol, lin, sc, dmax, tz, gather_radius, gscale, lay, cmm, (const float*)boxes); \
     } while (0)
     // With the gather variants in front (gather_radius >= 2) the staged box of d around the tile is of little use (sources
     // and taps are far away): H = 0 stages nothing (49 KB of accumulators instead of 111 KB of LDS -> three workgroups per CU)
