@@ -157,7 +157,9 @@ def side_run(N, loss, init, amp, steps, warmup, dev, timed_reps=0, chains=1, sig
     # A sub-millisecond transition (128^3) leaves the host a fraction of a millisecond to wake up from the run-ahead wait and enqueue
     # the next one: on a box whose cores are busy with somebody else's work one repetition now and then comes out 20 % long.  Three
     # repetitions of the timed loop, the MEDIAN reported, every repetition listed.
-    reps = 3 if N <= 128 else 1
+    # (The same at 256^3 for the short side runs: 25 transitions are 0.12 s, and a single host stall of 20 ms -- seen once in round 5 on the SSD
+    # line: 5.59 ms where eight runs on another box measured 4.68-4.77 -- is 16 % of such a window.)
+    reps = 3 if (N <= 128 or steps <= 100) else 1
     rep_ms = []
     for _ in range(reps):
         torch.cuda.synchronize(dev)
